@@ -1,0 +1,634 @@
+// afhip_api.hip — C-ABI entry points, plan lowering and kernel dispatch (include/aggfly_hip.h).
+//
+// Lowering (afhip_plan_create) turns the column list into
+//   * one inner accumulator set (STAT mode) + deduplicated threshold slots evaluated on
+//     raw data, + one ColOp per column (source, transform, outer reducer);
+//   * a chunk table over time: chunks are ranges of whole inner groups; a chunk either
+//     holds whole outer periods (each emits its final value) or is a piece of one long
+//     period (it emits a partial that k_combine_slots merges in time order);
+//   * the kernel variant (dtype, LDS-DMA or direct loads, STAT, slots, columns).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aggfly_hip.h"
+#include "afhip_kernels.h"
+#include "afhip_panel_kernels.h"
+#include "afhip_variants.h"
+
+using namespace afhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(AFHIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+int g_cu_count_cache = -1;
+int cu_count() {
+    if (g_cu_count_cache < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_cu_count_cache = p.multiProcessorCount;
+        else
+            g_cu_count_cache = 256;
+    }
+    return g_cu_count_cache;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const std::vector<T>& h) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = h.size();
+        size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        HIP_TRY(hipMalloc((void**)&p, bytes));
+        if (n) HIP_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        return AFHIP_OK;
+    }
+};
+
+}  // namespace
+
+struct afhip_csr {
+    int64_t R = 0, nnz = 0, n_cells = 0;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> cols;
+    DevBuf<double> w;
+};
+
+struct afhip_plan {
+    afhip_plan_desc desc{};
+    std::vector<int64_t> ib, ob;          // host copies
+    std::vector<afhip_column> columns;
+    // lowering
+    int stat = 0, nthr = 0, K = 0;
+    std::vector<ThrSlot> thr;
+    std::vector<ColOp> cols;
+    std::vector<ChunkDesc> chunks;
+    std::vector<int32_t> emit;
+    std::vector<int32_t> slot_ptr;        // [P+1]
+    int64_t n_slots = 0;
+    const Variant* variant = nullptr;
+    int64_t tiles = 0;
+    // device tables
+    DevBuf<int64_t> d_ib, d_ob;
+    DevBuf<int32_t> d_emit;
+    DevBuf<ChunkDesc> d_chunks;
+    DevBuf<int32_t> d_slot_ptr;
+    // workspace
+    int64_t ws_partial = 0, ws_panel = 0;   // byte sizes
+    void* own_ws = nullptr;
+    int64_t own_ws_bytes = 0;
+    double* sums = nullptr;
+    int64_t sums_bytes = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    ~afhip_plan() {
+        if (own_ws) (void)hipFree(own_ws);
+        if (sums) (void)hipFree(sums);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------
+extern "C" const char* afhip_last_error(void) { return g_err.c_str(); }
+extern "C" int afhip_abi_version(void) { return AFHIP_ABI_VERSION; }
+
+extern "C" int afhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int afhip_device_info(int dev, char* name, int name_len, char* arch, int arch_len,
+                                 int* n_cus, int64_t* hbm_bytes) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name);
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+    if (n_cus) *n_cus = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return AFHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR
+// ---------------------------------------------------------------------------------------
+extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, const double* w,
+                                int64_t R, int64_t nnz, int64_t n_cells, afhip_csr** out) {
+    if (!out) return fail(AFHIP_E_INVALID, "csr_create: out is NULL");
+    *out = nullptr;
+    if (R < 0 || nnz < 0 || n_cells <= 0 || !indptr || (nnz && (!cols || !w)))
+        return fail(AFHIP_E_INVALID, "csr_create: bad sizes/pointers (R=%lld nnz=%lld n_cells=%lld)",
+                    (long long)R, (long long)nnz, (long long)n_cells);
+    if (n_cells > INT32_MAX) return fail(AFHIP_E_INVALID, "csr_create: n_cells exceeds int32");
+    if (indptr[0] != 0 || indptr[R] != nnz) return fail(AFHIP_E_INVALID, "csr_create: indptr[0] != 0 or indptr[R] != nnz");
+    for (int64_t r = 0; r < R; ++r)
+        if (indptr[r + 1] < indptr[r]) return fail(AFHIP_E_INVALID, "csr_create: indptr not monotone at row %lld", (long long)r);
+    std::vector<int32_t> c32((size_t)nnz);
+    for (int64_t j = 0; j < nnz; ++j) {
+        if (cols[j] < 0 || cols[j] >= n_cells)
+            return fail(AFHIP_E_INVALID, "csr_create: column %lld out of range at entry %lld", (long long)cols[j], (long long)j);
+        c32[(size_t)j] = (int32_t)cols[j];
+    }
+    auto* h = new afhip_csr();
+    h->R = R; h->nnz = nnz; h->n_cells = n_cells;
+    int rc;
+    if ((rc = h->indptr.upload(std::vector<int64_t>(indptr, indptr + R + 1))) ||
+        (rc = h->cols.upload(c32)) ||
+        (rc = h->w.upload(std::vector<double>(w, w + nnz)))) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return AFHIP_OK;
+}
+
+extern "C" void afhip_csr_destroy(afhip_csr* csr) { delete csr; }
+
+static int launch_spmm(const afhip_csr* csr, const double* X, double* out, int64_t Q, hipStream_t st) {
+    const int64_t n = csr->R * Q;
+    if (n == 0) return AFHIP_OK;
+    const unsigned blocks = (unsigned)((n + WG - 1) / WG);
+    hipLaunchKernelGGL(k_csr_spmm, dim3(blocks), dim3(WG), 0, st, csr->indptr.p, csr->cols.p, csr->w.p, X, out, csr->R, Q);
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
+                                   double* out_dev, void* stream) {
+    if (!csr || !block_dev || !out_dev || nt < 0) return fail(AFHIP_E_INVALID, "scatter_block: bad arguments");
+    return launch_spmm(csr, block_dev, out_dev, nt, (hipStream_t)stream);
+}
+
+extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int64_t K, int64_t nt,
+                                  double* num_dev, double* den_dev, double* res_dev, void* stream) {
+    if (!csr || !x_dev || !res_dev || K <= 0 || nt < 0) return fail(AFHIP_E_INVALID, "spatial_wavg: bad arguments");
+    if (nt == 0) return AFHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t C = csr->n_cells, Q = (K + 1) * nt;
+    double *panel = nullptr, *sums = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&panel, (size_t)(C * Q) * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&sums, (size_t)std::max<int64_t>(csr->R * Q, 1) * sizeof(double), st));
+    {
+        const int64_t n = C * nt;
+        hipLaunchKernelGGL(k_validity_panel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, x_dev, panel, C, nt, (int)K);
+        HIP_TRY(hipGetLastError());
+    }
+    int rc = launch_spmm(csr, panel, sums, Q, st);
+    if (rc) return rc;
+    {
+        const int64_t n = K * csr->R * nt;
+        if (n) {
+            hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, sums, num_dev, den_dev, res_dev, csr->R, nt, (int)K);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipFreeAsync(panel, st));
+    HIP_TRY(hipFreeAsync(sums, st));
+    return AFHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// plan lowering
+// ---------------------------------------------------------------------------------------
+static bool is_stat(int c) { return c >= AFHIP_MEAN && c <= AFHIP_NANMEAN; }
+
+static int add_thr_slot(std::vector<ThrSlot>& thr, const double* a3, bool bins) {
+    ThrSlot s{};
+    s.t0 = a3[0]; s.t1 = a3[1];
+    s.base = (a3[2] == 0.0) ? a3[0] : a3[1];            // nb_kernels.py:167
+    s.a = bins ? 0.0 : 1.0; s.b = bins ? 1.0 : 0.0;
+    s.nan_poisons = bins ? 0 : 1;
+    for (size_t i = 0; i < thr.size(); ++i)
+        if (!memcmp(&thr[i], &s, sizeof s)) return (int)i;
+    thr.push_back(s);
+    return (int)thr.size() - 1;
+}
+
+static int lower_columns(afhip_plan* pl) {
+    const int K = pl->desc.K;
+    int stat = 0;
+    pl->thr.clear(); pl->cols.clear();
+    for (int j = 0; j < K; ++j) {
+        const afhip_column& c = pl->columns[j];
+        ColOp co{};
+        switch (c.inner) {
+            case AFHIP_MEAN: co.src = SRC_MEAN; stat = std::max(stat, 1); break;
+            case AFHIP_SUM: co.src = SRC_SUM; stat = std::max(stat, 1); break;
+            case AFHIP_MIN: co.src = SRC_MIN; stat = std::max(stat, 2); break;
+            case AFHIP_MAX: co.src = SRC_MAX; stat = std::max(stat, 2); break;
+            case AFHIP_NANMEAN: co.src = SRC_NANMEAN; stat = 3; break;
+            case AFHIP_DD: co.src = SRC_THR; co.src_idx = add_thr_slot(pl->thr, c.inner_args, false); break;
+            case AFHIP_BINS: co.src = SRC_THR; co.src_idx = add_thr_slot(pl->thr, c.inner_args, true); break;
+            case AFHIP_SINE_DD:
+                co.src = SRC_SINE; stat = std::max(stat, 2);
+                co.s0 = c.inner_args[0]; co.s1 = c.inner_args[1];
+                if (c.inner_args[2] != 0.0 && c.inner_args[2] != 1.0)
+                    return fail(AFHIP_E_INVALID, "column %d: sine_dd flag must be 0 or 1 (temporal.py:324)", j);
+                co.skind = (int)c.inner_args[2];
+                break;
+            default: return fail(AFHIP_E_INVALID, "column %d: unknown inner reducer %d", j, c.inner);
+        }
+        switch (c.transform) {
+            case AFHIP_TF_NONE: co.tf = TF_NONE; break;
+            case AFHIP_TF_POW: {
+                const double e = c.transform_arg;
+                if (e == std::floor(e) && std::fabs(e) <= 64.0) { co.tf = TF_POWI; co.tf_iarg = (int)e; }
+                else { co.tf = TF_POW; co.tf_arg = e; }
+                break;
+            }
+            case AFHIP_TF_HINGE: co.tf = TF_HINGE; co.tf_arg = c.transform_arg; break;
+            default: return fail(AFHIP_E_INVALID, "column %d: unknown transform %d", j, c.transform);
+        }
+        switch (c.outer) {
+            case AFHIP_IDENTITY: co.outer = OUT_FIRST; break;
+            case AFHIP_SUM: co.outer = OUT_SUM; break;
+            case AFHIP_MEAN: co.outer = OUT_MEAN; break;
+            case AFHIP_MIN: co.outer = OUT_MIN; break;
+            case AFHIP_MAX: co.outer = OUT_MAX; break;
+            case AFHIP_DD:
+            case AFHIP_BINS:
+                co.outer = c.outer == AFHIP_DD ? OUT_DD : OUT_BINS;
+                co.o0 = c.outer_args[0]; co.o1 = c.outer_args[1];
+                co.obase = (c.outer_args[2] == 0.0) ? c.outer_args[0] : c.outer_args[1];
+                break;
+            default:
+                return fail(AFHIP_E_UNSUPPORTED, "column %d: outer reducer %d is not fused (use the staged path)", j, c.outer);
+        }
+        pl->cols.push_back(co);
+    }
+    if ((int)pl->thr.size() > MAX_THR) return fail(AFHIP_E_UNSUPPORTED, "more than %d threshold slots in one pass", MAX_THR);
+    if (K > MAX_COLS) return fail(AFHIP_E_UNSUPPORTED, "more than %d columns in one pass", MAX_COLS);
+    pl->stat = stat;
+    pl->nthr = (int)pl->thr.size();
+    pl->K = K;
+    return AFHIP_OK;
+}
+
+// Chunking.  target_len = time steps a workgroup should stream; a long period is cut on
+// inner-group boundaries into pieces (each emits a partial), short consecutive periods are
+// packed into one chunk (each emits its own final value).
+static int build_chunks(afhip_plan* pl, int vec) {
+    const auto& ib = pl->ib;
+    const auto& ob = pl->ob;
+    const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
+    pl->tiles = (C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec);
+    // aim for ~16 workgroups per CU over the whole grid, never streaming fewer than 64 steps
+    const int64_t want_wgs = (int64_t)cu_count() * 16;
+    const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
+    const int64_t target_len = std::max<int64_t>(64, T / want_chunks);
+    // splitting a period adds partial traffic (16 B per extra slot, column and cell, write +
+    // read); keep it under ~2 % of the cube: extra_slots*K*16 <= 0.02*T*elem
+    const int64_t elem = pl->desc.dtype == AFHIP_F32 ? 4 : 8;
+    int64_t split_budget = std::max<int64_t>(1, (int64_t)(0.02 * (double)T * (double)elem / (16.0 * std::max(1, pl->K))));
+    const bool any_first = std::any_of(pl->cols.begin(), pl->cols.end(), [](const ColOp& c) { return c.outer == OUT_FIRST; });
+    const bool may_split = !pl->desc.exact_order && !any_first;
+
+    pl->chunks.clear();
+    pl->emit.assign((size_t)std::max<int64_t>(G1, 1), 0);
+    pl->slot_ptr.assign((size_t)P + 1, 0);
+    int64_t slot = 0;
+
+    auto steps_of = [&](int64_t p) { return ib[(size_t)ob[(size_t)p + 1]] - ib[(size_t)ob[(size_t)p]]; };
+    auto groups_of = [&](int64_t p) { return ob[(size_t)p + 1] - ob[(size_t)p]; };
+    auto splittable = [&](int64_t p) {
+        return may_split && split_budget > 0 && groups_of(p) >= 2 && steps_of(p) >= 2 * target_len;
+    };
+    auto push_chunk = [&](int64_t g_lo, int64_t g_hi, int64_t slot_base) {
+        ChunkDesc c{};
+        c.k_lo = ib[(size_t)g_lo]; c.k_hi = ib[(size_t)g_hi];
+        c.g_lo = (int32_t)g_lo; c.g_hi = (int32_t)g_hi; c.slot_base = (int32_t)slot_base;
+        pl->chunks.push_back(c);
+    };
+
+    int64_t p = 0;
+    while (p < P) {
+        const int64_t g0 = ob[(size_t)p], g1 = ob[(size_t)p + 1];
+        if (g1 == g0) {  // empty resample bin: no slot, the combine kernel writes NaN
+            pl->slot_ptr[(size_t)p] = (int32_t)slot;
+            ++p;
+            continue;
+        }
+        if (splittable(p)) {
+            const int64_t steps = steps_of(p);
+            const int64_t pieces = std::max<int64_t>(2, std::min<int64_t>({steps / target_len, g1 - g0, split_budget + 1}));
+            pl->slot_ptr[(size_t)p] = (int32_t)slot;
+            int64_t g = g0, made = 0;
+            for (int64_t i = 1; i <= pieces && g < g1; ++i) {
+                int64_t ge;
+                if (i == pieces) {
+                    ge = g1;
+                } else {
+                    const int64_t k_goal = ib[(size_t)g0] + (steps * i) / pieces;
+                    ge = (int64_t)(std::lower_bound(ib.begin() + g + 1, ib.begin() + g1, k_goal) - ib.begin());
+                    ge = std::min(ge, g1);
+                }
+                if (ge <= g) continue;
+                push_chunk(g, ge, slot);
+                pl->emit[(size_t)ge - 1] = 1;
+                ++slot; ++made;
+                g = ge;
+            }
+            split_budget -= std::max<int64_t>(0, made - 1);
+            ++p;
+            continue;
+        }
+        // pack whole periods until the chunk holds ~target_len steps
+        const int64_t cg0 = g0, slot_base = slot;
+        int64_t acc_steps = 0, cg1 = g0;
+        bool first = true;
+        while (p < P) {
+            const int64_t a0 = ob[(size_t)p], a1 = ob[(size_t)p + 1];
+            const int64_t st = steps_of(p);
+            if (!first && (acc_steps + st > target_len || splittable(p))) break;
+            pl->slot_ptr[(size_t)p] = (int32_t)slot;
+            if (a1 > a0) { pl->emit[(size_t)a1 - 1] = 1; ++slot; cg1 = a1; }
+            acc_steps += st;
+            first = false;
+            ++p;
+        }
+        push_chunk(cg0, cg1, slot_base);
+    }
+    pl->slot_ptr[(size_t)P] = (int32_t)slot;
+    pl->n_slots = slot;
+    if (pl->chunks.size() > 65535)
+        return fail(AFHIP_E_UNSUPPORTED, "plan needs %zu chunks (> 65535 grid.y)", pl->chunks.size());
+    return AFHIP_OK;
+}
+
+static int validate_desc(const afhip_plan_desc* d) {
+    if (!d) return fail(AFHIP_E_INVALID, "plan_create: desc is NULL");
+    if (d->T < 0 || d->n_cells <= 0 || d->K <= 0 || d->G1 < 0 || d->P < 0)
+        return fail(AFHIP_E_INVALID, "plan_create: bad sizes (T=%lld n_cells=%lld K=%d G1=%lld P=%lld)",
+                    (long long)d->T, (long long)d->n_cells, d->K, (long long)d->G1, (long long)d->P);
+    if (d->dtype != AFHIP_F32 && d->dtype != AFHIP_F64) return fail(AFHIP_E_INVALID, "plan_create: dtype must be AFHIP_F32 or AFHIP_F64");
+    if (!d->inner_bounds || !d->outer_bounds || !d->columns) return fail(AFHIP_E_INVALID, "plan_create: NULL table");
+    if (d->inner_bounds[0] != 0 || d->inner_bounds[d->G1] != d->T)
+        return fail(AFHIP_E_INVALID, "plan_create: inner_bounds must run from 0 to T");
+    for (int64_t g = 0; g < d->G1; ++g)
+        if (d->inner_bounds[g + 1] < d->inner_bounds[g]) return fail(AFHIP_E_INVALID, "plan_create: inner_bounds not monotone (time index must be monotonic increasing)");
+    if (d->outer_bounds[0] != 0 || d->outer_bounds[d->P] != d->G1)
+        return fail(AFHIP_E_INVALID, "plan_create: outer_bounds must run from 0 to G1");
+    for (int64_t p = 0; p < d->P; ++p)
+        if (d->outer_bounds[p + 1] < d->outer_bounds[p]) return fail(AFHIP_E_INVALID, "plan_create: outer_bounds not monotone");
+    if (d->G1 > INT32_MAX - 2) return fail(AFHIP_E_INVALID, "plan_create: too many inner groups");
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) {
+    if (!out) return fail(AFHIP_E_INVALID, "plan_create: out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    auto* pl = new afhip_plan();
+    pl->desc = *desc;
+    pl->ib.assign(desc->inner_bounds, desc->inner_bounds + desc->G1 + 1);
+    pl->ob.assign(desc->outer_bounds, desc->outer_bounds + desc->P + 1);
+    pl->columns.assign(desc->columns, desc->columns + desc->K);
+    pl->desc.inner_bounds = nullptr; pl->desc.outer_bounds = nullptr; pl->desc.columns = nullptr;
+    if ((rc = lower_columns(pl))) { delete pl; return rc; }
+
+    // variant: LDS-DMA ring when rows are 16-byte multiples, else direct scalar loads
+    const int64_t elem = desc->dtype == AFHIP_F32 ? 4 : 8;
+    const bool rows16 = ((desc->n_cells * elem) % 16) == 0 && desc->n_cells * elem >= 16;
+    int want_pipe = rows16 ? 1 : 0;
+    if (desc->tuning == 1) want_pipe = 0;       // force direct scalar loads
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, desc->tuning);
+    if (!v && want_pipe == 1) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0);
+    if (!v) {
+        delete pl;
+        return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
+    }
+    pl->variant = v;
+    if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
+
+    if ((rc = pl->d_ib.upload(pl->ib)) || (rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_emit.upload(pl->emit)) ||
+        (rc = pl->d_chunks.upload(pl->chunks)) || (rc = pl->d_slot_ptr.upload(pl->slot_ptr))) {
+        delete pl;
+        return rc;
+    }
+    const int64_t C = desc->n_cells, K = desc->K, P = desc->P;
+    auto a256 = [](int64_t b) { return (b + 255) / 256 * 256; };
+    pl->ws_partial = a256(std::max<int64_t>(pl->n_slots, 1) * K * C * 8);
+    pl->ws_panel = a256(C * (K + 1) * std::max<int64_t>(P, 1) * 8);
+    *out = pl;
+    return AFHIP_OK;
+}
+
+extern "C" void afhip_plan_destroy(afhip_plan* plan) { delete plan; }
+
+extern "C" int64_t afhip_plan_workspace_bytes(const afhip_plan* plan) {
+    if (!plan) return 0;
+    return plan->ws_partial + plan->ws_panel;
+}
+
+extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_len) {
+    if (!plan) return 0;
+    int64_t min_len = INT64_MAX, max_len = 0;
+    for (auto& c : plan->chunks) { min_len = std::min(min_len, c.k_hi - c.k_lo); max_len = std::max(max_len, c.k_hi - c.k_lo); }
+    char tmp[1024];
+    int n = snprintf(tmp, sizeof tmp,
+                     "variant=%s pipe=%d vec=%d stat=%d slots=%d kmax=%d depth=%d | T=%lld cells=%lld K=%d G1=%lld P=%lld | "
+                     "tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld | workspace=%.1f MiB",
+                     plan->variant->name, plan->variant->pipe, plan->variant->vec, plan->variant->stat, plan->variant->nthr,
+                     plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
+                     plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, (long long)plan->tiles, plan->chunks.size(),
+                     (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
+                     (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
+    if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
+    return n + 1;
+}
+
+static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st) {
+    if (pl->chunks.empty()) return AFHIP_OK;
+    FusedArgs fa{};
+    fa.cube = cube; fa.C = pl->desc.n_cells;
+    fa.inner_bounds = pl->d_ib.p; fa.emit = pl->d_emit.p; fa.chunks = pl->d_chunks.p;
+    fa.partial = partial; fa.K = pl->K; fa.nthr = pl->nthr;
+    for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];
+    for (int i = pl->nthr; i < MAX_THR; ++i) {       // padded slots never fire
+        fa.thr[i] = ThrSlot{};
+        fa.thr[i].t0 = INFINITY; fa.thr[i].t1 = -INFINITY;
+    }
+    for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
+    dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
+    void* args[] = {&fa};
+    HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3(WG), args, 0, st));
+    return AFHIP_OK;
+}
+
+static int launch_combine(afhip_plan* pl, const double* partial, double* cells, double* panel, hipStream_t st) {
+    const int64_t C = pl->desc.n_cells, P = pl->desc.P;
+    if (P == 0) return AFHIP_OK;
+    CombineArgs ca{};
+    ca.partial = partial; ca.slot_ptr = pl->d_slot_ptr.p; ca.outer_bounds = pl->d_ob.p;
+    ca.cells_out = cells; ca.panel = panel; ca.C = C; ca.P = P; ca.K = pl->K;
+    for (int j = 0; j < pl->K; ++j) ca.outer[j] = pl->cols[(size_t)j].outer;
+    dim3 grid((unsigned)P, (unsigned)((C + WG - 1) / WG));
+    hipLaunchKernelGGL(k_combine_slots, grid, dim3(WG), 0, st, ca);
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
+static int ensure_ws(afhip_plan* pl, int64_t bytes, void* user_ws, char** base) {
+    if (user_ws) { *base = (char*)user_ws; return AFHIP_OK; }
+    if (pl->own_ws_bytes < bytes) {
+        if (pl->own_ws) { HIP_TRY(hipFree(pl->own_ws)); pl->own_ws = nullptr; pl->own_ws_bytes = 0; }
+        HIP_TRY(hipMalloc(&pl->own_ws, (size_t)bytes));
+        pl->own_ws_bytes = bytes;
+    }
+    *base = (char*)pl->own_ws;
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cells_dev,
+                                       void* workspace_dev, void* stream) {
+    if (!plan || !cube_dev || !cells_dev) return fail(AFHIP_E_INVALID, "plan_run_temporal: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    char* base;
+    int rc = ensure_ws(plan, plan->ws_partial, workspace_dev, &base);
+    if (rc) return rc;
+    double* partial = (double*)base;
+    if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
+    return launch_combine(plan, partial, cells_dev, nullptr, st);
+}
+
+extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhip_csr* csr,
+                              double* num_dev, double* den_dev, double* res_dev, double* cells_dev,
+                              void* workspace_dev, void* stream, float* kernel_ms) {
+    if (!plan || !cube_dev || !csr || !res_dev) return fail(AFHIP_E_INVALID, "plan_run: NULL argument");
+    if (csr->n_cells != plan->desc.n_cells)
+        return fail(AFHIP_E_INVALID, "plan_run: CSR has %lld cells, plan has %lld", (long long)csr->n_cells, (long long)plan->desc.n_cells);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t K = plan->K, P = plan->desc.P, Q = (K + 1) * P;
+    // partial + panel live in the caller's workspace when given; the small [R][Q] sums
+    // buffer is always plan-owned (its size depends on the CSR, not on the plan)
+    const int64_t sums_bytes = (std::max<int64_t>(csr->R * Q, 1) * 8 + 255) / 256 * 256;
+    if (plan->sums_bytes < sums_bytes) {
+        if (plan->sums) { HIP_TRY(hipFree(plan->sums)); plan->sums = nullptr; plan->sums_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&plan->sums, (size_t)sums_bytes));
+        plan->sums_bytes = sums_bytes;
+    }
+    char* base;
+    int rc = ensure_ws(plan, plan->ws_partial + plan->ws_panel, workspace_dev, &base);
+    if (rc) return rc;
+    double* partial = (double*)base;
+    double* panel = (double*)(base + plan->ws_partial);
+    if (kernel_ms) {
+        for (auto& e : plan->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(plan->ev[0], st));
+    }
+    if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
+    if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
+    if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
+    if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
+    const int64_t n = K * csr->R * P;
+    if (n) {
+        hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, plan->sums, num_dev,
+                           den_dev, res_dev, csr->R, P, (int)K);
+        HIP_TRY(hipGetLastError());
+    }
+    if (kernel_ms) {
+        HIP_TRY(hipEventRecord(plan->ev[2], st));
+        HIP_TRY(hipEventSynchronize(plan->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&kernel_ms[0], plan->ev[0], plan->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&kernel_ms[1], plan->ev[0], plan->ev[2]));
+    }
+    return AFHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// standalone grouped reducers (drop-in for the numba kernels)
+// ---------------------------------------------------------------------------------------
+static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells, const int64_t* bounds,
+                     int64_t G, int code, const double* ddargs, int64_t D, void* out_dev, void* stream) {
+    if (!cube_dev || !bounds || !out_dev) return fail(AFHIP_E_INVALID, "group kernel: NULL argument");
+    if (G < 0 || D <= 0) return fail(AFHIP_E_INVALID, "group kernel: bad G/D");
+    if (G == 0) return AFHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // D can exceed one pass's slot/column budget: run passes of <= MAX_COLS columns
+    const int64_t per_pass = std::min<int64_t>(MAX_COLS, MAX_THR);
+    std::vector<int64_t> ob((size_t)G + 1);
+    for (int64_t g = 0; g <= G; ++g) ob[(size_t)g] = g;
+    if (D > per_pass && D > 1)
+        return fail(AFHIP_E_UNSUPPORTED, "group kernel: D=%lld thresholds exceed %lld per call; split the ddargs", (long long)D, (long long)per_pass);
+    std::vector<afhip_column> cols((size_t)D);
+    for (int64_t d = 0; d < D; ++d) {
+        afhip_column c{};
+        c.inner = code; c.transform = AFHIP_TF_NONE; c.outer = AFHIP_IDENTITY;
+        if (ddargs) { c.inner_args[0] = ddargs[d * 3]; c.inner_args[1] = ddargs[d * 3 + 1]; c.inner_args[2] = ddargs[d * 3 + 2]; }
+        cols[(size_t)d] = c;
+    }
+    afhip_plan_desc desc{};
+    desc.T = T; desc.n_cells = n_cells; desc.dtype = dtype; desc.K = (int32_t)D; desc.G1 = G;
+    desc.inner_bounds = bounds; desc.P = G; desc.outer_bounds = ob.data(); desc.columns = cols.data();
+    afhip_plan* pl = nullptr;
+    int rc = afhip_plan_create(&desc, &pl);
+    if (rc) return rc;
+    char* base;
+    if ((rc = ensure_ws(pl, pl->ws_partial, nullptr, &base))) { delete pl; return rc; }
+    double* partial = (double*)base;
+    if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
+    dim3 grid((unsigned)G, (unsigned)((n_cells + WG - 1) / WG));
+    if (dtype == AFHIP_F32)
+        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D);
+    else
+        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D);
+    hipError_t e = hipGetLastError();
+    // the plan owns the scratch the kernels are still reading: drain before freeing it
+    hipError_t e2 = hipStreamSynchronize(st);
+    delete pl;
+    if (e != hipSuccess) return fail(AFHIP_E_HIP, "k_slots_to_block launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(AFHIP_E_HIP, "stream synchronize failed: %s", hipGetErrorString(e2));
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_group_stat(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
+                                const int64_t* bounds, int64_t G, int code, void* out_dev, void* stream) {
+    if (code < AFHIP_MEAN || code > AFHIP_NANMEAN) return fail(AFHIP_E_INVALID, "group_stat: code %d is not a stat reducer", code);
+    return run_group(cube_dev, dtype, T, n_cells, bounds, G, code, nullptr, 1, out_dev, stream);
+}
+extern "C" int afhip_group_dd(const void* cube_dev, int dtype, int64_t T, int64_t n_cells, const int64_t* bounds,
+                              int64_t G, const double* ddargs, int64_t D, void* out_dev, void* stream) {
+    if (!ddargs) return fail(AFHIP_E_INVALID, "group_dd: ddargs is NULL");
+    return run_group(cube_dev, dtype, T, n_cells, bounds, G, AFHIP_DD, ddargs, D, out_dev, stream);
+}
+extern "C" int afhip_group_bins(const void* cube_dev, int dtype, int64_t T, int64_t n_cells, const int64_t* bounds,
+                                int64_t G, const double* ddargs, int64_t D, void* out_dev, void* stream) {
+    if (!ddargs) return fail(AFHIP_E_INVALID, "group_bins: ddargs is NULL");
+    return run_group(cube_dev, dtype, T, n_cells, bounds, G, AFHIP_BINS, ddargs, D, out_dev, stream);
+}
+extern "C" int afhip_group_sine_dd(const void* cube_dev, int dtype, int64_t T, int64_t n_cells, const int64_t* bounds,
+                                   int64_t G, const double* ddargs, int64_t D, void* out_dev, void* stream) {
+    if (!ddargs) return fail(AFHIP_E_INVALID, "group_sine_dd: ddargs is NULL");
+    return run_group(cube_dev, dtype, T, n_cells, bounds, G, AFHIP_SINE_DD, ddargs, D, out_dev, stream);
+}

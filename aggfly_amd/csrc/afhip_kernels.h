@@ -1,0 +1,398 @@
+// afhip_kernels.h — device code of the MI355X (gfx950) aggregation engine.
+//
+// Three kernels do the work of one aggregate_dataset() call:
+//
+//   k_fused_temporal  one streaming pass over the raw (time, cell) cube.  A lane owns VEC
+//                     neighbouring cells; it walks its time chunk once, keeps every inner
+//                     accumulator (sum/min/max, threshold slots) and every column's outer
+//                     accumulator in registers, and writes one partial per (slot, column,
+//                     cell).  HBM-bound: algorithmic bytes = T * n_cells * sizeof(elem).
+//                     Restates _block_stat/_block_dd/_block_bins/_block_sine_dd
+//                     (aggfly/aggregate/nb_kernels.py:121-251) and the transforms
+//                     (aggfly/dataset/dataset.py:475-481,527-543) per cell, in the
+//                     reference's k-ascending order.
+//   k_combine_slots   merges the partials of an outer period in slot order, applies the
+//                     shared validity rule (aggfly/aggregate/spatial.py:114-119) and lays
+//                     the result out cell-major for the sparse stage.
+//   k_csr_spmm        region x cell CSR weighted sums in table order
+//                     (_scatter_block, spatial.py:181-186), then k_panel_divide
+//                     (spatial.py:127-133).
+//
+// No MFMA anywhere: the path is a streaming scan plus a sparse segmented sum.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afhip {
+
+constexpr int WG = 256;          // 4 wavefronts of 64
+constexpr int MAX_THR = 16;      // threshold slots evaluated on raw data per pass
+constexpr int MAX_COLS = 16;     // output columns per pass
+
+// inner-source kinds (what a column reads at the end of an inner group)
+enum : int { SRC_MEAN = 0, SRC_SUM = 1, SRC_MIN = 2, SRC_MAX = 3, SRC_NANMEAN = 4, SRC_THR = 5, SRC_SINE = 6 };
+enum : int { TF_NONE = 0, TF_POWI = 1, TF_POW = 2, TF_HINGE = 3 };
+enum : int { OUT_FIRST = 0, OUT_SUM = 1, OUT_MEAN = 2, OUT_MIN = 3, OUT_MAX = 4, OUT_DD = 5, OUT_BINS = 6 };
+
+// One threshold slot on raw data: contribution = (t0 < v && v < t1) ? a*|v-base| + b : 0.
+// dd: a=1,b=0 (nb_kernels.py:169-177); bins: a=0,b=1 (nb_kernels.py:190-196).
+struct ThrSlot {
+    double t0, t1, base, a, b;
+    int32_t nan_poisons;  // dd: a NaN in the window makes the group NaN; bins: it does not
+    int32_t pad;
+};
+
+struct ColOp {
+    int32_t src, src_idx;      // SRC_*; slot index for SRC_THR
+    int32_t tf, tf_iarg;       // TF_*; integer exponent for TF_POWI
+    int32_t outer, skind;      // OUT_*; sine_dd kind flag (0 cooling, 1 heating)
+    double s0, s1;             // sine_dd thresholds
+    double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
+    double o0, o1, obase;      // outer dd/bins thresholds
+};
+
+struct ChunkDesc {
+    int64_t k_lo, k_hi;        // time steps [k_lo, k_hi)
+    int32_t g_lo, g_hi;        // inner groups [g_lo, g_hi); k_lo == ib[g_lo], k_hi == ib[g_hi]
+    int32_t slot_base, pad;
+};
+
+struct FusedArgs {
+    const void* cube;
+    int64_t C;                     // cells
+    const int64_t* inner_bounds;   // device [G1+1]
+    const int32_t* emit;           // device [G1]: 1 = write a slot after this inner group
+    const ChunkDesc* chunks;       // device [n_chunks]
+    double* partial;               // device [n_slots][K][C]
+    int32_t K, nthr;
+    ThrSlot thr[MAX_THR];
+    ColOp cols[MAX_COLS];
+};
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double nan64() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// x**e for a small integer e, evaluated as a double-double product chain so that the
+// result is the correctly rounded power in all but ~1e-16 of cases — what libm's pow()
+// behind np.power (dataset.py:543) returns.  Plain repeated multiplication differs from
+// np.power in the last bit for 26-35 % of inputs at e = 3, 4.
+__device__ __forceinline__ double powi_dd(double x, int e) {
+    if (e == 0) return 1.0;
+    int n = e < 0 ? -e : e;
+    double hi = x, lo = 0.0;
+    for (int i = 1; i < n; ++i) {
+        // (hi + lo) * x  ->  (p + q)
+        double p = hi * x;
+        double err = __fma_rn(hi, x, -p);
+        double q = __fma_rn(lo, x, err);
+        double s = p + q;
+        lo = q - (s - p);
+        hi = s;
+    }
+    double r = hi + lo;
+    return e < 0 ? 1.0 / r : r;
+}
+
+// Single-sine degree-day "parts" (nb_kernels.py:224-249).
+__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg) {
+    const double PI = 3.14159265358979323846;
+    if (thr <= tmin) return tavg - thr;
+    if (thr < tmax && tmin < thr) {
+        double rng = tmax - tmin;
+        double a = acos((2.0 * thr - tmax - tmin) / rng);
+        return ((tavg - thr) * a + rng * sin(a) / 2.0) / PI;
+    }
+    return 0.0;
+}
+__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg) {
+    const double PI = 3.14159265358979323846;
+    if (thr >= tmax) return thr - tavg;
+    if (thr < tmax && tmin < thr) {
+        double alpha = (tmax - tmin) / 2.0;
+        double r = (thr - tavg) / alpha;
+        double at = atan(r / sqrt(1.0 - r * r));
+        return (1.0 / PI) * ((thr - tavg) * (at + PI / 2.0) + alpha * cos(at));
+    }
+    return 0.0;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// The plan tables (bounds, emit flags, chunk list) are read-only for the whole launch and
+// indexed by wave-uniform values.  Reading them through the constant address space makes
+// hipcc use scalar loads (s_load, counted on lgkmcnt), so no compiler-issued vector load —
+// and with it no compiler-inserted s_waitcnt vmcnt(0) — lands inside the streaming loop.
+template <typename T>
+__device__ __forceinline__ T ld_uniform(const T* p) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "scalar words only");
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
+#else
+    return *p;
+#endif
+}
+
+template <typename TIn, int VEC> struct RawVec;
+template <> struct alignas(8) RawVec<double, 1> { double v[1]; };
+template <> struct alignas(16) RawVec<double, 2> { double v[2]; };
+template <> struct alignas(4) RawVec<float, 1> { float v[1]; };
+template <> struct alignas(16) RawVec<float, 4> { float v[4]; };
+
+// ---------------------------------------------------------------------------------------
+// k_fused_temporal
+//
+// grid = (cell tiles, chunks).  blockIdx.x (fastest) walks neighbouring tiles of the same
+// chunk, so workgroups resident together read adjacent 4 KB pieces of the same rows: the
+// union is one long contiguous run per time step.  There is no reuse between workgroups
+// (every byte is read once), so no XCD-aware remap is applied.
+//
+//   PIPE 0  lanes load straight to registers (any alignment; VEC = 1 is the fallback for
+//           shapes whose rows are not 16-byte multiples).
+//   PIPE 1  each wave streams its 1 KiB row pieces into a private LDS ring with
+//           global_load_lds_dwordx4 (no VGPR destination), DEPTH rows ahead, and reads the
+//           current row back with ds_read_b128.  The ring is wave-private, so there are no
+//           workgroup barriers: a counted s_waitcnt vmcnt(DEPTH-1) is the only ordering
+//           (MI355X_MICROARCH.md, "Two waves per SIMD" item 7).  The prefetch runs across
+//           inner-group boundaries, so short groups (daily data, tmin/tmax pairs) stream
+//           as well as long ones.
+//
+//   STAT 0 none | 1 sum | 2 sum+min+max | 3 sum+count+min+max with NaN skipping (nanmean)
+// ---------------------------------------------------------------------------------------
+//   FEAT bit 0: single-sine degree days compiled in (needs STAT >= 2)
+//        bit 1: pow() with a non-integer exponent compiled in
+// Both are bulky once inlined per column, so only the variants that need them carry them.
+template <typename TIn, int PIPE, int VEC, int STAT, int NTHR, int KMAX, int DEPTH, int FEAT>
+__global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
+    static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
+    const int64_t C = a.C;
+    const int K = a.K;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * WG + threadIdx.x) * VEC;
+    const bool active = c0 < C;
+    const int64_t c_ld = active ? c0 : (C - VEC);   // clamped: inactive lanes re-read valid cells
+    ChunkDesc ch;
+    {
+        const int64_t* w = (const int64_t*)&a.chunks[blockIdx.y];
+        ch.k_lo = ld_uniform(w);
+        ch.k_hi = ld_uniform(w + 1);
+        const int64_t g = ld_uniform(w + 2), sb = ld_uniform(w + 3);
+        ch.g_lo = (int32_t)(g & 0xffffffffLL); ch.g_hi = (int32_t)(g >> 32);
+        ch.slot_base = (int32_t)(sb & 0xffffffffLL); ch.pad = 0;
+    }
+    const TIn* __restrict__ cube = (const TIn*)a.cube;
+
+    // ---- per-cell state, all in registers (compile-time indexed) ----
+    double s[VEC], mn[VEC], mx[VEC];
+    int cnt[VEC];
+    bool hasnan[VEC];
+    double acc[NTHR > 0 ? NTHR : 1][VEC];
+    double os[KMAX][VEC];
+
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; hasnan[i] = false;
+#pragma unroll
+        for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
+    }
+    auto reset_outer = [&]() {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < K) {
+                const int o = a.cols[j].outer;
+                const double init = (o == OUT_MIN) ? inf64() : ((o == OUT_MAX) ? -inf64() : 0.0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) os[j][i] = init;
+            }
+        }
+    };
+    reset_outer();
+
+    // ---- the hot per-element update ----
+    auto consume = [&](const RawVec<TIn, VEC>& rv) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const double v = (double)rv.v[i];
+            const bool isn = v != v;
+            hasnan[i] = hasnan[i] | isn;
+            if (STAT == 1) {
+                s[i] += v;                          // a NaN poisons s; the group is NaN anyway
+            } else if (STAT == 2) {
+                s[i] += v;
+                mn[i] = (v < mn[i]) ? v : mn[i];    // NaN compares false: skipped like the reference
+                mx[i] = (v > mx[i]) ? v : mx[i];
+            } else if (STAT == 3) {
+                s[i] += isn ? 0.0 : v;
+                cnt[i] += isn ? 0 : 1;
+                mn[i] = (v < mn[i]) ? v : mn[i];
+                mx[i] = (v > mx[i]) ? v : mx[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NTHR; ++j) {
+                const bool m = (v > a.thr[j].t0) && (v < a.thr[j].t1);   // strict, NaN -> false
+                const double w = __fma_rn(a.thr[j].a, fabs(v - a.thr[j].base), a.thr[j].b);
+                acc[j][i] += m ? w : 0.0;
+            }
+        }
+    };
+
+    // ---- end of an inner group: column values, transforms, outer accumulation ----
+    int slot = ch.slot_base;
+    auto group_end = [&](int g, int64_t nsteps) {
+        const bool empty = nsteps == 0;
+        const double dn = (double)nsteps;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < K) {
+                const ColOp co = a.cols[j];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const bool bad = hasnan[i] || empty;
+                    double x = nan64();
+                    const int src = co.src;
+                    if (STAT >= 1 && src == SRC_MEAN) x = bad ? nan64() : s[i] / dn;
+                    else if (STAT >= 1 && src == SRC_SUM) x = bad ? nan64() : s[i];
+                    else if (STAT >= 2 && src == SRC_MIN) x = bad ? nan64() : mn[i];
+                    else if (STAT >= 2 && src == SRC_MAX) x = bad ? nan64() : mx[i];
+                    else if (STAT == 3 && src == SRC_NANMEAN)
+                        x = (empty || cnt[i] == 0) ? nan64() : s[i] / (double)cnt[i];
+                    else if (NTHR > 0 && src == SRC_THR) {
+                        double t = 0.0;
+                        bool poisons = false;
+#pragma unroll
+                        for (int q = 0; q < NTHR; ++q)
+                            if (q == co.src_idx) { t = acc[q][i]; poisons = a.thr[q].nan_poisons != 0; }
+                        x = (empty || (poisons && hasnan[i])) ? nan64() : t;
+                    } else if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {   // nb_kernels.py:218-251
+                        if (!bad) {
+                            const double tavg = s[i] / dn;
+                            if (co.skind == 0)
+                                x = sine_cool(co.s0, mn[i], mx[i], tavg) - sine_cool(co.s1, mn[i], mx[i], tavg);
+                            else
+                                x = -sine_heat(co.s0, mn[i], mx[i], tavg) + sine_heat(co.s1, mn[i], mx[i], tavg);
+                        }
+                    }
+                    const int tf = co.tf;
+                    if (tf == TF_POWI) x = powi_dd(x, co.tf_iarg);
+                    else if (tf == TF_HINGE) x = ((x > co.tf_arg) ? 1.0 : 0.0) * (x - co.tf_arg);
+                    else if ((FEAT & 2) && tf == TF_POW) x = pow(x, co.tf_arg);
+                    double o = os[j][i];
+                    switch (co.outer) {
+                        case OUT_FIRST: o = x; break;
+                        case OUT_SUM:
+                        case OUT_MEAN: o += x; break;               // NaN is sticky
+                        case OUT_MIN: { double t = (x < o) ? x : o; o = (x != x) ? x : t; break; }
+                        case OUT_MAX: { double t = (x > o) ? x : o; o = (x != x) ? x : t; break; }
+                        case OUT_DD: {
+                            const bool m = (x > co.o0) && (x < co.o1);
+                            o += (x != x) ? x : (m ? fabs(x - co.obase) : 0.0);
+                            break;
+                        }
+                        default: {  // OUT_BINS: a NaN value is simply out of range
+                            const bool m = (x > co.o0) && (x < co.o1);
+                            o += m ? 1.0 : 0.0;
+                            break;
+                        }
+                    }
+                    os[j][i] = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; hasnan[i] = false;
+#pragma unroll
+            for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
+        }
+        if (ld_uniform(&a.emit[g])) {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    if (j < K) {
+                        double* dst = a.partial + ((int64_t)slot * K + j) * C + c0;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) dst[i] = os[j][i];
+                    }
+                }
+            }
+            ++slot;
+            reset_outer();
+        }
+    };
+
+    int64_t k = ch.k_lo;
+    int g = ch.g_lo;
+
+    if constexpr (PIPE == 0) {
+        while (g < ch.g_hi) {
+            const int64_t gend = ld_uniform(&a.inner_bounds[g + 1]);
+            const int64_t gbeg = k;
+            const TIn* p = cube + k * C + c_ld;
+            // four rows in flight per lane inside a group
+            for (; k + 4 <= gend; k += 4) {
+                RawVec<TIn, VEC> r0, r1, r2, r3;
+                r0 = *(const RawVec<TIn, VEC>*)(p);
+                r1 = *(const RawVec<TIn, VEC>*)(p + C);
+                r2 = *(const RawVec<TIn, VEC>*)(p + 2 * C);
+                r3 = *(const RawVec<TIn, VEC>*)(p + 3 * C);
+                p += 4 * C;
+                consume(r0); consume(r1); consume(r2); consume(r3);
+            }
+            for (; k < gend; ++k) {
+                RawVec<TIn, VEC> r0 = *(const RawVec<TIn, VEC>*)(p);
+                p += C;
+                consume(r0);
+            }
+            group_end(g, gend - gbeg);
+            ++g;
+        }
+    } else {
+        // ---- LDS-DMA ring, wave-private ----
+        __shared__ __attribute__((aligned(16))) unsigned char ring[(WG / 64) * DEPTH * 1024];
+        unsigned char* my = ring + wave * (DEPTH * 1024);
+        const uint32_t my_lds = (uint32_t)(uintptr_t)(lds_ptr_t)my;     // LDS byte address
+        const uint32_t rd_off = (uint32_t)lane * 16u;
+        const int64_t k_last = ch.k_hi - 1;
+        const TIn* lane_base = cube + c_ld;
+        auto issue = [&](int64_t row, int sl) {
+            const int64_t r = row < k_last ? row : k_last;               // tail: re-load the last row
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(lane_base + r * C),
+                                             (lds_ptr_t)(my + sl * 1024), 16, 0, 0);
+        };
+        int sl = 0;  // ring slot of row k
+        if (ch.k_hi > ch.k_lo) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) issue(ch.k_lo + d, d);
+        }
+        while (g < ch.g_hi) {
+            const int64_t gend = ld_uniform(&a.inner_bounds[g + 1]);
+            const int64_t gbeg = k;
+            for (; k < gend; ++k) {
+                u32x4 raw;
+                // row k has landed once at most DEPTH-1 younger DMAs are outstanding
+                asm volatile("s_waitcnt vmcnt(%1)\n\t"
+                             "ds_read_b128 %0, %2\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=v"(raw)
+                             : "n"(DEPTH - 1), "v"(my_lds + (uint32_t)sl * 1024u + rd_off)
+                             : "memory");
+                issue(k + DEPTH, sl);            // slot is free again: its row is in registers
+                sl = (sl + 1 == DEPTH) ? 0 : sl + 1;
+                RawVec<TIn, VEC> rv;
+                __builtin_memcpy(&rv, &raw, 16);
+                consume(rv);
+            }
+            group_end(g, gend - gbeg);
+            ++g;
+        }
+        // no DMA may still target this workgroup's LDS when the wave retires
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+}  // namespace afhip

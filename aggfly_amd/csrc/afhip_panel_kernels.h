@@ -1,0 +1,138 @@
+// afhip_panel_kernels.h — the small kernels after the streaming pass: slot merge + shared
+// validity, CSR weighted sums, divide.  Included by afhip_api.hip only (non-template
+// __global__ functions must live in one translation unit).
+#pragma once
+#include "afhip_kernels.h"
+
+namespace afhip {
+
+// ---------------------------------------------------------------------------------------
+// k_combine_slots: partial[slot][K][C] -> cell values, validity, cell-major panel.
+//
+// One thread per (period p, cell c).  For each column the slots of p are merged in slot
+// (= time) order; OUT_MEAN divides by the period's inner-group count.  A period without
+// slots is an empty resample bin -> NaN (nb_kernels.py:138-141).
+//   cells_out [K][P][C]   (optional) per-cell values, NaN kept       = aggregate_time output
+//   panel     [C][(K+1)*P] where(valid, x, 0) per column and the valid plane in column K
+// ---------------------------------------------------------------------------------------
+struct CombineArgs {
+    const double* partial;
+    const int32_t* slot_ptr;       // device [P+1]: slots of period p = [slot_ptr[p], slot_ptr[p+1])
+    const int64_t* outer_bounds;   // device [P+1]
+    double* cells_out;             // may be null
+    double* panel;                 // may be null
+    int64_t C, P;
+    int32_t K;
+    int32_t outer[MAX_COLS];
+};
+
+__global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
+    const int64_t c = (int64_t)blockIdx.y * WG + threadIdx.x;   // grid = (periods, cell tiles)
+    const int64_t p = blockIdx.x;
+    if (c >= a.C) return;
+    const int s0 = a.slot_ptr[p], s1 = a.slot_ptr[p + 1];
+    const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
+    const int K = a.K;
+    const int64_t Q = (int64_t)(K + 1) * a.P;
+    bool valid = true;
+    // pass 1: merged values -> cells_out (or recomputed in pass 2 when it is absent)
+    for (int j = 0; j < K; ++j) {
+        double v;
+        if (s1 == s0) {
+            v = nan64();
+        } else {
+            v = a.partial[((int64_t)s0 * K + j) * a.C + c];
+            const int o = a.outer[j];
+            for (int s = s0 + 1; s < s1; ++s) {
+                const double x = a.partial[((int64_t)s * K + j) * a.C + c];
+                if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                else if (o == OUT_FIRST) { /* a period is never split for OUT_FIRST */ }
+                else v += x;
+            }
+            if (o == OUT_MEAN) v = v / ng;
+        }
+        valid = valid && (v == v);
+        if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;
+        if (a.panel) a.panel[c * Q + (int64_t)j * a.P + p] = v;   // zeroed below if invalid
+    }
+    if (a.panel) {
+        if (!valid)
+            for (int j = 0; j < K; ++j) a.panel[c * Q + (int64_t)j * a.P + p] = 0.0;
+        a.panel[c * Q + (int64_t)K * a.P + p] = valid ? 1.0 : 0.0;
+    }
+}
+
+// Standalone reducers: slots -> the reference's out[G, cell, D] layout and dtype
+// (nb_kernels.py:257-268: float64 accumulate, store in the input dtype).
+template <typename TOut>
+__global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, const int32_t* slot_ptr,
+                                                       TOut* out, int64_t C, int64_t G, int D) {
+    const int64_t c = (int64_t)blockIdx.y * WG + threadIdx.x;   // grid = (groups, cell tiles)
+    const int64_t g = blockIdx.x;
+    if (c >= C) return;
+    const int s0 = slot_ptr[g], s1 = slot_ptr[g + 1];
+    for (int d = 0; d < D; ++d) {
+        const double v = (s1 == s0) ? nan64() : partial[((int64_t)s0 * D + d) * C + c];
+        out[(g * C + c) * D + d] = (TOut)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_csr_spmm: out[r][q] = sum_j w[j] * X[col[j]][q], j over the row in table order.
+// One thread per (r, q), q fastest, so a wave reads whole rows of X contiguously.  The
+// product is rounded before the add (no FMA): np.add.at adds the already-rounded
+// contrib = w * block[...] (spatial.py:183-185).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ cols,
+                                                 const double* __restrict__ w,
+                                                 const double* __restrict__ X, double* __restrict__ out,
+                                                 int64_t R, int64_t Q) {
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (tid >= R * Q) return;
+    const int64_t r = tid / Q, q = tid - r * Q;
+    const int64_t j0 = indptr[r], j1 = indptr[r + 1];
+    double accv = 0.0;
+    for (int64_t j = j0; j < j1; ++j) {
+        const double contrib = __dmul_rn(w[j], X[(int64_t)cols[j] * Q + q]);
+        accv = __dadd_rn(accv, contrib);
+    }
+    out[tid] = accv;
+}
+
+// sums[R][(K+1)*P] -> num[K][R][P], den[R][P], res[K][R][P] (spatial.py:127-133)
+__global__ __launch_bounds__(WG) void k_panel_divide(const double* __restrict__ sums, double* num,
+                                                     double* den, double* res, int64_t R, int64_t P, int K) {
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    const int64_t n = (int64_t)K * R * P;
+    if (tid >= n) return;
+    const int64_t k = tid / (R * P);
+    const int64_t rp = tid - k * R * P;
+    const int64_t r = rp / P, p = rp - r * P;
+    const int64_t Q = (int64_t)(K + 1) * P;
+    const double nu = sums[r * Q + k * P + p];
+    const double de = sums[r * Q + (int64_t)K * P + p];
+    if (num) num[tid] = nu;
+    if (den && k == 0) den[rp] = de;
+    res[tid] = (de != 0.0) ? nu / de : nan64();
+}
+
+// x[K][C][nt] -> panel[C][(K+1)*nt] with shared validity (spatial.py:114-123); used by
+// afhip_spatial_wavg, whose input layout is the reference's (cell, time) block per name.
+__global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict__ x, double* __restrict__ panel,
+                                                       int64_t C, int64_t nt, int K) {
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (tid >= C * nt) return;
+    const int64_t c = tid / nt, t = tid - c * nt;
+    const int64_t Q = (int64_t)(K + 1) * nt;
+    bool valid = true;
+    for (int j = 0; j < K; ++j) { const double v = x[((int64_t)j * C + c) * nt + t]; valid = valid && (v == v); }
+    for (int j = 0; j < K; ++j) {
+        const double v = x[((int64_t)j * C + c) * nt + t];
+        panel[c * Q + (int64_t)j * nt + t] = valid ? v : 0.0;
+    }
+    panel[c * Q + (int64_t)K * nt + t] = valid ? 1.0 : 0.0;
+}
+
+}  // namespace afhip

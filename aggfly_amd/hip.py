@@ -1,0 +1,376 @@
+"""ctypes binding of ``libaggfly_hip.so`` (C ABI: include/aggfly_hip.h).
+
+This is the only door from Python into the engine.  There is no CPU fallback: if the
+shared library is missing or no GPU is visible, calls raise ``HipEngineError`` — the
+reference's numba/dask engines (`aggfly/aggregate/nb_kernels.py`, `temporal.py`) are not
+reimplemented on the host.
+
+Device memory, streams and (for multi-GPU) the process group come from PyTorch-ROCm;
+only raw pointers and sizes cross into the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaggfly_hip.so")
+
+# codes (include/aggfly_hip.h)
+F32, F64 = 0, 1
+MEAN, SUM, MIN, MAX, NANMEAN, DD, BINS, SINE_DD, IDENTITY = range(9)
+TF_NONE, TF_POW, TF_HINGE = 0, 1, 2
+CALC_CODE = {"mean": MEAN, "sum": SUM, "min": MIN, "max": MAX, "nanmean": NANMEAN,
+             "dd": DD, "bins": BINS, "sine_dd": SINE_DD}
+E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4
+
+EXPORTS = (
+    "afhip_last_error", "afhip_abi_version", "afhip_device_count", "afhip_device_info",
+    "afhip_group_stat", "afhip_group_dd", "afhip_group_bins", "afhip_group_sine_dd",
+    "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg",
+    "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
+    "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
+)
+
+
+class HipEngineError(RuntimeError):
+    """The HIP engine is unavailable or a HIP call failed."""
+
+
+class HipUnsupported(HipEngineError):
+    """A valid plan the fused kernels cannot express in one pass (AFHIP_E_UNSUPPORTED)."""
+
+
+class Column(C.Structure):
+    _fields_ = [("inner", C.c_int32), ("transform", C.c_int32), ("outer", C.c_int32),
+                ("reserved", C.c_int32), ("inner_args", C.c_double * 3),
+                ("transform_arg", C.c_double), ("outer_args", C.c_double * 3)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("T", C.c_int64), ("n_cells", C.c_int64), ("dtype", C.c_int32), ("K", C.c_int32),
+                ("G1", C.c_int64), ("inner_bounds", C.POINTER(C.c_int64)),
+                ("P", C.c_int64), ("outer_bounds", C.POINTER(C.c_int64)),
+                ("columns", C.POINTER(Column)), ("exact_order", C.c_int32), ("tuning", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises HipEngineError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipEngineError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C aggfly_amd/csrc`).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise HipEngineError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    lib.afhip_last_error.restype = C.c_char_p
+    lib.afhip_plan_workspace_bytes.restype = i64
+    lib.afhip_csr_destroy.restype = None
+    lib.afhip_plan_destroy.restype = None
+    lib.afhip_device_info.argtypes = [i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)]
+    lib.afhip_group_stat.argtypes = [vp, i32, i64, i64, vp, i64, i32, vp, vp]
+    for nm in ("afhip_group_dd", "afhip_group_bins", "afhip_group_sine_dd"):
+        getattr(lib, nm).argtypes = [vp, i32, i64, i64, vp, i64, vp, i64, vp, vp]
+    lib.afhip_csr_create.argtypes = [vp, vp, vp, i64, i64, i64, C.POINTER(vp)]
+    lib.afhip_csr_destroy.argtypes = [vp]
+    lib.afhip_scatter_block.argtypes = [vp, vp, i64, vp, vp]
+    lib.afhip_spatial_wavg.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp]
+    lib.afhip_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(vp)]
+    lib.afhip_plan_destroy.argtypes = [vp]
+    lib.afhip_plan_workspace_bytes.argtypes = [vp]
+    lib.afhip_plan_describe.argtypes = [vp, C.c_char_p, i32]
+    lib.afhip_plan_run_temporal.argtypes = [vp, vp, vp, vp, vp]
+    lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = load().afhip_last_error().decode("utf-8", "replace")
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_UNSUPPORTED:
+        raise HipUnsupported(msg)
+    raise HipEngineError(f"HIP engine error {rc}: {msg}")
+
+
+def device_count() -> int:
+    return int(load().afhip_device_count())
+
+
+def device_info(dev: int = 0) -> dict:
+    name, arch = C.create_string_buffer(256), C.create_string_buffer(256)
+    cus, mem = C.c_int(0), C.c_int64(0)
+    _check(load().afhip_device_info(dev, name, 256, arch, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "arch": arch.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+
+def require_gpu():
+    """Fail loudly when the product path is asked to run without a GPU."""
+    if device_count() < 1:
+        raise HipEngineError("no HIP device visible: the aggregation engine runs on MI355X only (no CPU fallback)")
+
+
+# --------------------------------------------------------------------------------------
+# torch plumbing (device memory + stream only)
+# --------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(t) -> int:
+    torch = _torch()
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise TypeError(f"climate cube must be float32 or float64, got {t.dtype}")
+
+
+def _dev_cube(t):
+    """(T, cells...) CUDA tensor, contiguous, time-major -> (tensor, T, n_cells)."""
+    if not t.is_cuda:
+        raise HipEngineError("cube must be resident in HBM (a CUDA/HIP tensor)")
+    t = t.contiguous()
+    T = t.shape[0]
+    return t, int(T), int(t.numel() // max(T, 1)) if T else int(np.prod(t.shape[1:]))
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int64)
+
+
+def _group(fn_name, cube, bounds, code=None, ddargs=None):
+    torch = _torch()
+    lib = load()
+    require_gpu()
+    cube, T, n_cells = _dev_cube(cube)
+    bounds = _i64(bounds)
+    G = len(bounds) - 1
+    if bounds[0] != 0 or bounds[-1] != T or np.any(np.diff(bounds) < 0):
+        raise ValueError("bounds must be monotone and run from 0 to T")
+    spatial = tuple(cube.shape[1:])
+    if ddargs is None:
+        out = torch.empty((G,) + spatial, dtype=cube.dtype, device=cube.device)
+        if G:
+            _check(lib.afhip_group_stat(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
+                                        int(code), out.data_ptr(), _stream_ptr()))
+        return out
+    dda = np.ascontiguousarray(np.atleast_2d(np.asarray(ddargs, dtype=np.float64)))
+    D = dda.shape[0]
+    out = torch.empty((G,) + spatial + (D,), dtype=cube.dtype, device=cube.device)
+    MAXD = 16
+    if G:
+        if D <= MAXD:
+            _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
+                                         dda.ctypes.data, D, out.data_ptr(), _stream_ptr()))
+        else:  # more thresholds than one pass holds: run passes of 16 and interleave
+            for d0 in range(0, D, MAXD):
+                sub = np.ascontiguousarray(dda[d0:d0 + MAXD])
+                tmp = torch.empty((G,) + spatial + (len(sub),), dtype=cube.dtype, device=cube.device)
+                _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
+                                             sub.ctypes.data, len(sub), tmp.data_ptr(), _stream_ptr()))
+                out[..., d0:d0 + len(sub)] = tmp
+    return out
+
+
+def group_stat(cube, bounds, calc: str):
+    """`_block_stat` (`aggfly/aggregate/nb_kernels.py:121-155`): cube[T,NY,NX] -> out[G,NY,NX]."""
+    return _group("afhip_group_stat", cube, bounds, code=CALC_CODE[calc])
+
+
+def group_dd(cube, bounds, ddargs):
+    """`_block_dd` (`nb_kernels.py:158-179`): -> out[G,NY,NX,D]."""
+    return _group("afhip_group_dd", cube, bounds, ddargs=ddargs)
+
+
+def group_bins(cube, bounds, ddargs):
+    """`_block_bins` (`nb_kernels.py:182-199`): -> out[G,NY,NX,D]."""
+    return _group("afhip_group_bins", cube, bounds, ddargs=ddargs)
+
+
+def group_sine_dd(cube, bounds, ddargs):
+    """`_block_sine_dd` (`nb_kernels.py:202-251`): -> out[G,NY,NX,D]."""
+    return _group("afhip_group_sine_dd", cube, bounds, ddargs=ddargs)
+
+
+class CSR:
+    """Region x cell weights resident in HBM (`_weight_triplets`, `aggfly/aggregate/spatial.py:157-178`).
+
+    Built from COO triplets in table order; a stable sort by region row keeps the table's
+    entry order inside each row, which is the order `np.add.at` sums in.
+    """
+
+    def __init__(self, region_idx, cell_idx, w_vals, n_regions: int, n_cells: int):
+        lib = load()
+        require_gpu()
+        region_idx = _i64(region_idx)
+        cell_idx = _i64(cell_idx)
+        w = np.ascontiguousarray(np.asarray(w_vals, dtype=np.float64))
+        if not (len(region_idx) == len(cell_idx) == len(w)):
+            raise ValueError("COO triplets must have equal lengths")
+        if len(region_idx) and (region_idx.min() < 0 or region_idx.max() >= n_regions):
+            raise ValueError("region index out of range")
+        order = np.argsort(region_idx, kind="stable")
+        counts = np.bincount(region_idx, minlength=n_regions)
+        self.indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.cols = np.ascontiguousarray(cell_idx[order])
+        self.w = np.ascontiguousarray(w[order])
+        self.R, self.nnz, self.n_cells = int(n_regions), int(len(w)), int(n_cells)
+        h = C.c_void_p()
+        _check(lib.afhip_csr_create(self.indptr.ctypes.data, self.cols.ctypes.data, self.w.ctypes.data,
+                                    self.R, self.nnz, self.n_cells, C.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().afhip_csr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scatter_block(self, block):
+        """`_scatter_block` (`spatial.py:181-186`): block[n_cells, t] f64 -> out[R, t]."""
+        torch = _torch()
+        block = block.contiguous()
+        if block.dtype != torch.float64 or block.shape[0] != self.n_cells:
+            raise ValueError("block must be float64 [n_cells, t]")
+        nt = int(block.shape[1])
+        out = torch.empty((self.R, nt), dtype=torch.float64, device=block.device)
+        _check(load().afhip_scatter_block(self._h, block.data_ptr(), nt, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def wavg(self, x):
+        """Shared validity + num/den + divide (`spatial.py:110-133`): x[K, n_cells, t] f64
+        -> (num[K,R,t], den[R,t], res[K,R,t])."""
+        torch = _torch()
+        x = x.contiguous()
+        if x.dtype != torch.float64 or x.ndim != 3 or x.shape[1] != self.n_cells:
+            raise ValueError("x must be float64 [K, n_cells, t]")
+        K, _, nt = (int(v) for v in x.shape)
+        num = torch.empty((K, self.R, nt), dtype=torch.float64, device=x.device)
+        den = torch.empty((self.R, nt), dtype=torch.float64, device=x.device)
+        res = torch.empty((K, self.R, nt), dtype=torch.float64, device=x.device)
+        _check(load().afhip_spatial_wavg(self._h, x.data_ptr(), K, nt, num.data_ptr(), den.data_ptr(),
+                                         res.data_ptr(), _stream_ptr()))
+        return num, den, res
+
+
+class FusedPlan:
+    """One pass over the raw cube for K output columns (afhip_plan_* in include/aggfly_hip.h).
+
+    ``columns`` is a list of dicts: inner (calc name), inner_args (t0,t1,flag), transform
+    (None | 'pow' | 'hinge'), transform_arg, outer (calc name or 'identity'), outer_args.
+    """
+
+    def __init__(self, T, n_cells, dtype_code, inner_bounds, outer_bounds, columns,
+                 exact_order=False, tuning=0):
+        lib = load()
+        require_gpu()
+        self.ib = _i64(inner_bounds)
+        self.ob = _i64(outer_bounds)
+        self.K = len(columns)
+        self.P = len(self.ob) - 1
+        self.T, self.n_cells, self.dtype_code = int(T), int(n_cells), int(dtype_code)
+        cols = (Column * self.K)()
+        for j, c in enumerate(columns):
+            cols[j].inner = CALC_CODE[c["inner"]]
+            tf = c.get("transform")
+            cols[j].transform = {None: TF_NONE, "pow": TF_POW, "hinge": TF_HINGE}[tf]
+            cols[j].transform_arg = float(c.get("transform_arg", 0.0))
+            outer = c.get("outer", "identity")
+            cols[j].outer = IDENTITY if outer == "identity" else CALC_CODE[outer]
+            for i, v in enumerate(c.get("inner_args", (0.0, 0.0, 0.0))):
+                cols[j].inner_args[i] = float(v)
+            for i, v in enumerate(c.get("outer_args", (0.0, 0.0, 0.0))):
+                cols[j].outer_args[i] = float(v)
+        d = PlanDesc()
+        d.T, d.n_cells, d.dtype, d.K = self.T, self.n_cells, self.dtype_code, self.K
+        d.G1 = len(self.ib) - 1
+        d.inner_bounds = self.ib.ctypes.data_as(C.POINTER(C.c_int64))
+        d.P = self.P
+        d.outer_bounds = self.ob.ctypes.data_as(C.POINTER(C.c_int64))
+        d.columns = cols
+        d.exact_order = 1 if exact_order else 0
+        d.tuning = int(tuning)
+        h = C.c_void_p()
+        _check(lib.afhip_plan_create(C.byref(d), C.byref(h)))
+        self._h = h
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(2048)
+        load().afhip_plan_describe(self._h, buf, 2048)
+        return buf.value.decode()
+
+    def workspace_bytes(self) -> int:
+        return int(load().afhip_plan_workspace_bytes(self._h))
+
+    def _check_cube(self, cube):
+        cube, T, n_cells = _dev_cube(cube)
+        if T != self.T or n_cells != self.n_cells or _dtype_code(cube) != self.dtype_code:
+            raise ValueError(f"cube shape/dtype does not match the plan (T={self.T}, cells={self.n_cells})")
+        return cube
+
+    def run_temporal(self, cube):
+        """-> cells[K, P, n_cells] float64 (the temporal stage's per-cell output)."""
+        torch = _torch()
+        cube = self._check_cube(cube)
+        cells = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=cube.device)
+        _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), None, _stream_ptr()))
+        return cells
+
+    def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None):
+        """-> dict(num[K,R,P], den[R,P], res[K,R,P], cells?, kernel_ms?)."""
+        torch = _torch()
+        cube = self._check_cube(cube)
+        dev = cube.device
+        if out is None:
+            out = {"num": torch.empty((self.K, csr.R, self.P), dtype=torch.float64, device=dev),
+                   "den": torch.empty((csr.R, self.P), dtype=torch.float64, device=dev),
+                   "res": torch.empty((self.K, csr.R, self.P), dtype=torch.float64, device=dev)}
+            if want_cells:
+                out["cells"] = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=dev)
+        ms = (C.c_float * 2)() if timed else None
+        cells_ptr = out["cells"].data_ptr() if "cells" in out else None
+        _check(load().afhip_plan_run(self._h, cube.data_ptr(), csr.handle, out["num"].data_ptr(),
+                                     out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, None,
+                                     _stream_ptr(), ms))
+        if timed:
+            out["kernel_ms"] = (float(ms[0]), float(ms[1]))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().afhip_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

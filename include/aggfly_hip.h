@@ -1,0 +1,190 @@
+/* aggfly_hip.h — C ABI of the MI355X (gfx950) engine for aggfly's aggregate_dataset() hot path.
+ *
+ * The reference (dylanhogan/aggfly v0.2.0) is pure Python; it has no FFI layer.  The
+ * seams this library sits behind are its numba kernels and numpy block functions, which
+ * are already C-shaped: contiguous arrays in, caller-owned output, no exceptions
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - `*_dev` pointers are device (HBM) addresses owned by the caller; tables marked
+ *     HOST are read on the host during the call and may be freed afterwards;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it and the call returns without synchronising unless stated;
+ *   - cubes are time-major: element (k, cell) at cube[k * n_cells + cell], cell =
+ *     iy * NX + ix, exactly the (time, y, x) block the reference hands its kernels
+ *     (aggfly/aggregate/nb_kernels.py:280);
+ *   - every function returns 0 on success or a negative AFHIP_E_* code;
+ *     afhip_last_error() gives the message for the calling thread.  Like the numba
+ *     kernels, the GPU kernels themselves never raise: argument errors are reported
+ *     before anything is launched.
+ */
+#ifndef AGGFLY_HIP_H
+#define AGGFLY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFHIP_ABI_VERSION 1
+
+/* status codes */
+#define AFHIP_OK            0
+#define AFHIP_E_INVALID    -1   /* bad argument (the Python host raises ValueError)      */
+#define AFHIP_E_HIP        -2   /* a HIP runtime call failed                              */
+#define AFHIP_E_UNSUPPORTED -3  /* valid plan the fused kernels cannot express            */
+#define AFHIP_E_NOMEM      -4
+
+/* element type of a climate cube */
+#define AFHIP_F32 0
+#define AFHIP_F64 1
+
+/* reducer codes: 0..4 are _STAT_CODE of aggfly/aggregate/nb_kernels.py:33 */
+#define AFHIP_MEAN     0
+#define AFHIP_SUM      1
+#define AFHIP_MIN      2
+#define AFHIP_MAX      3
+#define AFHIP_NANMEAN  4
+#define AFHIP_DD       5   /* _block_dd      nb_kernels.py:158-179 */
+#define AFHIP_BINS     6   /* _block_bins    nb_kernels.py:182-199 */
+#define AFHIP_SINE_DD  7   /* _block_sine_dd nb_kernels.py:202-251 */
+#define AFHIP_IDENTITY 8   /* outer level of a single-level plan: pass the inner value through */
+
+/* element-wise transforms between the two temporal levels */
+#define AFHIP_TF_NONE  0
+#define AFHIP_TF_POW   1   /* Dataset.power / _power  aggfly/dataset/dataset.py:442-473,527-543 */
+#define AFHIP_TF_HINGE 2   /* Dataset.spline hinge (x>knot)*(x-knot), dataset.py:475-481 (knot 20) */
+
+const char* afhip_last_error(void);
+int afhip_abi_version(void);
+/* Number of visible GPUs (hipGetDeviceCount); 0 when there is none. */
+int afhip_device_count(void);
+/* Name/arch/CU count of device `dev` into caller buffers (arch e.g. "gfx950"). */
+int afhip_device_info(int dev, char* name, int name_len, char* arch, int arch_len, int* n_cus,
+                      int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Grouped temporal reducers — drop-in for the numba kernels.
+ *
+ *   afhip_group_stat     replaces _block_stat(cube, bounds, code, out)        nb_kernels.py:121-155
+ *   afhip_group_dd       replaces _block_dd(cube, bounds, ddargs, out)        nb_kernels.py:158-179
+ *   afhip_group_bins     replaces _block_bins(cube, bounds, ddargs, out)      nb_kernels.py:182-199
+ *   afhip_group_sine_dd  replaces _block_sine_dd(cube, bounds, ddargs, out)   nb_kernels.py:202-251
+ *
+ * cube_dev   [T, n_cells] of `dtype`;  bounds HOST int64[G+1], group g = steps
+ *            [bounds[g], bounds[g+1]) (empty groups allowed -> NaN);
+ * ddargs     HOST double[D*3] rows (t0, t1, flag) as in the reference;
+ * out_dev    [G, n_cells] (stat) or [G, n_cells, D] of `dtype` — the reference's output
+ *            layout and dtype (accumulation is float64, the store rounds to `dtype`,
+ *            nb_kernels.py:257-268).
+ * ---------------------------------------------------------------------------------- */
+int afhip_group_stat(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
+                     const int64_t* bounds, int64_t G, int code, void* out_dev, void* stream);
+int afhip_group_dd(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
+                   const int64_t* bounds, int64_t G, const double* ddargs, int64_t D,
+                   void* out_dev, void* stream);
+int afhip_group_bins(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
+                     const int64_t* bounds, int64_t G, const double* ddargs, int64_t D,
+                     void* out_dev, void* stream);
+int afhip_group_sine_dd(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
+                        const int64_t* bounds, int64_t G, const double* ddargs, int64_t D,
+                        void* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Region x cell weights, uploaded once as CSR.
+ *
+ * Replaces the COO triplets of _weight_triplets (aggfly/aggregate/spatial.py:157-178).
+ * Rows are regions in sorted-region-id order; inside a row the entries keep the weights
+ * table's order, so sums run in the order np.add.at visits them (spatial.py:185).
+ * indptr HOST int64[R+1]; cols HOST int64[nnz] (cell positions, 0 <= col < n_cells);
+ * w HOST double[nnz].  The handle owns device copies; free with afhip_csr_destroy.
+ * ---------------------------------------------------------------------------------- */
+typedef struct afhip_csr afhip_csr;
+int afhip_csr_create(const int64_t* indptr, const int64_t* cols, const double* w, int64_t R,
+                     int64_t nnz, int64_t n_cells, afhip_csr** out);
+void afhip_csr_destroy(afhip_csr* csr);
+
+/* Replaces _scatter_block(block, region_idx, cell_idx, w_vals, n_regions)
+ * (spatial.py:181-186): out[r, t] = sum_j w[j] * block[col[j], t], float64, entries in
+ * table order, products rounded before each add (no fused multiply-add).
+ * block_dev [n_cells, nt] float64; out_dev [R, nt] float64. */
+int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
+                        double* out_dev, void* stream);
+
+/* Replaces the body of SpatialAggregator.compute (spatial.py:110-133) for K names:
+ * shared validity (all K non-NaN), den = W.valid, num_k = W.where(valid, x_k, 0),
+ * res = num/den where den != 0 else NaN.
+ * x_dev [K, n_cells, nt] float64; num_dev [K, R, nt]; den_dev [R, nt]; res_dev [K, R, nt]
+ * (num_dev / den_dev may be NULL). */
+int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int64_t K, int64_t nt,
+                       double* num_dev, double* den_dev, double* res_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused plan: one pass over the raw cube for all output columns.
+ *
+ * Replaces, for one aggregate_dataset() call, the lazy graph built by aggregate_time
+ * (aggfly/aggregate/aggregate.py:101-162) + SpatialAggregator.compute and executed by the
+ * single dask.compute at spatial.py:125.  A column is
+ *
+ *     inner reducer over inner groups of raw steps        ('aggregate', calc @ groupby)
+ *       -> element-wise transform                         ('transform', power / spline)
+ *       -> outer reducer over outer groups of inner values ('aggregate', calc @ groupby)
+ *
+ * A single-level spec uses outer = AFHIP_IDENTITY with outer_bounds = [0,1,..,G1].
+ * ---------------------------------------------------------------------------------- */
+typedef struct afhip_column {
+    int32_t inner;          /* AFHIP_MEAN..AFHIP_SINE_DD                                   */
+    int32_t transform;      /* AFHIP_TF_*                                                   */
+    int32_t outer;          /* AFHIP_MEAN, SUM, MIN, MAX, DD, BINS or AFHIP_IDENTITY        */
+    int32_t reserved;
+    double inner_args[3];   /* (t0, t1, flag) for DD / BINS / SINE_DD                       */
+    double transform_arg;   /* exponent (POW) or knot (HINGE)                               */
+    double outer_args[3];   /* (t0, t1, flag) for an outer DD / BINS                        */
+} afhip_column;
+
+typedef struct afhip_plan_desc {
+    int64_t T;                     /* time steps in the cube                                */
+    int64_t n_cells;               /* NY*NX                                                  */
+    int32_t dtype;                 /* AFHIP_F32 / AFHIP_F64                                  */
+    int32_t K;                     /* number of columns                                      */
+    int64_t G1;                    /* inner groups                                           */
+    const int64_t* inner_bounds;   /* HOST int64[G1+1] over time steps                       */
+    int64_t P;                     /* outer groups (output periods)                          */
+    const int64_t* outer_bounds;   /* HOST int64[P+1] over inner groups                      */
+    const afhip_column* columns;   /* HOST [K]                                               */
+    int32_t exact_order;           /* 1: never split an outer period across workgroups, so
+                                      every per-cell sum runs in the reference's order       */
+    int32_t tuning;                /* 0 = default; see DESIGN.md (pipeline variant override) */
+} afhip_plan_desc;
+
+typedef struct afhip_plan afhip_plan;
+int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out);
+void afhip_plan_destroy(afhip_plan* plan);
+/* Bytes of device scratch the plan needs (per-chunk partials + the cell-major panel). */
+int64_t afhip_plan_workspace_bytes(const afhip_plan* plan);
+/* Human-readable lowering (kernel variant, chunks, slots) into buf; returns bytes needed. */
+int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_len);
+
+/* Temporal stage only: cells_dev[K, P, n_cells] float64 = the per-cell, per-period value
+ * of every column (NaN where the reference's temporal stage yields NaN).  This is what
+ * aggregate_time returns before the spatial step (aggregate.py:160-162).
+ * workspace_dev may be NULL (the plan then allocates and caches its own). */
+int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cells_dev,
+                            void* workspace_dev, void* stream);
+
+/* Whole path: temporal stage, shared validity, CSR weighted sums, divide.
+ * num_dev [K, R, P], den_dev [R, P], res_dev [K, R, P] float64 (num/den may be NULL);
+ * cells_dev optional as above (NULL to skip materialising it).
+ * If kernel_ms is not NULL the call records HIP events on `stream` around the temporal
+ * kernel and around the whole sequence, synchronises the stream, and writes
+ * kernel_ms[0] = temporal kernel ms, kernel_ms[1] = whole sequence ms. */
+int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhip_csr* csr,
+                   double* num_dev, double* den_dev, double* res_dev, double* cells_dev,
+                   void* workspace_dev, void* stream, float* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGGFLY_HIP_H */

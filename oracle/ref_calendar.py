@@ -1,0 +1,140 @@
+"""Oracle-side CF calendars (noleap / 360_day / all_leap) without cftime.  TEST INFRASTRUCTURE.
+
+The reference groups non-standard calendars with xarray's cftime-aware resample
+(`aggfly/aggregate/nb_kernels.py:100-110`): one count per output bin in bin order,
+empty interior bins kept (zero-filled there, `:108`), labels = the resample bin labels
+("1D" -> bin start, "ME"/"YE" -> period end, `aggfly/aggregate/temporal.py:456`).  cftime
+and xarray are not installed here, so this file restates that grouping from the CF
+calendar definitions.  Written independently of ``aggfly_amd/cfcalendar.py`` (the product's
+own calendar engine) so that the two check each other in tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_NOLEAP_MDAYS = (31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)
+_ALLLEAP_MDAYS = (31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)
+
+
+def _month_lengths(calendar: str):
+    if calendar in ("noleap", "365_day"):
+        return _NOLEAP_MDAYS
+    if calendar in ("all_leap", "366_day"):
+        return _ALLLEAP_MDAYS
+    if calendar == "360_day":
+        return (30,) * 12
+    raise ValueError(f"oracle calendar: unsupported calendar {calendar!r}")
+
+
+class OracleCFTime:
+    """One timestamp on a CF calendar; carries ``.calendar`` like a cftime object."""
+
+    __slots__ = ("year", "month", "day", "hour", "calendar")
+
+    def __init__(self, year, month, day, hour=0, calendar="noleap"):
+        self.year, self.month, self.day, self.hour, self.calendar = year, month, day, hour, calendar
+
+    def _key(self):
+        return (self.year, self.month, self.day, self.hour)
+
+    def __eq__(self, other):
+        return isinstance(other, OracleCFTime) and self._key() == other._key() and self.calendar == other.calendar
+
+    def __lt__(self, other):
+        return self._key() < other._key()
+
+    def __hash__(self):
+        return hash((self._key(), self.calendar))
+
+    def __repr__(self):
+        return f"OracleCFTime({self.year:04d}-{self.month:02d}-{self.day:02d} {self.hour:02d}h, {self.calendar})"
+
+
+class OracleCFIndex:
+    """A time axis on a CF calendar: arrays of year/month/day/hour + calendar name."""
+
+    def __init__(self, year, month, day, hour, calendar):
+        self.year = np.asarray(year, dtype=np.int64)
+        self.month = np.asarray(month, dtype=np.int64)
+        self.day = np.asarray(day, dtype=np.int64)
+        self.hour = np.asarray(hour, dtype=np.int64)
+        self.calendar = calendar
+
+    def __len__(self):
+        return len(self.year)
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            return OracleCFTime(int(self.year[i]), int(self.month[i]), int(self.day[i]), int(self.hour[i]), self.calendar)
+        i = np.asarray(i)
+        return OracleCFIndex(self.year[i], self.month[i], self.day[i], self.hour[i], self.calendar)
+
+    def day_ordinal(self):
+        ml = _month_lengths(self.calendar)
+        cum = np.concatenate([[0], np.cumsum(ml)])
+        return self.year * cum[-1] + cum[self.month - 1] + (self.day - 1)
+
+    @property
+    def is_monotonic_increasing(self):
+        key = self.day_ordinal() * 24 + self.hour
+        return bool(np.all(np.diff(key) >= 0))
+
+
+def cf_daily_index(calendar: str, ndays: int, start=(2000, 1, 1)) -> OracleCFIndex:
+    """`xr.date_range(start, periods=ndays, freq="D", calendar=calendar, use_cftime=True)`
+    as used by the reference tests (`aggfly/tests/test_aggregate.py:436-440`)."""
+    ml = _month_lengths(calendar)
+    y, m, d = start
+    ys, ms, ds = [], [], []
+    for _ in range(ndays):
+        ys.append(y); ms.append(m); ds.append(d)
+        d += 1
+        if d > ml[m - 1]:
+            d = 1
+            m += 1
+            if m > 12:
+                m = 1
+                y += 1
+    return OracleCFIndex(ys, ms, ds, np.zeros(ndays, dtype=np.int64), calendar)
+
+
+def cf_resample_groups(index: OracleCFIndex, freq: str):
+    """Contiguous group bounds + labels for a CF-calendar axis.
+
+    Restates the cftime branch of `resample_groups` (`nb_kernels.py:100-110`): bins are
+    consecutive calendar days / months / years from the first to the last timestamp,
+    an empty interior bin is a zero-width range, labels are bin starts for "1D" and
+    period ends (last calendar day, 00:00) for "ME"/"YE".
+    """
+    if not index.is_monotonic_increasing:
+        raise ValueError("monotonic-increasing time index required")
+    ml = _month_lengths(index.calendar)
+    if freq == "1D":
+        ordinal = index.day_ordinal()
+    elif freq == "ME":
+        ordinal = index.year * 12 + (index.month - 1)
+    elif freq == "YE":
+        ordinal = index.year.copy()
+    elif freq == "W":
+        raise NotImplementedError("groupby='week' is not supported on non-standard CF calendars")
+    else:
+        raise KeyError(freq)
+    first = int(ordinal[0])
+    nbins = int(ordinal[-1]) - first + 1
+    counts = np.bincount(ordinal - first, minlength=nbins)
+    bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+
+    labels = []
+    cum = np.concatenate([[0], np.cumsum(ml)])
+    for b in range(nbins):
+        o = first + b
+        if freq == "1D":
+            y, doy = divmod(o, int(cum[-1]))
+            m = int(np.searchsorted(cum, doy, side="right"))
+            labels.append(OracleCFTime(y, m, doy - int(cum[m - 1]) + 1, 0, index.calendar))
+        elif freq == "ME":
+            y, m0 = divmod(o, 12)
+            labels.append(OracleCFTime(y, m0 + 1, ml[m0], 0, index.calendar))
+        else:
+            labels.append(OracleCFTime(o, 12, ml[11], 0, index.calendar))
+    return bounds, labels
