@@ -1,0 +1,354 @@
+"""Public aggregation API — same names, arguments and error behaviour as the reference's
+`aggfly/aggregate/aggregate.py`, `temporal.py` and `spatial.py`, executed by the HIP engine.
+
+    aggregate_dataset(weights, dataset=None, aggregator_dict=None, dataset_dict=None,
+                      engine="auto", **kwargs) -> pd.DataFrame        aggregate.py:210-282
+    aggregate_time(dataset, weights=None, aggregator_dict=None, engine="auto", **kwargs)
+                                                                       aggregate.py:101-162
+    aggregate_space(dataset_dict, weights, npartitions=None, **kwargs) aggregate.py:165-198
+    TemporalAggregator(calc, groupby, ddargs=None, pre_compute=False, engine="auto")
+                                                                       temporal.py:19-263
+    SpatialAggregator(dataset, weights, names).compute()               spatial.py:37-154
+
+``engine`` accepts the reference's names plus ``"hip"``.  Every valid name runs the HIP
+engine (there is no dask or numba here); an unknown name raises ``ValueError`` like
+`resolve_engine` (`aggfly/aggregate/nb_kernels.py:59-74`).
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Union
+
+import numpy as np
+import pandas as pd
+
+from . import engine as eng
+from . import hip
+from .cfcalendar import CFTimeIndex
+from .dataarray import DataArray, _is_torch
+from .dataset import Dataset
+from .timegroups import resample_groups, translate_groupby
+
+ENGINES = ("auto", "hip", "dask", "numba")
+_DEPRECATED_CLUSTER_KWARGS = ("n_workers", "threads_per_worker", "processes", "memory_limit", "cluster_args")
+_warned_cpu_engine = False
+
+
+def resolve_engine(engine: str, da=None, calc: str = "mean") -> str:
+    """Engine selector seam (`nb_kernels.py:59-74`).  All valid names resolve to "hip"."""
+    global _warned_cpu_engine
+    if engine not in ENGINES:
+        raise ValueError(f"engine must be 'dask', 'numba', 'hip' or 'auto', got {engine!r}")
+    if engine in ("dask", "numba") and not _warned_cpu_engine:
+        _warned_cpu_engine = True
+        warnings.warn(f"engine={engine!r} is kept for API compatibility; this build has no CPU engines "
+                      "and runs the HIP (MI355X) engine", RuntimeWarning, stacklevel=3)
+    return "hip"
+
+
+# dask-client helpers of the reference (`aggfly/aggregate/aggregate_utils.py:38-102`): there is
+# no dask scheduler to manage; kept so existing scripts and the CLI import cleanly.
+def distributed_client():
+    return None
+
+
+def is_distributed() -> bool:
+    return False
+
+
+def start_dask_client(n_workers: int = 2, threads_per_worker: int = 2, cap_numba_threads: int = 1, **kwargs):
+    warnings.warn("start_dask_client is a no-op: the HIP engine does not use dask", RuntimeWarning, stacklevel=2)
+    return None
+
+
+def shutdown_dask_client():
+    return None
+
+
+# --------------------------------------------------------------------------------------
+# temporal
+# --------------------------------------------------------------------------------------
+def _labels_of(ds: Dataset):
+    return ds.da.coords["time"]
+
+
+def _time_major(ds: Dataset):
+    return eng.device_cube(ds)
+
+
+def _dataset_from_cells(template: Dataset, cells_pc, labels, history) -> Dataset:
+    """Wrap a [P, n_cells] device tensor as a Dataset on the template's grid."""
+    ny, nx = len(template.latitude), len(template.longitude)
+    data = cells_pc.reshape(cells_pc.shape[0], ny, nx)
+    da = DataArray(data, ("time", "latitude", "longitude"),
+                   {"time": labels, "latitude": template.latitude, "longitude": template.longitude})
+    new = template.deepcopy()
+    new.da = da
+    new.history = list(history)
+    return new
+
+
+class TemporalAggregator:
+    """One grouped temporal reduction (`temporal.py:19-263`)."""
+
+    def __init__(self, calc: str, groupby: str, ddargs=None, pre_compute: bool = False, engine: str = "auto"):
+        if calc not in eng.HIP_CALCS:
+            raise ValueError(f"unknown calc {calc!r}; supported: {sorted(eng.HIP_CALCS)}")
+        self.calc = calc
+        self.groupby = translate_groupby(groupby)          # KeyError on unknown names, temporal.py:456
+        self.ddargs = ddargs
+        self.multi_dd = ddargs is not None and np.array(ddargs).ndim > 1
+        self.pre_compute = pre_compute
+        self.engine = engine
+        self.kwargs = {"ddargs": ddargs} if calc in eng.THR_CALCS else {}
+
+    def execute(self, dataset: Dataset, weights=None, update: bool = False, **kwargs):
+        """Run this step on ``dataset`` (single level) and return a Dataset, or a list of
+        Datasets for a multi-row ``ddargs`` (`temporal.py:165-263`)."""
+        resolve_engine(self.engine, None, self.calc)
+        tindex = _labels_of(dataset)
+        if self.groupby == "W" and isinstance(tindex, CFTimeIndex):                # temporal.py:221-227
+            raise NotImplementedError(
+                "groupby='week' is not supported on non-standard CF calendars (noleap/360_day/etc.): "
+                "xarray/cftime has no weekly offset. Use 'date', 'month', or 'year'.")
+        if len(dataset.da.dims) != 3:
+            raise ValueError(f"the temporal engine expects 2 spatial dims, got {dataset.da.dims}")
+        cube = _time_major(dataset)
+        bounds, labels = resample_groups(tindex, self.groupby)
+        rows = np.atleast_2d(np.asarray(self.ddargs, dtype=float)) if self.ddargs is not None else [None]
+        cols = [eng.ColumnProg("x", eng.AggStep(self.calc, self.groupby, None if r is None else tuple(r))) for r in rows]
+        ob = np.arange(len(bounds), dtype=np.int64)
+        outs = []
+        for i in range(0, len(cols), eng.MAX_COLS_PER_PASS):
+            for pr in eng.run_fused_pass(cube, cols[i:i + eng.MAX_COLS_PER_PASS], bounds, ob):
+                outs.extend(pr.cells[j] for j in range(pr.cells.shape[0]))
+        hist = list(dataset.history) + [self.groupby]
+        res = [_dataset_from_cells(dataset, c, labels, hist) for c in outs]
+        if self.multi_dd:
+            return res[0] if len(res) == 1 else res
+        if update:
+            dataset.da, dataset.history = res[0].da, res[0].history
+            return dataset
+        return res[0]
+
+
+def _apply_transform(ds: Dataset, key: str, params: dict):
+    """`transform_dataset` (`aggregate.py:36-78`) on a device-resident Dataset (staged path)."""
+    if "exp" in params:
+        exp = params["exp"]
+        if not isinstance(exp, list):
+            exp = [exp]
+        return [ds.power(e) for e in exp[0]], [f"{key}_{e}" for e in exp[0]]
+    if "inter" in params:
+        return [ds.interact(params["inter"])], [key]
+    if "spline" in params.get("transform", ""):
+        return list(ds.spline()), [f"{key}_spline{x}" for x in (1, 2)]
+    raise ValueError("No valid transform argument provided.")
+
+
+def _staged_name(dataset: Dataset, key: str, steps, engine: str) -> Dict[str, Dataset]:
+    """The reference's interpreter loop, one GPU step at a time (`aggregate.py:131-158`)."""
+    keys, data = [key], [dataset.deepcopy().to_device()]     # every step below runs in HBM
+    for kind, params in steps:
+        if kind == "aggregate":
+            agg = params if isinstance(params, TemporalAggregator) else TemporalAggregator(**params, engine=engine)
+            data = [agg.execute(x) for x in data]
+            if agg.multi_dd:
+                if len(data) > 1:
+                    raise ValueError("Cannot aggregate multiple datasets with multiple ddargs, "
+                                     "e.g., multiple polynomials for multiple bins")
+                d0 = data[0]
+                data = d0 if isinstance(d0, list) else [d0]
+                keys = [f"{key}_{x[0]}_{x[1]}" for x in agg.ddargs]
+        elif kind == "transform":
+            nd, nk = [], []
+            for d, k in zip(data, keys):
+                d2, k2 = _apply_transform(d, k, params)
+                nd.extend(d2)
+                nk.extend(k2)
+            data, keys = nd, nk
+        else:
+            raise ValueError(f"unknown step type {kind!r}")
+    return dict(zip(keys, data))
+
+
+def _lower_all(aggregator_dict):
+    """-> (ordered keys, {key: ColumnProg} for fused names, [names that must run staged])."""
+    fused_cols, staged, order = [], [], []
+    for name, steps in aggregator_dict.items():
+        cols, fusable = eng.lower_spec(name, steps)
+        order.append((name, [c.key for c in cols], fusable))
+        if fusable:
+            fused_cols.extend(cols)
+        else:
+            staged.append(name)
+    return order, fused_cols, staged
+
+
+def aggregate_time(dataset: Dataset, weights=None, aggregator_dict=None, engine: str = "auto", **kwargs) -> Dict[str, Dataset]:
+    """`aggregate_time` (`aggregate.py:101-162`): {output name: Dataset on the output time axis}."""
+    resolve_engine(engine)
+    if aggregator_dict is None:
+        if kwargs is None:
+            raise ValueError("No arguments provided.")
+        aggregator_dict = kwargs
+    tindex = _labels_of(dataset)
+    order, fused_cols, staged = _lower_all(aggregator_dict)
+    _guard_week(fused_cols, tindex)
+    results: Dict[str, Dataset] = {}
+    if fused_cols:
+        cube = _time_major(dataset)
+        for cols, ib, ob, labels in eng.plan_groups(tindex, fused_cols):
+            for pr in eng.run_fused_pass(cube, cols, ib, ob):
+                for j, k in enumerate(pr.keys):
+                    results[k] = _dataset_from_cells(dataset, pr.cells[j], labels, dataset.history)
+    for name in staged:
+        results.update(_staged_name(dataset, name, aggregator_dict[name], engine))
+    out = {}
+    for name, keys, _ in order:        # the reference's insertion order (`aggregate.py:160-161`)
+        for k in keys:
+            out[k] = results[k]
+    return out
+
+
+def _guard_week(cols, tindex):
+    if isinstance(tindex, CFTimeIndex):
+        for c in cols:
+            if c.inner.freq == "W" or (c.outer is not None and c.outer.freq == "W"):
+                raise NotImplementedError(
+                    "groupby='week' is not supported on non-standard CF calendars (noleap/360_day/etc.): "
+                    "xarray/cftime has no weekly offset. Use 'date', 'month', or 'year'.")
+
+
+# --------------------------------------------------------------------------------------
+# spatial
+# --------------------------------------------------------------------------------------
+def _same_labels(a, b) -> bool:
+    if isinstance(a, CFTimeIndex) or isinstance(b, CFTimeIndex):
+        return isinstance(a, CFTimeIndex) and isinstance(b, CFTimeIndex) and a == b
+    return len(a) == len(b) and bool(np.all(np.asarray(a) == np.asarray(b)))
+
+
+def _label_values(labels):
+    if isinstance(labels, CFTimeIndex):
+        arr = np.empty(len(labels), dtype=object)
+        for i, t in enumerate(labels):
+            arr[i] = t
+        return arr
+    return pd.DatetimeIndex(labels).values
+
+
+def _assemble_frame(res: np.ndarray, names, region_ids, labels, weights) -> pd.DataFrame:
+    """Long frame + NaN-row policy (`spatial.py:136-154`).  res: [K, R, P]."""
+    n_regions, n_time = res.shape[1], res.shape[2]
+    out = pd.DataFrame({"region_id": np.repeat(region_ids, n_time),
+                        "time": np.tile(_label_values(labels), n_regions)})
+    for k, nm in enumerate(names):
+        out[nm] = res[k].reshape(-1)
+    if getattr(weights, "zero_weight", "area") == "nan":
+        wsum = weights.weights.groupby("index_right")["weight"].sum()
+        zero_regions = set(wsum.index[~(wsum > 0)])
+        keep = out["region_id"].isin(zero_regions) | out[list(names)].notna().all(axis=1)
+        return out.loc[keep].reset_index(drop=True)
+    return out.dropna(subset=list(names)).reset_index(drop=True)
+
+
+class SpatialAggregator:
+    """Weighted regional average of temporally-reduced data (`spatial.py:37-154`)."""
+
+    def __init__(self, dataset: Union[list, Dataset], weights, names: Union[str, List[str]] = "climate"):
+        self.dataset = dataset if isinstance(dataset, list) else [dataset]
+        self.grid = weights.grid
+        self.weights_obj = weights
+        self.weights = weights.weights
+        self.names = [names] if isinstance(names, str) else list(names)
+        self.zero_weight = getattr(weights, "zero_weight", "area")
+
+    def compute(self, npartitions: int = None) -> pd.DataFrame:
+        import torch
+        labels = _labels_of(self.dataset[0])
+        for d in self.dataset[1:]:
+            if not _same_labels(labels, _labels_of(d)):
+                raise ValueError("all output variables must share one output time axis "
+                                 "(the reference would align them with NaN fill and drop the rows)")
+        csr, region_ids = eng.get_csr(self.weights_obj, self.dataset[0])
+        # [K, n_cells, P] float64 in HBM
+        xs = []
+        for d in self.dataset:
+            c = eng.device_cube(d)                                   # [P, ny, nx]
+            xs.append(c.reshape(c.shape[0], -1).t().to(torch.float64))
+        x = torch.stack(xs).contiguous()
+        _, _, res = csr.wavg(x)
+        return _assemble_frame(res.cpu().numpy(), self.names, region_ids, labels, self.weights_obj)
+
+
+def aggregate_space(dataset_dict: Dict[str, Dataset], weights, npartitions=None, **kwargs) -> pd.DataFrame:
+    """`aggregate_space` (`aggregate.py:165-198`)."""
+    return SpatialAggregator(list(dataset_dict.values()), weights, names=list(dataset_dict.keys())).compute()
+
+
+# --------------------------------------------------------------------------------------
+# the whole path
+# --------------------------------------------------------------------------------------
+def _merge_regions(df: pd.DataFrame, weights) -> pd.DataFrame:
+    """`aggregate.py:276-280`."""
+    gr = weights.georegions
+    return gr.shp[[gr.regionid]].merge(df, left_index=True, right_on="region_id").drop(columns="region_id")
+
+
+def panel_arrays(weights, dataset: Dataset, aggregator_dict, engine: str = "auto"):
+    """The numeric core of aggregate_dataset: -> (res [K,R,P] HBM tensor, names, region_ids,
+    labels).  One fused pass when every column shares its group frequencies; otherwise the
+    temporal outputs are gathered and reduced together so the validity mask stays shared
+    across ALL names (`spatial.py:114-119`)."""
+    import torch
+    resolve_engine(engine)
+    tindex = _labels_of(dataset)
+    order, fused_cols, staged = _lower_all(aggregator_dict)
+    _guard_week(fused_cols, tindex)
+    names = [k for _, keys, _ in order for k in keys]
+    csr, region_ids = eng.get_csr(weights, dataset)
+    if not staged:
+        groups = eng.plan_groups(tindex, fused_cols)
+        if len(groups) == 1 and [c.key for c in groups[0][0]] == names:
+            cols, ib, ob, labels = groups[0]
+            try:
+                pr = eng.run_fused_pass(_time_major(dataset), cols, ib, ob, csr=csr, want_cells=False)
+            except hip.HipUnsupported:
+                pr = []
+            if len(pr) == 1 and pr[0].panel is not None:
+                return pr[0].panel["res"], names, region_ids, labels
+    tdict = aggregate_time(dataset, weights, aggregator_dict, engine=engine)
+    labels = _labels_of(next(iter(tdict.values())))
+    xs = []
+    for nm in names:
+        d = tdict[nm]
+        if not _same_labels(labels, _labels_of(d)):
+            raise ValueError("all output variables must share one output time axis "
+                             "(the reference would align them with NaN fill and drop the rows)")
+        c = eng.device_cube(d)
+        xs.append(c.reshape(c.shape[0], -1).t().to(torch.float64))
+    _, _, res = csr.wavg(torch.stack(xs).contiguous())
+    return res, names, region_ids, labels
+
+
+def aggregate_dataset(weights, dataset: Dataset = None, aggregator_dict=None, dataset_dict=None,
+                      engine: str = "auto", **kwargs) -> pd.DataFrame:
+    """`aggregate_dataset` (`aggregate.py:210-282`): [regionid, time, <output columns>]."""
+    if dataset is None:
+        raise ValueError("No dataset provided.")
+    stale = {k: kwargs.pop(k) for k in _DEPRECATED_CLUSTER_KWARGS if k in kwargs}
+    if stale:
+        warnings.warn(
+            f"aggregate_dataset no longer builds a Dask cluster; {sorted(stale)} is/are ignored. "
+            "This engine runs on the GPU; no dask client is involved.", DeprecationWarning, stacklevel=2)
+    if aggregator_dict is None and kwargs:
+        aggregator_dict = kwargs
+    if aggregator_dict is not None:
+        res, names, region_ids, labels = panel_arrays(weights, dataset, aggregator_dict, engine)
+        df = _assemble_frame(res.cpu().numpy(), names, region_ids, labels, weights)
+    else:
+        if dataset_dict is None:
+            dataset_dict = {"variable": dataset}
+        df = aggregate_space(dataset_dict, weights)
+    return _merge_regions(df, weights)

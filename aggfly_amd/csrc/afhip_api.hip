@@ -109,10 +109,14 @@ struct afhip_plan {
     double* sums = nullptr;
     int64_t sums_bytes = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
+    std::vector<hipEvent_t> prof_ev;
+    int64_t prof_count = 0;
     ~afhip_plan() {
         if (own_ws) (void)hipFree(own_ws);
         if (sums) (void)hipFree(sums);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : prof_ev) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -547,7 +551,10 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         for (auto& e : plan->ev) if (!e) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventRecord(plan->ev[0], st));
     }
+    const bool prof = !plan->prof_ev.empty() && (size_t)(2 * plan->prof_count + 1) < plan->prof_ev.size();
+    if (prof) HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count)], st));
     if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
+    if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
     if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
     if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
@@ -564,6 +571,31 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         HIP_TRY(hipEventElapsedTime(&kernel_ms[1], plan->ev[0], plan->ev[2]));
     }
     return AFHIP_OK;
+}
+
+extern "C" int afhip_plan_profile_begin(afhip_plan* plan, int64_t max_launches) {
+    if (!plan || max_launches < 0) return fail(AFHIP_E_INVALID, "plan_profile_begin: bad arguments");
+    for (auto& e : plan->prof_ev) if (e) (void)hipEventDestroy(e);
+    plan->prof_ev.assign((size_t)(2 * max_launches), nullptr);
+    for (auto& e : plan->prof_ev) HIP_TRY(hipEventCreate(&e));
+    plan->prof_count = 0;
+    return AFHIP_OK;
+}
+
+extern "C" int64_t afhip_plan_profile_end(afhip_plan* plan, float* ms_out, int64_t cap) {
+    if (!plan) return 0;
+    const int64_t n = plan->prof_count;
+    for (int64_t i = 0; i < n && i < cap; ++i) {
+        if (hipEventSynchronize(plan->prof_ev[(size_t)(2 * i + 1)]) != hipSuccess ||
+            hipEventElapsedTime(&ms_out[i], plan->prof_ev[(size_t)(2 * i)], plan->prof_ev[(size_t)(2 * i + 1)]) != hipSuccess) {
+            fail(AFHIP_E_HIP, "plan_profile_end: event query failed");
+            return -1;
+        }
+    }
+    for (auto& e : plan->prof_ev) if (e) (void)hipEventDestroy(e);
+    plan->prof_ev.clear();
+    plan->prof_count = 0;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,327 @@
+"""Host scheduler of the HIP engine: spec lowering, plan cache, device residency, CSR cache.
+
+Replaces, for ``engine="hip"``, the lazy xarray/dask graph the reference builds in
+`aggregate_time` (`aggfly/aggregate/aggregate.py:101-162`) and runs at
+`aggfly/aggregate/spatial.py:125`:
+
+* ``lower_spec`` walks one output name's step list exactly like the reference's
+  interpreter loop (same fan-out, same key names, same errors) but symbolically, and emits
+  *column programs* ``inner reducer -> transform -> outer reducer``;
+* columns of all names that share their two group frequencies are packed into one fused
+  pass (``hip.FusedPlan``) that reads the raw cube ONCE — the reference re-reads the raw
+  data for every output name (`aggregate.py:133`);
+* a step list that does not fit the two-level shape (three 'aggregate' levels, a transform
+  on raw data, ``inter``) runs *staged*: the same GPU kernels, one step at a time, with the
+  intermediates kept in HBM.
+
+Nothing here computes on the CPU; without the HIP library or a GPU every entry point raises.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import weakref
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import pandas as pd
+
+from . import hip
+from .dataarray import DataArray, _is_torch
+from .dataset import Dataset
+from .timegroups import resample_groups, translate_groupby
+
+STAT_CALCS = ("mean", "sum", "min", "max", "nanmean")
+THR_CALCS = ("dd", "bins", "sine_dd")
+HIP_CALCS = frozenset(STAT_CALCS + THR_CALCS)           # NUMBA_CALCS, nb_kernels.py:34
+FUSED_OUTER = ("sum", "mean", "min", "max", "dd", "bins")
+MAX_COLS_PER_PASS = 16
+
+
+class config:
+    """Engine switches (also read from the environment at import)."""
+    #: never split an outer period across workgroups: per-cell sums then run in exactly the
+    #: reference's k-ascending order (bit-exact sums) at the cost of parallelism when there
+    #: are few outer periods.
+    exact_order = os.environ.get("AGGFLY_HIP_EXACT_ORDER", "0") == "1"
+    #: kernel tuning arm (see include/aggfly_hip.h, afhip_plan_desc.tuning)
+    tuning = int(os.environ.get("AGGFLY_HIP_TUNING", "0"))
+
+
+# --------------------------------------------------------------------------------------
+# spec lowering
+# --------------------------------------------------------------------------------------
+@dataclass
+class AggStep:
+    calc: str
+    freq: str
+    ddargs: Optional[tuple] = None      # one (t0, t1, flag) row, or None
+
+
+@dataclass
+class ColumnProg:
+    key: str
+    inner: Optional[AggStep] = None
+    tf: Optional[tuple] = None          # ("pow", e) | ("hinge", knot)
+    outer: Optional[AggStep] = None
+
+    def levels(self):
+        return (self.inner is not None) + (self.outer is not None)
+
+
+def _agg_params(params):
+    """Accept a params dict or a TemporalAggregator-like object (`aggregate.py:137-138`)."""
+    if isinstance(params, dict):
+        unknown = set(params) - {"calc", "groupby", "ddargs", "pre_compute"}
+        if unknown:
+            raise TypeError(f"TemporalAggregator got unexpected arguments {sorted(unknown)}")
+        calc, groupby, ddargs = params["calc"], params["groupby"], params.get("ddargs")
+        freq = translate_groupby(groupby)
+    else:
+        calc, freq, ddargs = params.calc, params.groupby, params.ddargs
+    if calc not in HIP_CALCS:
+        raise ValueError(f"unknown calc {calc!r}; supported: {sorted(HIP_CALCS)}")
+    multi = ddargs is not None and np.array(ddargs).ndim > 1              # temporal.py:156-161
+    if calc in THR_CALCS and ddargs is None:
+        raise ValueError(f"calc {calc!r} needs ddargs")
+    return calc, freq, ddargs, multi
+
+
+def lower_spec(key: str, steps):
+    """One output name -> (list[ColumnProg], fusable).
+
+    Mirrors the loop at `aggregate.py:131-158`: 'aggregate' maps over the current column
+    list; a multi-row ``ddargs`` fans out to ``{key}_{lo}_{hi}`` from the BASE key
+    (`aggregate.py:148,299`) and refuses more than one input (`:144-147`); 'transform' fans
+    out per column (`:150-157`).
+    """
+    cols = [ColumnProg(key)]
+    fusable = True
+    for kind, params in steps:
+        if kind == "aggregate":
+            calc, freq, ddargs, multi = _agg_params(params)
+            rows = [tuple(float(v) for v in r) for r in np.atleast_2d(np.asarray(ddargs, dtype=float))] if ddargs is not None else [None]
+            if multi and len(cols) > 1:
+                raise ValueError("Cannot aggregate multiple datasets with multiple ddargs, "
+                                 "e.g., multiple polynomials for multiple bins")
+            new = []
+            for c in cols:
+                for r in rows:
+                    step = AggStep(calc, freq, r)
+                    n = ColumnProg(c.key, c.inner, c.tf, c.outer)
+                    if n.inner is None and n.tf is None:
+                        n.inner = step
+                    elif n.outer is None and n.inner is not None:
+                        n.outer = step
+                        if calc not in FUSED_OUTER:
+                            fusable = False
+                    else:
+                        fusable = False
+                    new.append(n)
+            if multi:
+                raw = np.atleast_2d(np.asarray(ddargs, dtype=object))
+                for n, x in zip(new, raw):
+                    n.key = f"{key}_{x[0]}_{x[1]}"                         # aggregate.py:299
+            cols = new
+        elif kind == "transform":
+            new = []
+            for c in cols:
+                if "exp" in params:
+                    exp = params["exp"]
+                    if not isinstance(exp, list):
+                        exp = [exp]
+                    items = [(f"{c.key}_{e}", ("pow", float(e))) for e in exp[0]]   # aggregate.py:54-63
+                elif "inter" in params:
+                    items = [(c.key, ("inter", params["inter"]))]
+                elif "spline" in params.get("transform", ""):
+                    items = [(f"{c.key}_spline1", None), (f"{c.key}_spline2", ("hinge", 20.0))]
+                else:
+                    raise ValueError("No valid transform argument provided.")
+                for k2, tf in items:
+                    n = ColumnProg(k2, c.inner, c.tf, c.outer)
+                    if tf is not None:
+                        if tf[0] == "inter" or n.inner is None or n.outer is not None or n.tf is not None:
+                            fusable = False
+                        else:
+                            n.tf = tf
+                    new.append(n)
+            cols = new
+        else:
+            raise ValueError(f"unknown step type {kind!r} (expected 'aggregate' or 'transform')")
+    for c in cols:
+        if c.inner is None:
+            fusable = False
+    return cols, fusable
+
+
+# --------------------------------------------------------------------------------------
+# device residency and caches
+# --------------------------------------------------------------------------------------
+def device_cube(dataset: Dataset):
+    """The dataset's (time, lat, lon) cube as an HBM tensor (uploaded if still on the host)."""
+    import torch
+    hip.require_gpu()
+    d = dataset.cube()
+    if not _is_torch(d):
+        if d.dtype not in (np.float32, np.float64):
+            d = d.astype(np.float64)
+        d = torch.from_numpy(d)
+    if not d.is_cuda:
+        d = d.cuda(non_blocking=True)
+    if d.dtype not in (torch.float32, torch.float64):
+        d = d.to(torch.float64)
+    return d.contiguous()
+
+
+def _hash(*arrs) -> str:
+    h = hashlib.sha1()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+_PLAN_CACHE: dict = {}
+_PLAN_CACHE_MAX = 32
+
+
+def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=None) -> hip.FusedPlan:
+    exact = config.exact_order if exact_order is None else exact_order
+    tune = config.tuning if tuning is None else tuning
+    ckey = (T, n_cells, dtype_code, _hash(ib, ob), repr(columns), exact, tune)
+    p = _PLAN_CACHE.get(ckey)
+    if p is None:
+        p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune)
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[ckey] = p
+    return p
+
+
+def weight_triplets(wdf: pd.DataFrame, cell_ids: np.ndarray):
+    """`_weight_triplets` (`aggfly/aggregate/spatial.py:157-178`), vectorised: rows = rank of
+    ``index_right`` among the sorted unique ids, cols = position of ``cell_id`` in the grid's
+    cell order, entries whose cell is absent from the grid dropped."""
+    region_ids = np.sort(wdf["index_right"].unique())
+    rows = np.searchsorted(region_ids, wdf["index_right"].to_numpy())
+    cell_ids = np.asarray(cell_ids)
+    cid = wdf["cell_id"].to_numpy()
+    if np.array_equal(cell_ids, np.arange(len(cell_ids))):
+        keep = (cid >= 0) & (cid < len(cell_ids))
+        cols = cid
+    else:
+        order = np.argsort(cell_ids, kind="stable")
+        pos = np.searchsorted(cell_ids[order], cid)
+        pos = np.clip(pos, 0, len(cell_ids) - 1)
+        keep = cell_ids[order][pos] == cid
+        cols = order[pos]
+    w = wdf["weight"].to_numpy(dtype=float)
+    return rows[keep].astype(np.int64), np.asarray(cols)[keep].astype(np.int64), w[keep], region_ids
+
+
+_CSR_CACHE: dict = {}
+
+
+def get_csr(weights, dataset: Dataset):
+    """CSR for ``weights`` laid over ``dataset``'s grid, cached per (table, grid).
+
+    The weights' ``cell_id`` lives on the +-180-sorted grid.  A 0-360 dataset is NOT
+    re-sorted in memory (the reference does, `spatial.py:60`): the longitude permutation is
+    folded into the CSR column indices instead, so the cube is streamed as stored.
+    """
+    wdf = weights.weights
+    if wdf is None:
+        raise ValueError("weights have no table; call calculate_weights() / pass table=")
+    ny, nx = len(dataset.latitude), len(dataset.longitude)
+    order, _ = dataset.lon_order_to_180()
+    # keyed on the table object's identity; a finalizer evicts the entry when the table dies,
+    # so a recycled id() can never serve a stale CSR
+    ckey = (id(wdf), len(wdf), ny, nx, _hash(order, np.asarray(weights.grid.cell_id)))
+    hit = _CSR_CACHE.get(ckey)
+    if hit is not None:
+        return hit
+    try:
+        weakref.finalize(wdf, _CSR_CACHE.pop, ckey, None)
+    except TypeError:
+        ckey = None      # not weak-referenceable: do not cache
+    cell_ids = np.asarray(weights.grid.cell_id)
+    if len(cell_ids) != ny * nx:
+        raise ValueError(f"weights grid has {len(cell_ids)} cells but the dataset grid has {ny}x{nx}; "
+                         "clip the dataset to the same regions as the weights")
+    rows, cols, w, region_ids = weight_triplets(wdf, cell_ids)
+    iy, ixs = np.divmod(cols, nx)
+    cols_mem = iy * nx + order[ixs]            # sorted-grid position -> position in the stored cube
+    csr = hip.CSR(rows, cols_mem, w, len(region_ids), ny * nx)
+    if ckey is not None:
+        if len(_CSR_CACHE) >= 8:
+            _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
+        _CSR_CACHE[ckey] = (csr, region_ids)
+    return csr, region_ids
+
+
+# --------------------------------------------------------------------------------------
+# fused execution
+# --------------------------------------------------------------------------------------
+def _column_dict(c: ColumnProg) -> dict:
+    d = {"inner": c.inner.calc}
+    if c.inner.ddargs is not None:
+        d["inner_args"] = c.inner.ddargs
+        if c.inner.calc == "sine_dd" and c.inner.ddargs[2] not in (0.0, 1.0):
+            raise ValueError("Invalid ddargs[2] value")                    # temporal.py:324
+    if c.tf is not None:
+        d["transform"], d["transform_arg"] = c.tf
+    if c.outer is not None:
+        d["outer"] = c.outer.calc
+        if c.outer.ddargs is not None:
+            d["outer_args"] = c.outer.ddargs
+    else:
+        d["outer"] = "identity"
+    return d
+
+
+@dataclass
+class PassResult:
+    keys: list
+    labels: object
+    plan: hip.FusedPlan
+    cells: object = None        # [K, P, C] device tensor when materialised
+    panel: dict = None          # num/den/res when the whole path ran fused
+
+
+def plan_groups(time_index, cols):
+    """Group fusable columns by their (inner freq, outer freq); -> list of
+    (cols, ib, ob, labels)."""
+    groups = {}
+    for c in cols:
+        gk = (c.inner.freq, c.outer.freq if c.outer else None)
+        groups.setdefault(gk, []).append(c)
+    out = []
+    for (f1, f2), cs in groups.items():
+        ib, lab1 = resample_groups(time_index, f1)
+        if f2 is None:
+            ob, labels = np.arange(len(ib), dtype=np.int64), lab1
+        else:
+            ob, labels = resample_groups(lab1, f2)
+        for i in range(0, len(cs), MAX_COLS_PER_PASS):
+            out.append((cs[i:i + MAX_COLS_PER_PASS], ib, ob, labels))
+    return out
+
+
+def run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=None):
+    """Run one fused pass; splits it if the library says the pass is too wide."""
+    T = int(cube.shape[0])
+    n_cells = int(cube[0].numel()) if T else int(np.prod(cube.shape[1:]))
+    code = hip._dtype_code(cube)
+    cdicts = [_column_dict(c) for c in cols]
+    try:
+        plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order)
+    except hip.HipUnsupported:
+        if len(cols) == 1:
+            raise
+        h = len(cols) // 2
+        return run_fused_pass(cube, cols[:h], ib, ob, None, True, exact_order) + \
+            run_fused_pass(cube, cols[h:], ib, ob, None, True, exact_order)
+    if csr is not None:
+        out = plan.run(cube, csr, want_cells=want_cells)
+        return [PassResult([c.key for c in cols], None, plan, out.get("cells"), out)]
+    return [PassResult([c.key for c in cols], None, plan, plan.run_temporal(cube), None)]

@@ -32,6 +32,7 @@ EXPORTS = (
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end",
 )
 
 
@@ -91,6 +92,9 @@ def load():
     lib.afhip_plan_describe.argtypes = [vp, C.c_char_p, i32]
     lib.afhip_plan_run_temporal.argtypes = [vp, vp, vp, vp, vp]
     lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    lib.afhip_plan_profile_begin.argtypes = [vp, i64]
+    lib.afhip_plan_profile_end.argtypes = [vp, C.POINTER(C.c_float), i64]
+    lib.afhip_plan_profile_end.restype = i64
     _lib = lib
     return lib
 
@@ -363,6 +367,20 @@ class FusedPlan:
         if timed:
             out["kernel_ms"] = (float(ms[0]), float(ms[1]))
         return out
+
+    def profile_begin(self, max_launches: int):
+        """Arm HIP-event pairs around the temporal kernel of the next ``max_launches`` runs."""
+        _check(load().afhip_plan_profile_begin(self._h, int(max_launches)))
+        self._prof_cap = int(max_launches)
+
+    def profile_end(self):
+        """-> list of per-launch temporal-kernel durations in ms (waits for the events)."""
+        cap = getattr(self, "_prof_cap", 0)
+        buf = (C.c_float * max(cap, 1))()
+        n = load().afhip_plan_profile_end(self._h, buf, cap)
+        if n < 0:
+            _check(E_HIP)
+        return [float(buf[i]) for i in range(min(n, cap))]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,328 @@
+"""Loaders feeding the hot path: ``dataset_from_path`` and a dependency-free Zarr v2 codec.
+
+The reference opens stores through xarray (`aggfly/dataset/dataset.py:636-740`) and converts
+to time-contiguous Zarr with `dataset_to_zarr` / `zarr_from_path`
+(`aggfly/dataset/zarr_convert.py:50-156`).  Neither xarray nor zarr/netCDF4 is installed here
+or on the GPU box, so this module reads what can be read with numpy + the standard
+library:
+
+* Zarr v2 directory stores: C-order chunks, ``compressor`` null / zlib / gzip (and blosc or
+  zstd when the ``blosc`` / ``zstandard`` module happens to be importable), ``_ARRAY_DIMENSIONS``
+  attributes, CF time decoding (``units`` + ``calendar``; non-standard calendars go to
+  ``cfcalendar``), ``scale_factor`` / ``add_offset`` / ``_FillValue``;
+* ``.npz`` bundles with ``data``, ``time``, ``latitude``, ``longitude``;
+* NetCDF-3 classic files through ``scipy.io.netcdf_file``.
+
+Chunks are decoded on host threads into one time-major host buffer, which
+``Dataset.to_device()`` then uploads in a single copy.
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from typing import Optional
+
+import numpy as np
+import pandas as pd
+
+from .cfcalendar import STANDARD_CALENDARS, CFTimeIndex, decode_cf_time
+from .dataarray import DataArray
+from .dataset import Dataset
+
+_ZARR_MARKERS = ("zarr.json", ".zmetadata", ".zgroup", ".zarray")
+_NON_ZARR_SUFFIXES = (".nc", ".nc4", ".netcdf", ".cdf", ".h5", ".hdf5", ".grib", ".grb", ".grib2", ".tif", ".tiff")
+
+
+def _looks_like_zarr(path, storage_options=None) -> bool:
+    """`dataset.py:589-617`, local paths only."""
+    if not isinstance(path, str):
+        return False
+    lowered = path.lower().rstrip("/")
+    if ".zarr" in lowered:
+        return True
+    if lowered.endswith(_NON_ZARR_SUFFIXES):
+        return False
+    return os.path.isdir(path) and any(os.path.exists(os.path.join(path, m)) for m in _ZARR_MARKERS)
+
+
+# --------------------------------------------------------------------------------------
+# Zarr v2
+# --------------------------------------------------------------------------------------
+def _decompress(buf: bytes, comp) -> bytes:
+    if comp is None:
+        return buf
+    cid = comp.get("id")
+    if cid == "zlib":
+        return zlib.decompress(buf)
+    if cid == "gzip":
+        return gzip.decompress(buf)
+    if cid == "blosc":
+        try:
+            import blosc
+        except ImportError as e:
+            raise ImportError("this Zarr store is blosc-compressed and the 'blosc' module is not installed; "
+                              "re-encode it with zlib or no compressor (dataset_to_zarr does)") from e
+        return blosc.decompress(buf)
+    if cid == "zstd":
+        try:
+            import zstandard
+        except ImportError as e:
+            raise ImportError("this Zarr store is zstd-compressed and 'zstandard' is not installed") from e
+        return zstandard.ZstdDecompressor().decompress(buf)
+    raise ValueError(f"unsupported Zarr compressor {cid!r}")
+
+
+class ZarrArray:
+    """One array of a Zarr v2 directory store."""
+
+    def __init__(self, path: str):
+        self.path = path
+        with open(os.path.join(path, ".zarray")) as f:
+            self.meta = json.load(f)
+        if self.meta.get("zarr_format") != 2:
+            raise ValueError("only Zarr format 2 is supported")
+        if self.meta.get("order", "C") != "C":
+            raise ValueError("only C-order Zarr chunks are supported")
+        if self.meta.get("filters"):
+            raise ValueError("Zarr filters are not supported")
+        self.shape = tuple(self.meta["shape"])
+        self.chunks = tuple(self.meta["chunks"])
+        self.dtype = np.dtype(self.meta["dtype"])
+        self.sep = self.meta.get("dimension_separator", ".")
+        self.attrs = {}
+        ap = os.path.join(path, ".zattrs")
+        if os.path.exists(ap):
+            with open(ap) as f:
+                self.attrs = json.load(f)
+
+    @property
+    def dims(self):
+        return tuple(self.attrs.get("_ARRAY_DIMENSIONS", [f"dim_{i}" for i in range(len(self.shape))]))
+
+    def _chunk(self, idx):
+        fn = os.path.join(self.path, self.sep.join(str(i) for i in idx) if idx else "0")
+        if not os.path.exists(fn):
+            fill = self.meta.get("fill_value")
+            fv = np.nan if fill in (None, "NaN") and self.dtype.kind == "f" else (0 if fill is None else fill)
+            return np.full(self.chunks, fv, dtype=self.dtype)
+        with open(fn, "rb") as f:
+            raw = _decompress(f.read(), self.meta.get("compressor"))
+        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+
+    def read(self, out: Optional[np.ndarray] = None, threads: int = 8) -> np.ndarray:
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        if not self.shape:
+            out[...] = self._chunk(())
+            return out
+        grid = [range((s + c - 1) // c) for s, c in zip(self.shape, self.chunks)]
+        idxs = list(np.ndindex(*[len(g) for g in grid]))
+
+        def work(idx):
+            blk = self._chunk(idx)
+            sl_out, sl_blk = [], []
+            for i, c, s in zip(idx, self.chunks, self.shape):
+                lo, hi = i * c, min((i + 1) * c, s)
+                sl_out.append(slice(lo, hi))
+                sl_blk.append(slice(0, hi - lo))
+            out[tuple(sl_out)] = blk[tuple(sl_blk)]
+
+        if threads > 1 and len(idxs) > 1:
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                list(ex.map(work, idxs))
+        else:
+            for i in idxs:
+                work(i)
+        return out
+
+
+def _decode_time(values, attrs):
+    units, cal = attrs.get("units"), attrs.get("calendar", "standard")
+    if units is None:
+        return pd.DatetimeIndex(values)
+    if cal in STANDARD_CALENDARS:
+        unit, _, epoch = units.partition(" since ")
+        unit = unit.strip().lower().rstrip("s")
+        factor = {"second": 1e9, "minute": 60e9, "hour": 3600e9, "day": 86400e9}[unit]
+        base = pd.Timestamp(epoch.strip())
+        return pd.DatetimeIndex(base.value + np.round(np.asarray(values, dtype=np.float64) * factor).astype(np.int64))
+    return decode_cf_time(values, units, cal)
+
+
+def _cf_mask_scale(arr, attrs):
+    fv = attrs.get("_FillValue", attrs.get("missing_value"))
+    sf, ao = attrs.get("scale_factor"), attrs.get("add_offset")
+    if fv is None and sf is None and ao is None:
+        return arr
+    out = arr.astype(np.float64 if arr.dtype.itemsize > 2 and arr.dtype.kind != "f" else (arr.dtype if arr.dtype.kind == "f" else np.float32))
+    if fv is not None and not (isinstance(fv, float) and np.isnan(fv)):
+        out[arr == fv] = np.nan
+    if sf is not None:
+        out *= sf
+    if ao is not None:
+        out += ao
+    return out
+
+
+def open_zarr(path: str, var: str, threads: int = 8) -> DataArray:
+    arr = ZarrArray(os.path.join(path, var))
+    dims = arr.dims
+    data = _cf_mask_scale(arr.read(threads=threads), arr.attrs)
+    coords = {}
+    for d in dims:
+        cp = os.path.join(path, d)
+        if os.path.exists(os.path.join(cp, ".zarray")):
+            c = ZarrArray(cp)
+            v = c.read(threads=1)
+            coords[d] = _decode_time(v, c.attrs) if ("units" in c.attrs and " since " in str(c.attrs["units"])) else v
+    return DataArray(data, dims, coords, name=var, attrs=arr.attrs)
+
+
+def _write_array(path, name, data, dims, chunks, attrs, compressor):
+    d = os.path.join(path, name)
+    os.makedirs(d, exist_ok=True)
+    data = np.ascontiguousarray(data)
+    chunks = tuple(int(min(c, s)) if s else 1 for c, s in zip(chunks, data.shape))
+    meta = {"zarr_format": 2, "shape": list(data.shape), "chunks": list(chunks), "dtype": data.dtype.str,
+            "compressor": compressor, "fill_value": "NaN" if data.dtype.kind == "f" else 0, "order": "C", "filters": None}
+    with open(os.path.join(d, ".zarray"), "w") as f:
+        json.dump(meta, f)
+    with open(os.path.join(d, ".zattrs"), "w") as f:
+        json.dump(dict(attrs, _ARRAY_DIMENSIONS=list(dims)), f)
+    grid = [range((s + c - 1) // c) for s, c in zip(data.shape, chunks)]
+    for idx in np.ndindex(*[len(g) for g in grid]):
+        blk = np.full(chunks, np.nan if data.dtype.kind == "f" else 0, dtype=data.dtype)
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, data.shape))
+        part = data[sl]
+        blk[tuple(slice(0, n) for n in part.shape)] = part
+        raw = blk.tobytes()
+        if compressor and compressor["id"] == "zlib":
+            raw = zlib.compress(raw, compressor.get("level", 1))
+        with open(os.path.join(d, ".".join(str(i) for i in idx)), "wb") as f:
+            f.write(raw)
+
+
+def _encode_time(t):
+    if isinstance(t, CFTimeIndex):
+        return (t.seconds / 3600.0), {"units": "hours since 0000-01-01 00:00:00", "calendar": t.calendar}
+    t = pd.DatetimeIndex(t)
+    hours = (t.values.astype("datetime64[s]").astype(np.int64) - np.datetime64("1900-01-01", "s").astype(np.int64)) / 3600.0
+    return hours, {"units": "hours since 1900-01-01 00:00:00", "calendar": "proleptic_gregorian"}
+
+
+def _auto_chunks(sizes: dict, itemsize: int, target_mb: float = 256) -> dict:
+    """Chunk policy of `_auto_chunks` (`zarr_convert.py:31-47`): keep time in one chunk when a
+    square spatial tile of >= 32 cells fits the byte budget (tile capped at 256 and at the
+    grid extent); otherwise split time next to a 128-cell tile."""
+    ny, nx, nt = int(sizes["latitude"]), int(sizes["longitude"]), max(int(sizes["time"]), 1)
+    budget = max(1, int(target_mb * 1024 * 1024 / itemsize))
+    side = int((budget / nt) ** 0.5)
+    if side >= 32:
+        side = int(min(side, 256, ny, nx))
+        return {"time": -1, "latitude": side, "longitude": side}
+    side = int(min(128, ny, nx))
+    return {"time": int(min(max(1, budget // (side * side)), nt)), "latitude": side, "longitude": side}
+
+
+def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress: bool = True, mode: str = "w"):
+    """`dataset_to_zarr` (`zarr_convert.py:50-121`): write a time-major, time-contiguous store."""
+    cube = dataset.cube()
+    if not isinstance(cube, np.ndarray):
+        cube = cube.cpu().numpy()
+    sizes = {"time": cube.shape[0], "latitude": cube.shape[1], "longitude": cube.shape[2]}
+    ch = dict(_auto_chunks(sizes, cube.dtype.itemsize)) if chunks is None else dict(chunks)
+    ctuple = tuple(sizes[d] if ch.get(d, -1) in (-1, None) else ch[d] for d in ("time", "latitude", "longitude"))
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, ".zgroup"), "w") as f:
+        json.dump({"zarr_format": 2}, f)
+    comp = {"id": "zlib", "level": 1} if compress else None
+    _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp)
+    tv, tattrs = _encode_time(dataset.time)
+    _write_array(path, "time", np.asarray(tv, dtype=np.float64), ("time",), (len(tv),), tattrs, None)
+    _write_array(path, "latitude", dataset.latitude, ("latitude",), (len(dataset.latitude),), {}, None)
+    _write_array(path, "longitude", dataset.longitude, ("longitude",), (len(dataset.longitude),), {}, None)
+    return path
+
+
+def zarr_from_path(src: str, dst: str, var: str, **kwargs):
+    """`zarr_from_path` (`zarr_convert.py:124-156`): convert any readable source to Zarr."""
+    ds_kw = {k: kwargs.pop(k) for k in ("xycoords", "timecoord", "lon_is_360", "time_sel") if k in kwargs}
+    ds = dataset_from_path(src, var, **ds_kw)
+    return dataset_to_zarr(ds, dst, var=var, **kwargs)
+
+
+# --------------------------------------------------------------------------------------
+# other containers
+# --------------------------------------------------------------------------------------
+def _open_npz(path, var):
+    z = np.load(path, allow_pickle=False)
+    data = z[var] if var in z.files else z["data"]
+    dims = ("time", "latitude", "longitude")
+    t = z["time"]
+    time = pd.DatetimeIndex(t) if t.dtype.kind == "M" else decode_cf_time(t, str(z["time_units"]), str(z["calendar"]))
+    return DataArray(data, dims, {"time": time, "latitude": z["latitude"], "longitude": z["longitude"]}, name=var)
+
+
+def _open_netcdf3(path, var):
+    from scipy.io import netcdf_file
+    with netcdf_file(path, "r", mmap=False) as nc:
+        v = nc.variables[var]
+        dims = tuple(v.dimensions)
+        attrs = {k: (val.decode() if isinstance(val, bytes) else val) for k, val in v._attributes.items()}
+        data = _cf_mask_scale(np.array(v.data), attrs)
+        coords = {}
+        for d in dims:
+            if d in nc.variables:
+                cv = nc.variables[d]
+                cattrs = {k: (val.decode() if isinstance(val, bytes) else val) for k, val in cv._attributes.items()}
+                vals = np.array(cv.data)
+                coords[d] = _decode_time(vals, cattrs) if " since " in str(cattrs.get("units", "")) else vals
+    return DataArray(data, dims, coords, name=var, attrs=attrs)
+
+
+def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="time", time_sel=None,
+                      georegions=None, lon_is_360=True, time_fix=False, preprocess=None, name=None,
+                      chunks=None, preprocess_at_load=False, parallel=True, **kwargs) -> Dataset:
+    """`dataset_from_path` (`dataset.py:636-740`), same signature.  ``chunks`` / ``parallel``
+    are accepted and ignored (there is no dask graph); a list / glob of paths is concatenated
+    along time like ``open_mfdataset``."""
+    import glob
+    if isinstance(path, str) and "://" in path:
+        raise ImportError(f"remote stores ({path.split('://')[0]}://) need fsspec backends that are not available here")
+    paths = sorted(glob.glob(path)) if isinstance(path, str) and "*" in path else (list(path) if isinstance(path, (list, tuple)) else [path])
+    if not paths:
+        raise FileNotFoundError(path)
+    engine = kwargs.pop("engine", None)
+    parts = []
+    for p in paths:
+        if engine == "zarr" or (engine is None and _looks_like_zarr(p)):
+            da = open_zarr(p, var)
+        elif p.endswith(".npz"):
+            da = _open_npz(p, var)
+        else:
+            da = _open_netcdf3(p, var)
+        if preprocess is not None and (preprocess_at_load or len(paths) > 1):
+            da = preprocess(da)
+        parts.append(da)
+    if len(parts) > 1:
+        tdim = timecoord
+        ax = parts[0].dims.index(tdim)
+        data = np.concatenate([p_.values for p_ in parts], axis=ax)
+        t0 = parts[0].coords[tdim]
+        if isinstance(t0, CFTimeIndex):
+            time = CFTimeIndex(np.concatenate([p_.coords[tdim].seconds for p_ in parts]), t0.calendar)
+        else:
+            time = pd.DatetimeIndex(np.concatenate([np.asarray(p_.coords[tdim]) for p_ in parts]))
+        coords = dict(parts[0].coords)
+        coords[tdim] = time
+        da = DataArray(data, parts[0].dims, coords, name=var)
+        preprocess = None
+    else:
+        da = parts[0]
+        if preprocess_at_load:
+            preprocess = None
+    return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
+                   preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)

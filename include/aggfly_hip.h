@@ -184,6 +184,14 @@ int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhip_csr* csr,
                    double* num_dev, double* den_dev, double* res_dev, double* cells_dev,
                    void* workspace_dev, void* stream, float* kernel_ms);
 
+/* Per-launch device timing of the dominant (temporal) kernel without host syncs in the
+ * timed region: _begin arms up to max_launches HIP event pairs; every afhip_plan_run then
+ * records one pair around the temporal kernel on its stream; _end waits for the recorded
+ * events, writes one duration (ms) per launch into ms_out[0..cap) and returns how many
+ * launches were recorded (-1 on error).  Used by bench.py for roofline.achieved. */
+int afhip_plan_profile_begin(afhip_plan* plan, int64_t max_launches);
+int64_t afhip_plan_profile_end(afhip_plan* plan, float* ms_out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,10 @@ class OracleCFIndex:
     def __len__(self):
         return len(self.year)
 
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
     def __getitem__(self, i):
         if isinstance(i, (int, np.integer)):
             return OracleCFTime(int(self.year[i]), int(self.month[i]), int(self.day[i]), int(self.hour[i]), self.calendar)
@@ -124,17 +128,17 @@ def cf_resample_groups(index: OracleCFIndex, freq: str):
     counts = np.bincount(ordinal - first, minlength=nbins)
     bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 
-    labels = []
+    ys, ms, ds = [], [], []
     cum = np.concatenate([[0], np.cumsum(ml)])
     for b in range(nbins):
         o = first + b
         if freq == "1D":
             y, doy = divmod(o, int(cum[-1]))
             m = int(np.searchsorted(cum, doy, side="right"))
-            labels.append(OracleCFTime(y, m, doy - int(cum[m - 1]) + 1, 0, index.calendar))
+            ys.append(y); ms.append(m); ds.append(doy - int(cum[m - 1]) + 1)
         elif freq == "ME":
             y, m0 = divmod(o, 12)
-            labels.append(OracleCFTime(y, m0 + 1, ml[m0], 0, index.calendar))
+            ys.append(y); ms.append(m0 + 1); ds.append(ml[m0])
         else:
-            labels.append(OracleCFTime(o, 12, ml[11], 0, index.calendar))
-    return bounds, labels
+            ys.append(o); ms.append(12); ds.append(ml[11])
+    return bounds, OracleCFIndex(ys, ms, ds, np.zeros(nbins, dtype=np.int64), index.calendar)

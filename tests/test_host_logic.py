@@ -1,0 +1,191 @@
+"""Host logic that needs no GPU: spec lowering, group bounds, calendars, CSR triplets,
+the Zarr codec, the C-ABI surface.  CPU only."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_inputs as gi  # noqa: E402
+
+import aggfly_amd as af
+from aggfly_amd import cfcalendar as cfc, engine as eng, hip, timegroups as tg
+from oracle import ref_temporal as rt
+from oracle.ref_calendar import cf_daily_index
+from oracle.ref_spatial import weight_triplets as ref_triplets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = hip.load()
+    hdr = open(os.path.join(ROOT, "include", "aggfly_hip.h")).read()
+    declared = set(re.findall(r"\b(afhip_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.afhip_abi_version() == 1
+    assert isinstance(hip.device_count(), int)
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(hip.Column) == 4 * 4 + 8 * 7
+    assert ctypes.sizeof(hip.PlanDesc) == 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4
+
+
+def test_product_fails_loudly_without_gpu():
+    if hip.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(hip.HipEngineError, match="no HIP device"):
+        hip.require_gpu()
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}))
+    with pytest.raises(hip.HipEngineError):
+        af.aggregate_time(ds, tavg=[("aggregate", {"calc": "mean", "groupby": "date"})])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "aggfly_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+def test_lower_spec_key_naming_and_fanout():
+    spec = gi.g1_spec()
+    keys = []
+    for name, steps in spec.items():
+        cols, fusable = eng.lower_spec(name, steps)
+        assert fusable
+        keys += [c.key for c in cols]
+    assert keys == gi.goldens()["G1_temporal_table"]["columns"]
+    cols, fus = eng.lower_spec("x", [("aggregate", {"calc": "mean", "groupby": "date"}),
+                                     ("transform", {"transform": "spline"}),
+                                     ("aggregate", {"calc": "sum", "groupby": "year"})])
+    assert fus and [c.key for c in cols] == ["x_spline1", "x_spline2"] and cols[0].tf is None and cols[1].tf == ("hinge", 20.0)
+    # three aggregate levels / transform on raw data are valid but run staged
+    assert not eng.lower_spec("x", [("aggregate", {"calc": "mean", "groupby": "date"}),
+                                    ("aggregate", {"calc": "mean", "groupby": "month"}),
+                                    ("aggregate", {"calc": "sum", "groupby": "year"})])[1]
+    assert not eng.lower_spec("x", [("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                                    ("aggregate", {"calc": "mean", "groupby": "date"})])[1]
+
+
+def test_lower_spec_errors_match_reference():
+    with pytest.raises(ValueError, match="multiple ddargs"):
+        eng.lower_spec("x", [("aggregate", {"calc": "mean", "groupby": "date"}),
+                             ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                             ("aggregate", {"calc": "bins", "groupby": "month", "ddargs": [[0, 1, 0], [1, 2, 0]]})])
+    with pytest.raises(KeyError):
+        eng.lower_spec("x", [("aggregate", {"calc": "mean", "groupby": "decade"})])
+    with pytest.raises(ValueError, match="No valid transform"):
+        eng.lower_spec("x", [("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "log"})])
+    with pytest.raises(ValueError, match="engine must be"):
+        af.resolve_engine("bogus")
+    assert af.resolve_engine("auto") == "hip" and af.resolve_engine("hip") == "hip"
+
+
+@pytest.mark.parametrize("freq", ["1D", "ME", "YE", "W"])
+def test_resample_groups_datetime_matches_oracle(freq):
+    t = pd.date_range("2000-12-30 06:00", periods=24 * 40, freq="6h")
+    t = t.delete(slice(100, 230))                       # a gap spanning whole days
+    b, lab = tg.resample_groups(t, freq)
+    bo, labo = rt.resample_groups(t, freq)
+    assert b.tolist() == bo.tolist() and lab.equals(labo)
+    with pytest.raises(ValueError, match="monotonic"):
+        tg.resample_groups(t[::-1], freq)
+
+
+@pytest.mark.parametrize("calendar", ["360_day", "noleap", "all_leap"])
+@pytest.mark.parametrize("freq", ["1D", "ME", "YE"])
+def test_cf_calendar_groups_match_independent_oracle(calendar, freq):
+    n = 800
+    ti = af.cf_range("2000-01-01", n, "D", calendar)
+    to = cf_daily_index(calendar, n)
+    keep = np.r_[0:40, 75:400, 401:n]                   # gaps incl. a whole missing month
+    b, lab = tg.resample_groups(ti[keep], freq)
+    bo, labo = rt.resample_groups(to[keep], freq)
+    assert b.tolist() == bo.tolist()
+    assert len(lab) == len(labo)
+    for a, o in zip(lab, labo):
+        assert (a.year, a.month, a.day, a.hour) == (o.year, o.month, o.day, o.hour) and a.calendar == calendar
+
+
+def test_cf_calendar_basics_K2():
+    k = gi.goldens()["K2_bounds"]
+    t360 = af.cf_range("2000-01-01", 720, "D", "360_day")
+    b_m, lab_m = tg.resample_groups(t360, "ME")
+    assert set(np.diff(b_m).tolist()) == {k["360_day_720_ME_group_size"]} and len(lab_m) == k["360_day_720_ME_n_labels"]
+    assert isinstance(lab_m, af.CFTimeIndex) and str(lab_m[1]) == "2000-02-30 00:00:00"
+    assert tg.resample_groups(t360, "YE")[0].tolist() == k["360_day_720_YE_bounds"]
+    assert np.diff(tg.resample_groups(af.cf_range("2000-01-01", 365, "D", "noleap"), "ME")[0])[:3].tolist() == k["noleap_365_ME_first3"]
+    with pytest.raises(NotImplementedError, match="week"):
+        cfc.resample_bins(t360, "W")
+    dec = cfc.decode_cf_time([0, 1, 59], "days since 2000-01-01", "noleap")
+    assert str(dec[2]) == "2000-03-01 00:00:00"
+
+
+def test_weight_triplets_match_reference_semantics():
+    wdf = pd.DataFrame({"cell_id": [3, 0, 7, 99, 2, 2], "index_right": [5, 5, 2, 2, 9, 2], "weight": [.1, .2, .3, .4, .5, .6]})
+    cell_ids = np.arange(8)
+    for cids in (cell_ids, np.array([7, 6, 5, 4, 3, 2, 1, 0])):
+        r, c, w, ids = eng.weight_triplets(wdf, cids)
+        ro, co, wo, idso = ref_triplets(wdf, cids)
+        assert r.tolist() == ro.tolist() and c.tolist() == co.tolist() and w.tolist() == wo.tolist() and ids.tolist() == idso.tolist()
+
+
+def test_dataset_normalisation_and_lon_resort():
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    da = af.DataArray(data=arr, dims=["time", "latitude", "longitude"], coords={"time": time, "latitude": lat, "longitude": lon})
+    ds = af.Dataset(da, lon_is_360=True)
+    assert ds.da.dims == ("latitude", "longitude", "time") and ds.cube().shape == (4, 2, 2)
+    order, lon180 = ds.lon_order_to_180()
+    assert order.tolist() == [1, 0] and lon180.tolist() == [-90.0, 90.0]
+    ds2 = ds.deepcopy(); ds2.rescale_longitude()
+    assert not ds2.lon_is_360 and ds2.longitude.tolist() == [-90.0, 90.0]
+    assert np.array_equal(ds2.cube(), arr[:, :, ::-1])
+    assert ds.lon_is_360 and ds.longitude.tolist() == [90.0, 270.0]           # deepcopy left the original alone
+    assert ds2.grid.cell_id.tolist() == [0, 1, 2, 3]
+    w = af.weights_from_objects(ds, af.GeoRegions(pd.DataFrame({"geoid": ["region_1"]})), table=gi.g2_weights_table())
+    assert w.zero_weight == "nan" and not w.grid.lon_is_360
+    with pytest.raises(ValueError, match="zero_weight must be one of"):
+        af.weights_from_objects(ds, af.GeoRegions(pd.DataFrame({"geoid": ["r"]})), zero_weight="bogus")
+
+
+def test_preprocess_and_unsorted_time():
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    perm = [2, 0, 3, 1]
+    da = af.DataArray(arr[perm] + 273.15, ["time", "latitude", "longitude"], {"time": time[perm], "latitude": lat, "longitude": lon})
+    ds = af.Dataset(da, preprocess=lambda x: x - 273.15)
+    assert np.allclose(ds.cube(), arr) and ds.time.equals(time)
+
+
+def test_zarr_roundtrip_and_auto_chunks(tmp_path):
+    from aggfly_amd.io import _auto_chunks, _looks_like_zarr
+    c = _auto_chunks({"latitude": 721, "longitude": 1440, "time": 8784}, 4, 256)
+    assert c["time"] == -1 and c["latitude"] == c["longitude"] and c["latitude"] >= 32
+    c = _auto_chunks({"latitude": 721, "longitude": 1440, "time": 350640}, 4, 256)
+    assert 0 < c["time"] < 350640 and c["time"] * c["latitude"] * c["longitude"] * 4 <= 256 * 1024 * 1024
+    c = _auto_chunks({"latitude": 2, "longitude": 2, "time": 4}, 8, 256)
+    assert c["latitude"] <= 2 and c["longitude"] <= 2
+    rng = np.random.default_rng(0)
+    for cal in (None, "noleap"):
+        T = 50
+        time = pd.date_range("2001-01-01", periods=T, freq="D") if cal is None else af.cf_range("2001-01-01", T, "D", cal)
+        arr = rng.normal(280, 10, (T, 5, 6)).astype(np.float32)
+        ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"],
+                                     {"time": time, "latitude": np.arange(5.0), "longitude": np.arange(6.0)}), lon_is_360=False)
+        store = str(tmp_path / f"s_{cal}.zarr")
+        af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 16, "latitude": 3, "longitude": 4})
+        assert _looks_like_zarr(store)
+        back = af.dataset_from_path(store, var="t2m", lon_is_360=False, preprocess=lambda x: x - 273.15)
+        assert np.array_equal(back.cube(), arr - np.float32(273.15))
+        if cal is None:
+            assert back.time.equals(time)
+        else:
+            assert back.time == time and back.time.calendar == "noleap"
