@@ -1,0 +1,168 @@
+"""Multi-GPU execution of the hot path: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on the GPUs; "gloo" in the CPU tests).
+
+The reference has no distributed path of its own (dask only, `aggregate_utils.py:62`); what
+shards here is the path itself:
+
+* ``shard="time"`` — the time axis is cut at OUTER-period boundaries, so every (cell, period)
+  window lives on exactly one GPU.  Each rank reduces its own periods to ``res[K, R, P_local]``
+  and one ``all_gather`` assembles the region x period panel.  No halo, no all-to-all.
+* ``shard="cells"`` — for specs with fewer output periods than GPUs (annual output of one
+  year): each rank takes a latitude band; ``num`` and ``den`` are plain sums over cells, so one
+  ``all_reduce(SUM)`` of ``(K+1)·R·P`` doubles finishes the job, then ``res = num / den``.
+
+The exchange helpers (`gather_panel`, `reduce_num_den`) work on any backend and are covered by
+world_size-2 gloo tests; only `aggregate_dataset_sharded` touches the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .cfcalendar import CFTimeIndex
+from .timegroups import resample_groups
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world(group=None):
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def split_even(n: int, rank: int, world_size: int):
+    """Contiguous balanced split of range(n): -> (lo, hi)."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def output_freq(aggregator_dict) -> str:
+    """The output frequency of a spec (the last 'aggregate' step of every name must agree)."""
+    from .engine import _agg_params
+    freqs = set()
+    for name, steps in aggregator_dict.items():
+        last = None
+        for kind, params in steps:
+            if kind == "aggregate":
+                last = _agg_params(params)[1]
+        if last is None:
+            raise ValueError(f"output {name!r} has no aggregate step")
+        freqs.add(last)
+        for kind, params in steps:
+            if kind == "aggregate" and _agg_params(params)[1] == "W":
+                raise ValueError("time sharding needs nested groupings (date/month/year); 'week' does not nest")
+    if len(freqs) != 1:
+        raise ValueError(f"all outputs must share one output frequency to shard the time axis, got {sorted(freqs)}")
+    return freqs.pop()
+
+
+def time_shard_bounds(tindex, freq: str, rank: int, world_size: int):
+    """-> (k_lo, k_hi, p_lo, p_hi, P): this rank's time steps and output periods."""
+    bounds, labels = resample_groups(tindex, freq)
+    P = len(labels)
+    p_lo, p_hi = split_even(P, rank, world_size)
+    return int(bounds[p_lo]), int(bounds[p_hi]), p_lo, p_hi, P
+
+
+def gather_panel(res_local, p_counts, group=None):
+    """all_gather of per-rank ``res[K, R, P_local]`` tensors with different P_local.
+
+    Every rank pads to max(P_local), one all_gather moves the padded blocks (RCCL over xGMI
+    on GPUs), and the blocks are trimmed and concatenated along the period axis.
+    Returns the full ``res[K, R, P]`` on every rank."""
+    import torch
+    dist = _dist()
+    rank, ws = world(group)
+    if ws == 1:
+        return res_local
+    pmax = int(max(p_counts))
+    K, R = res_local.shape[0], res_local.shape[1]
+    pad = torch.full((K, R, pmax), float("nan"), dtype=res_local.dtype, device=res_local.device)
+    pad[:, :, :res_local.shape[2]] = res_local
+    blocks = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(blocks, pad.contiguous(), group=group)
+    return torch.cat([b[:, :, :int(n)] for b, n in zip(blocks, p_counts)], dim=2)
+
+
+def reduce_num_den(num, den, group=None):
+    """Cell-axis sharding: sum the per-rank numerators/denominators, then divide
+    (`aggfly/aggregate/spatial.py:127-133`).  -> (num, den, res) on every rank."""
+    import torch
+    dist = _dist()
+    _, ws = world(group)
+    if ws > 1:
+        buf = torch.cat([num.reshape(-1), den.reshape(-1)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        num = buf[:num.numel()].reshape(num.shape)
+        den = buf[num.numel():].reshape(den.shape)
+    res = torch.where(den.unsqueeze(0) != 0, num / den.unsqueeze(0), torch.full_like(num, float("nan")))
+    return num, den, res
+
+
+def band_csr_triplets(rows, cols, w, ny, nx, y0, y1):
+    """Restrict COO triplets (cols on the stored ny x nx grid) to the latitude band [y0, y1) and
+    re-index the columns onto the band."""
+    iy = cols // nx
+    keep = (iy >= y0) & (iy < y1)
+    return rows[keep], cols[keep] - y0 * nx, w[keep]
+
+
+def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engine="auto", shard="time",
+                              group=None, **kwargs):
+    """`aggregate_dataset` across the GPUs of the process group.  Every rank passes the same
+    dataset description; each reduces its shard; the assembled frame is returned on every rank.
+    """
+    import torch
+    from . import aggregate as agg, engine as eng, hip
+    if dataset is None:
+        raise ValueError("No dataset provided.")
+    if aggregator_dict is None:
+        aggregator_dict = kwargs
+    rank, ws = world(group)
+    tindex = dataset.da.coords["time"]
+    freq = output_freq(aggregator_dict)
+    if shard == "time":
+        k_lo, k_hi, p_lo, p_hi, P = time_shard_bounds(tindex, freq, rank, ws)
+        counts = [split_even(P, r, ws)[1] - split_even(P, r, ws)[0] for r in range(ws)]
+        _, labels = resample_groups(tindex, freq)
+        local = dataset.deepcopy()
+        local.da = dataset.da.isel(time=slice(k_lo, k_hi))
+        order, fused_cols, _ = agg._lower_all(aggregator_dict)
+        names = [k for _, keys, _ in order for k in keys]
+        csr, region_ids = eng.get_csr(weights, dataset)
+        if k_hi > k_lo:
+            res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
+        else:
+            res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
+        full = gather_panel(res, counts, group)
+    elif shard == "cells":
+        ny, nx = len(dataset.latitude), len(dataset.longitude)
+        y0, y1 = split_even(ny, rank, ws)
+        order_, fused_cols, staged = agg._lower_all(aggregator_dict)
+        if staged:
+            raise ValueError("cell sharding supports fused (two-level) specs only")
+        names = [k for _, keys, _ in order_ for k in keys]
+        groups = eng.plan_groups(tindex, fused_cols)
+        if len(groups) != 1:
+            raise ValueError("cell sharding needs all outputs to share their group frequencies")
+        cols, ib, ob, labels = groups[0]
+        wrows, wcols, wv, region_ids = eng.weight_triplets(weights.weights, np.asarray(weights.grid.cell_id))
+        lon_order, _ = dataset.lon_order_to_180()
+        iy, ixs = np.divmod(wcols, nx)
+        wcols_mem = iy * nx + lon_order[ixs]
+        br, bc, bw = band_csr_triplets(wrows, wcols_mem, wv, ny, nx, y0, y1)
+        cube = eng.device_cube(dataset)[:, y0:y1, :].contiguous()
+        csr = hip.CSR(br, bc, bw, len(region_ids), (y1 - y0) * nx)
+        pr = eng.run_fused_pass(cube, cols, ib, ob, csr=csr, want_cells=False)
+        if len(pr) != 1:
+            raise hip.HipUnsupported("cell sharding needs the spec to fit one fused pass")
+        _, _, full = reduce_num_den(pr[0].panel["num"], pr[0].panel["den"], group)
+    else:
+        raise ValueError("shard must be 'time' or 'cells'")
+    df = agg._assemble_frame(full.cpu().numpy(), names, region_ids, labels, weights)
+    return agg._merge_regions(df, weights)

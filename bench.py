@@ -57,14 +57,26 @@ def make_cube(torch, T, ny, nx, dtype, seed):
     return cube
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
     """The reference's numba-engine arithmetic (C port, OpenMP over grid rows like prange) on a
     latitude band of the same workload; every output name re-reads the raw data and every
     intermediate is materialised, exactly as the reference does (aggregate.py:133)."""
     from aggfly_amd import synth
     from oracle import cport
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     cport.build()
     ib = synth.hourly_bounds(T)
     ob = np.array([0, len(ib) - 1], dtype=np.int64)
@@ -96,6 +108,7 @@ def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
         if time.perf_counter() - t0 > target_s or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
+    cores = min(cores, ny_sample)          # OpenMP runs over grid rows, like numba's prange
     return {"value": T * ny_sample * nx / dt, "unit": "grid-cell-timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{ny_sample}x{nx} latitude band of the workload grid, T={T}, fp64, {reps} passes of {dt:.2f} s "
                       f"(C/OpenMP port of the reference's numba engine, oracle/c)"}
@@ -197,7 +210,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(T, max(8, len(os.sched_getaffinity(0))), nx, seed=20260101)
+                line["cpu_baseline"] = cpu_baseline(T, max(8, min(host_cores(), 64)), nx, seed=20260101)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "grid-cell-timesteps/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e}"}

@@ -1,0 +1,111 @@
+"""N > 1 path on CPU: world_size-2 gloo process groups exercise the sharding maths and the
+two exchange steps (panel all_gather for time shards, num/den all_reduce for cell shards).
+The per-shard numbers come from the oracle, so what is checked is exactly that
+"shard -> local reduce -> exchange" equals the unsharded result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from aggfly_amd import distributed as D, synth
+from aggfly_amd.timegroups import resample_groups
+from oracle import cport
+from oracle.ref_spatial import spatial_num_den
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _case():
+    T, ny, nx = 24 * 80, 8, 10
+    cube = synth.temperature_cube(T, ny, nx, seed=31, ocean_frac=0.1, scattered_nan=25)
+    time = pd.date_range("2003-01-10", periods=T, freq="h")
+    tab = synth.weights_table(ny, nx, 6, seed=32, secondary=True)
+    return cube, time, tab, ny, nx
+
+
+def _cells(cube, time):
+    """[K=2, P, cells]: mean@date -> pow(1,2) -> sum@month via the oracle's C port."""
+    ib, lab = resample_groups(time, "1D")
+    ob, labels = resample_groups(lab, "ME")
+    m = cport.resample(cube, ib, "mean")
+    return np.stack([cport.resample(np.power(m, e), ob, "sum").reshape(len(labels), -1) for e in (1, 2)]), labels
+
+
+def _full_res(cube, time, tab, ncells):
+    cells, labels = _cells(cube, time)
+    nums, den, _ = spatial_num_den({f"k{k}": cells[k].T for k in range(2)}, tab, np.arange(ncells))
+    num = np.stack([nums["k0"], nums["k1"]])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(den[None] != 0, num / den[None], np.nan), labels
+
+
+def _worker(rank, ws, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        cube, time, tab, ny, nx = _case()
+        want, labels = _full_res(cube, time, tab, ny * nx)
+        if mode == "time":
+            k_lo, k_hi, p_lo, p_hi, P = D.time_shard_bounds(time, "ME", rank, ws)
+            assert P == len(labels)
+            local, _ = _full_res(cube[k_lo:k_hi], time[k_lo:k_hi], tab, ny * nx)
+            assert local.shape[2] == p_hi - p_lo
+            counts = [D.split_even(P, r, ws)[1] - D.split_even(P, r, ws)[0] for r in range(ws)]
+            full = D.gather_panel(torch.from_numpy(local), counts).numpy()
+            np.testing.assert_array_equal(full, want)             # periods never straddle ranks: bit-identical
+        else:
+            y0, y1 = D.split_even(ny, rank, ws)
+            cells, _ = _cells(cube, time)
+            band = cells.reshape(2, -1, ny, nx)[:, :, y0:y1, :].reshape(2, cells.shape[1], -1)
+            rows, cols, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+            br, bc, bw = D.band_csr_triplets(rows, cols, w, ny, nx, y0, y1)
+            btab = pd.DataFrame({"index_right": br, "cell_id": bc, "weight": bw})
+            R = int(rows.max()) + 1
+            num = np.zeros((2, R, cells.shape[1])); den = np.zeros((R, cells.shape[1]))
+            if len(btab):
+                nums, d, ids = spatial_num_den({f"k{k}": band[k].T for k in range(2)}, btab, np.arange((y1 - y0) * nx))
+                num[:, ids] = np.stack([nums["k0"], nums["k1"]]); den[ids] = d
+            _, _, res = D.reduce_num_den(torch.from_numpy(num), torch.from_numpy(den))
+            np.testing.assert_allclose(res.numpy(), want, rtol=1e-13, equal_nan=True)
+        q.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["time", "cells"])
+def test_world2_exchange(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(out) == [(0, "ok"), (1, "ok")], out
+
+
+def test_shard_maths_single_process():
+    assert [D.split_even(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [D.split_even(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    spec = dict(a=[("aggregate", {"calc": "mean", "groupby": "date"}), ("aggregate", {"calc": "sum", "groupby": "year"})],
+                b=[("aggregate", {"calc": "max", "groupby": "year"})])
+    assert D.output_freq(spec) == "YE"
+    with pytest.raises(ValueError, match="share one output frequency"):
+        D.output_freq(dict(spec, c=[("aggregate", {"calc": "max", "groupby": "month"})]))
+    t = pd.date_range("1999-12-31 12:00", periods=24 * 800, freq="h")
+    spans = [D.time_shard_bounds(t, "YE", r, 3) for r in range(3)]
+    assert spans[0][0] == 0 and spans[-1][1] == len(t) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert D.world() == (0, 1)
