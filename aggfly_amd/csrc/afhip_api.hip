@@ -97,6 +97,7 @@ struct afhip_plan {
     int64_t n_slots = 0;
     const Variant* variant = nullptr;
     int64_t tiles = 0;
+    int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     // device tables
     DevBuf<int64_t> d_ib, d_ob;
     DevBuf<int32_t> d_emit;
@@ -229,8 +230,13 @@ static bool is_stat(int c) { return c >= AFHIP_MEAN && c <= AFHIP_NANMEAN; }
 static int add_thr_slot(std::vector<ThrSlot>& thr, const double* a3, bool bins) {
     ThrSlot s{};
     s.t0 = a3[0]; s.t1 = a3[1];
-    s.base = (a3[2] == 0.0) ? a3[0] : a3[1];            // nb_kernels.py:167
-    s.a = bins ? 0.0 : 1.0; s.b = bins ? 1.0 : 0.0;
+    const bool base_is_t0 = (a3[2] == 0.0);                 // nb_kernels.py:167
+    if (bins) { s.A = 0.0; s.B = 1.0; }
+    else if (base_is_t0) { s.A = 1.0; s.B = -a3[0]; }
+    else { s.A = -1.0; s.B = a3[1]; }
+    // float thresholds equivalent to the double compares for float inputs
+    s.t0f = (float)a3[0]; if ((double)s.t0f > a3[0]) s.t0f = std::nextafterf(s.t0f, -INFINITY);
+    s.t1f = (float)a3[1]; if ((double)s.t1f < a3[1]) s.t1f = std::nextafterf(s.t1f, INFINITY);
     s.nan_poisons = bins ? 0 : 1;
     for (size_t i = 0; i < thr.size(); ++i)
         if (!memcmp(&thr[i], &s, sizeof s)) return (int)i;
@@ -305,9 +311,11 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const auto& ib = pl->ib;
     const auto& ob = pl->ob;
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
-    pl->tiles = (C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec);
+    // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
+    pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count()) ? 64 : WG;
+    pl->tiles = (C + (int64_t)pl->wg * vec - 1) / ((int64_t)pl->wg * vec);
     // aim for ~16 workgroups per CU over the whole grid, never streaming fewer than 64 steps
-    const int64_t want_wgs = (int64_t)cu_count() * 16;
+    const int64_t want_wgs = (int64_t)cu_count() * 16 * (WG / pl->wg);
     const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
     const int64_t target_len = std::max<int64_t>(64, T / want_chunks);
     // splitting a period adds partial traffic (16 B per extra slot, column and cell, write +
@@ -462,10 +470,10 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     char tmp[1024];
     int n = snprintf(tmp, sizeof tmp,
                      "variant=%s pipe=%d vec=%d stat=%d slots=%d kmax=%d depth=%d | T=%lld cells=%lld K=%d G1=%lld P=%lld | "
-                     "tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld | workspace=%.1f MiB",
+                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld | workspace=%.1f MiB",
                      plan->variant->name, plan->variant->pipe, plan->variant->vec, plan->variant->stat, plan->variant->nthr,
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
-                     plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, (long long)plan->tiles, plan->chunks.size(),
+                     plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
                      (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
@@ -482,11 +490,13 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     for (int i = pl->nthr; i < MAX_THR; ++i) {       // padded slots never fire
         fa.thr[i] = ThrSlot{};
         fa.thr[i].t0 = INFINITY; fa.thr[i].t1 = -INFINITY;
+        fa.thr[i].t0f = INFINITY; fa.thr[i].t1f = -INFINITY;
     }
     for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
-    HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3(WG), args, 0, st));
+    const size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
+    HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;
 }
 

@@ -34,10 +34,17 @@ enum : int { SRC_MEAN = 0, SRC_SUM = 1, SRC_MIN = 2, SRC_MAX = 3, SRC_NANMEAN = 
 enum : int { TF_NONE = 0, TF_POWI = 1, TF_POW = 2, TF_HINGE = 3 };
 enum : int { OUT_FIRST = 0, OUT_SUM = 1, OUT_MEAN = 2, OUT_MIN = 3, OUT_MAX = 4, OUT_DD = 5, OUT_BINS = 6 };
 
-// One threshold slot on raw data: contribution = (t0 < v && v < t1) ? a*|v-base| + b : 0.
-// dd: a=1,b=0 (nb_kernels.py:169-177); bins: a=0,b=1 (nb_kernels.py:190-196).
+// One threshold slot on raw data: contribution = (t0 < v && v < t1) ? fma(A, v, B) : 0.
+//   dd, base = t0:  inside the window v - t0 > 0, so |v - base| = fma(+1, v, -t0)
+//   dd, base = t1:  inside the window v - t1 < 0, so |v - base| = fma(-1, v, +t1)
+//   bins:           fma(0, v, 1) = 1
+// One rounding, identical to the reference's av = v - base; if av < 0: av = -av
+// (nb_kernels.py:169-177) and c += 1.0 (nb_kernels.py:190-196).
+// t0f / t1f are t0 rounded down / t1 rounded up to float: for a float v,
+// (double)v > t0  <=>  v > t0f  and  (double)v < t1  <=>  v < t1f, so f32 cubes compare in f32.
 struct ThrSlot {
-    double t0, t1, base, a, b;
+    double t0, t1, A, B;
+    float t0f, t1f;
     int32_t nan_poisons;  // dd: a NaN in the window makes the group NaN; bins: it does not
     int32_t pad;
 };
@@ -166,37 +173,41 @@ template <> struct alignas(16) RawVec<float, 4> { float v[4]; };
 //   FEAT bit 0: single-sine degree days compiled in (needs STAT >= 2)
 //        bit 1: pow() with a non-integer exponent compiled in
 // Both are bulky once inlined per column, so only the variants that need them carry them.
+//
+// The workgroup size is a launch parameter (64 or 256 threads): waves never talk to each
+// other, so small grids are launched as single-wave workgroups for a finer tail.
 template <typename TIn, int PIPE, int VEC, int STAT, int NTHR, int KMAX, int DEPTH, int FEAT>
 __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
     const int64_t C = a.C;
     const int K = a.K;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t c0 = ((int64_t)blockIdx.x * WG + threadIdx.x) * VEC;
+    const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     const bool active = c0 < C;
     const int64_t c_ld = active ? c0 : (C - VEC);   // clamped: inactive lanes re-read valid cells
-    ChunkDesc ch;
+    int64_t k_lo, k_hi;
+    int g_lo, g_hi, slot;
     {
         const int64_t* w = (const int64_t*)&a.chunks[blockIdx.y];
-        ch.k_lo = ld_uniform(w);
-        ch.k_hi = ld_uniform(w + 1);
+        k_lo = ld_uniform(w);
+        k_hi = ld_uniform(w + 1);
         const int64_t g = ld_uniform(w + 2), sb = ld_uniform(w + 3);
-        ch.g_lo = (int32_t)(g & 0xffffffffLL); ch.g_hi = (int32_t)(g >> 32);
-        ch.slot_base = (int32_t)(sb & 0xffffffffLL); ch.pad = 0;
+        g_lo = (int32_t)(g & 0xffffffffLL); g_hi = (int32_t)(g >> 32);
+        slot = (int32_t)(sb & 0xffffffffLL);
     }
-    const TIn* __restrict__ cube = (const TIn*)a.cube;
+    const int rows = (int)(k_hi - k_lo);            // chunk-relative 32-bit loop control: scalar ALU only
+    const TIn* __restrict__ cube = (const TIn*)a.cube + k_lo * C + c_ld;
 
     // ---- per-cell state, all in registers (compile-time indexed) ----
     double s[VEC], mn[VEC], mx[VEC];
     int cnt[VEC];
-    bool hasnan[VEC];
+    unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
     double acc[NTHR > 0 ? NTHR : 1][VEC];
     double os[KMAX][VEC];
 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; hasnan[i] = false;
+        s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
         for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
     }
@@ -217,9 +228,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     auto consume = [&](const RawVec<TIn, VEC>& rv) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const double v = (double)rv.v[i];
-            const bool isn = v != v;
-            hasnan[i] = hasnan[i] | isn;
+            const TIn vr = rv.v[i];
+            const double v = (double)vr;
+            const bool isn = vr != vr;
+            nanmask[i] |= __builtin_amdgcn_ballot_w64(isn);
             if (STAT == 1) {
                 s[i] += v;                          // a NaN poisons s; the group is NaN anyway
             } else if (STAT == 2) {
@@ -234,18 +246,26 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < NTHR; ++j) {
-                const bool m = (v > a.thr[j].t0) && (v < a.thr[j].t1);   // strict, NaN -> false
-                const double w = __fma_rn(a.thr[j].a, fabs(v - a.thr[j].base), a.thr[j].b);
+                bool m;                                                   // strict, NaN -> false
+                if constexpr (sizeof(TIn) == 4) m = (vr > a.thr[j].t0f) && (vr < a.thr[j].t1f);
+                else m = (v > a.thr[j].t0) && (v < a.thr[j].t1);
+                const double w = __fma_rn(a.thr[j].A, v, a.thr[j].B);
                 acc[j][i] += m ? w : 0.0;
             }
         }
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----
-    int slot = ch.slot_base;
-    auto group_end = [&](int g, int64_t nsteps) {
+    auto group_end = [&](int g, int nsteps) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
+        bool hasnan[VEC];
+        double mean[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
+            mean[i] = (STAT >= 1) ? s[i] / dn : 0.0;
+        }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     const bool bad = hasnan[i] || empty;
                     double x = nan64();
                     const int src = co.src;
-                    if (STAT >= 1 && src == SRC_MEAN) x = bad ? nan64() : s[i] / dn;
+                    if (STAT >= 1 && src == SRC_MEAN) x = bad ? nan64() : mean[i];
                     else if (STAT >= 1 && src == SRC_SUM) x = bad ? nan64() : s[i];
                     else if (STAT >= 2 && src == SRC_MIN) x = bad ? nan64() : mn[i];
                     else if (STAT >= 2 && src == SRC_MAX) x = bad ? nan64() : mx[i];
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         x = (empty || (poisons && hasnan[i])) ? nan64() : t;
                     } else if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {   // nb_kernels.py:218-251
                         if (!bad) {
-                            const double tavg = s[i] / dn;
+                            const double tavg = mean[i];
                             if (co.skind == 0)
                                 x = sine_cool(co.s0, mn[i], mx[i], tavg) - sine_cool(co.s1, mn[i], mx[i], tavg);
                             else
@@ -305,7 +325,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; hasnan[i] = false;
+            s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
             for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
         }
@@ -325,16 +345,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     };
 
-    int64_t k = ch.k_lo;
-    int g = ch.g_lo;
+    int kk = 0;                 // row index relative to the chunk
+    int g = g_lo;
 
     if constexpr (PIPE == 0) {
-        while (g < ch.g_hi) {
-            const int64_t gend = ld_uniform(&a.inner_bounds[g + 1]);
-            const int64_t gbeg = k;
-            const TIn* p = cube + k * C + c_ld;
+        const TIn* p = cube;
+        while (g < g_hi) {
+            const int gend = (int)(ld_uniform(&a.inner_bounds[g + 1]) - k_lo);
+            const int gbeg = kk;
             // four rows in flight per lane inside a group
-            for (; k + 4 <= gend; k += 4) {
+            for (; kk + 4 <= gend; kk += 4) {
                 RawVec<TIn, VEC> r0, r1, r2, r3;
                 r0 = *(const RawVec<TIn, VEC>*)(p);
                 r1 = *(const RawVec<TIn, VEC>*)(p + C);
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 p += 4 * C;
                 consume(r0); consume(r1); consume(r2); consume(r3);
             }
-            for (; k < gend; ++k) {
+            for (; kk < gend; ++kk) {
                 RawVec<TIn, VEC> r0 = *(const RawVec<TIn, VEC>*)(p);
                 p += C;
                 consume(r0);
@@ -353,35 +373,37 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     } else {
         // ---- LDS-DMA ring, wave-private ----
-        __shared__ __attribute__((aligned(16))) unsigned char ring[(WG / 64) * DEPTH * 1024];
-        unsigned char* my = ring + wave * (DEPTH * 1024);
-        const uint32_t my_lds = (uint32_t)(uintptr_t)(lds_ptr_t)my;     // LDS byte address
-        const uint32_t rd_off = (uint32_t)lane * 16u;
-        const int64_t k_last = ch.k_hi - 1;
-        const TIn* lane_base = cube + c_ld;
-        auto issue = [&](int64_t row, int sl) {
-            const int64_t r = row < k_last ? row : k_last;               // tail: re-load the last row
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(lane_base + r * C),
-                                             (lds_ptr_t)(my + sl * 1024), 16, 0, 0);
+        extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // waves * DEPTH KiB
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)ring;
+        const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)wave * (DEPTH * 1024u));
+        const uint32_t rd_lane = wave_lds + (uint32_t)lane * 16u;
+        const int last = rows - 1;
+        const int64_t row_bytes = C * (int64_t)sizeof(TIn);
+        const char* lane_base = (const char*)cube;
+        auto issue = [&](int row, int sl) {
+            const int r = row < last ? row : last;                       // tail: re-load the last row
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(lane_base + (int64_t)r * row_bytes),
+                                             (lds_ptr_t)(uintptr_t)(wave_lds + (uint32_t)sl * 1024u), 16, 0, 0);
         };
-        int sl = 0;  // ring slot of row k
-        if (ch.k_hi > ch.k_lo) {
+        int sl = 0;  // ring slot of row kk
+        if (rows > 0) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) issue(ch.k_lo + d, d);
+            for (int d = 0; d < DEPTH; ++d) issue(d, d);
         }
-        while (g < ch.g_hi) {
-            const int64_t gend = ld_uniform(&a.inner_bounds[g + 1]);
-            const int64_t gbeg = k;
-            for (; k < gend; ++k) {
+        while (g < g_hi) {
+            const int gend = (int)(ld_uniform(&a.inner_bounds[g + 1]) - k_lo);
+            const int gbeg = kk;
+            for (; kk < gend; ++kk) {
                 u32x4 raw;
-                // row k has landed once at most DEPTH-1 younger DMAs are outstanding
+                // row kk has landed once at most DEPTH-1 younger DMAs are outstanding
                 asm volatile("s_waitcnt vmcnt(%1)\n\t"
                              "ds_read_b128 %0, %2\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=v"(raw)
-                             : "n"(DEPTH - 1), "v"(my_lds + (uint32_t)sl * 1024u + rd_off)
+                             : "n"(DEPTH - 1), "v"(rd_lane + (uint32_t)sl * 1024u)
                              : "memory");
-                issue(k + DEPTH, sl);            // slot is free again: its row is in registers
+                issue(kk + DEPTH, sl);           // slot is free again: its row is in registers
                 sl = (sl + 1 == DEPTH) ? 0 : sl + 1;
                 RawVec<TIn, VEC> rv;
                 __builtin_memcpy(&rv, &raw, 16);
