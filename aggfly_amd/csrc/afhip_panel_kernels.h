@@ -94,10 +94,16 @@ __global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ ind
     const int64_t r = tid / Q, q = tid - r * Q;
     const int64_t j0 = indptr[r], j1 = indptr[r + 1];
     double accv = 0.0;
-    for (int64_t j = j0; j < j1; ++j) {
-        const double contrib = __dmul_rn(w[j], X[(int64_t)cols[j] * Q + q]);
-        accv = __dadd_rn(accv, contrib);
+    int64_t j = j0;
+    // eight independent gathers in flight, then the adds in table order
+    for (; j + 8 <= j1; j += 8) {
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = __dmul_rn(w[j + u], X[(int64_t)cols[j + u] * Q + q]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) accv = __dadd_rn(accv, p[u]);
     }
+    for (; j < j1; ++j) accv = __dadd_rn(accv, __dmul_rn(w[j], X[(int64_t)cols[j] * Q + q]));
     out[tid] = accv;
 }
 

@@ -290,18 +290,33 @@ class PassResult:
 
 def plan_groups(time_index, cols):
     """Group fusable columns by their (inner freq, outer freq); -> list of
-    (cols, ib, ob, labels)."""
+    (cols, ib, ob, labels).
+
+    When every inner group holds exactly one step (daily data grouped by 'date') and the
+    inner reducer is a plain statistic with no transform, the inner value IS the raw value
+    (v/1 = v, NaN stays NaN), so the column is rewritten to a single level with the outer
+    reducer applied straight to the raw steps: its thresholds then run in the streaming loop
+    instead of the per-group epilogue.  Results are identical by construction."""
+    level1 = {}
+    for c in cols:
+        if c.inner.freq not in level1:
+            level1[c.inner.freq] = resample_groups(time_index, c.inner.freq)
     groups = {}
     for c in cols:
-        gk = (c.inner.freq, c.outer.freq if c.outer else None)
-        groups.setdefault(gk, []).append(c)
+        ib, lab1 = level1[c.inner.freq]
+        f2 = c.outer.freq if c.outer else None
+        unit = f2 is not None and c.tf is None and c.inner.calc in STAT_CALCS and len(ib) > 1 and bool(np.all(np.diff(ib) == 1))
+        groups.setdefault((c.inner.freq, f2, unit), []).append(c)
     out = []
-    for (f1, f2), cs in groups.items():
-        ib, lab1 = resample_groups(time_index, f1)
+    for (f1, f2, unit), cs in groups.items():
+        ib, lab1 = level1[f1]
         if f2 is None:
             ob, labels = np.arange(len(ib), dtype=np.int64), lab1
         else:
             ob, labels = resample_groups(lab1, f2)
+        if unit:
+            cs = [ColumnProg(c.key, AggStep(c.outer.calc, c.outer.freq, c.outer.ddargs), None, None) for c in cs]
+            ib, ob = ob, np.arange(len(ob), dtype=np.int64)
         for i in range(0, len(cs), MAX_COLS_PER_PASS):
             out.append((cs[i:i + MAX_COLS_PER_PASS], ib, ob, labels))
     return out

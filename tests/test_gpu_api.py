@@ -290,3 +290,32 @@ def test_temporal_aggregator_class_and_device_resident_dataset(torch_cuda):
     one = af.TemporalAggregator("mean", "date").execute(ds)
     np.testing.assert_array_equal(one.da.transpose("time", "latitude", "longitude").values,
                                   ra.OTemporalAggregator("mean", "date").execute(ods).values)
+
+
+def test_daily_data_two_level_specs_collapse_to_one_level(torch_cuda):
+    """CMIP6-style daily data (configs[3]): 'mean@date' is the identity there, so the engine
+    runs bins/dd/sum@year straight on the raw steps.  Same numbers as the two-level oracle."""
+    T, ny, nx = 365 * 3, 10, 16
+    cube = synth.temperature_cube(T, ny, nx, seed=41, steps_per_day=1, ocean_frac=0.1, scattered_nan=30)
+    lat, lon = -20 + 2.0 * np.arange(ny), 2.5 * np.arange(nx)
+    edges = np.arange(-20, 50, 5.0)
+    spec = dict(
+        tbin=[("aggregate", {"calc": "mean", "groupby": "date"}),
+              ("aggregate", {"calc": "bins", "groupby": "year", "ddargs": [[a, b, 0] for a, b in zip(edges[:-1], edges[1:])]})],
+        gdd=[("aggregate", {"calc": "mean", "groupby": "date"}), ("aggregate", {"calc": "dd", "groupby": "year", "ddargs": [10, 30, 0]})],
+        tsum=[("aggregate", {"calc": "max", "groupby": "date"}), ("aggregate", {"calc": "mean", "groupby": "year"})],
+        t2=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(2, 3)}),
+            ("aggregate", {"calc": "sum", "groupby": "year"})],
+    )
+    tab = synth.weights_table(ny, nx, 7, seed=42)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    for time, otime in ((pd.date_range("2001-01-01", periods=T, freq="D"),) * 2,
+                        (af.cf_range("2001-01-01", T, "D", "noleap"), cf_daily_index("noleap", T, (2001, 1, 1)))):
+        ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
+        w = af.weights_from_objects(ds, gr, table=tab)
+        got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+        ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
+        want = ra.aggregate_dataset(ow, ra.ODataset(cube, otime, lat, lon, True), engine="numba", **spec)
+        assert list(got.columns) == list(want.columns) and len(got) == len(want) == 3 * len(gr.shp)
+        cols = [c for c in got.columns if c not in ("geoid", "time")]
+        np.testing.assert_allclose(got[cols].values, want[cols].values, rtol=1e-12, atol=0, equal_nan=True)

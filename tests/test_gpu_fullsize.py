@@ -1,0 +1,122 @@
+"""Parity at BASELINE.json's full sizes (configs[1]: one year hourly on the 215 x 1440
+counties extent, fp64, 21.7 GB resident).  The oracle cannot run the whole cube in seconds,
+so the checks are (a) the oracle on a random SAMPLE of cells and regions of the full-size
+run, compared exactly, and (b) size-independent properties: constant fields, affine
+linearity of the mean columns, the bins partition identity, split-vs-unsplit chunking."""
+import numpy as np
+import pytest
+
+from aggfly_amd import hip, synth
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+
+T, NY, NX = 8760, 215, 1440
+C = NY * NX
+
+
+def _cube(torch, seed=1, const=None):
+    import bench
+    if const is not None:
+        return torch.full((T, NY, NX), float(const), dtype=torch.float64, device="cuda")
+    return bench.make_cube(torch, T, NY, NX, torch.float64, seed)
+
+
+@pytest.fixture(scope="module")
+def setup(torch_cuda):
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs ~50 GB of free HBM")
+    cube = _cube(torch)
+    # NaN "ocean" cells and scattered NaNs, applied on the device
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ocean = torch.rand((NY, NX), generator=g, device="cuda") < 0.05
+    cube[:, ocean] = float("nan")
+    idx = torch.randint(0, T * C, (2000,), generator=g, device="cuda")
+    cube.view(-1)[idx] = float("nan")
+    tab = synth.weights_table(NY, NX, 3100, seed=7, secondary=True, zero_frac=0.02)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, C)
+    ib = synth.hourly_bounds(T)
+    ob = np.array([0, len(ib) - 1], dtype=np.int64)
+    return dict(torch=torch, cube=cube, tab=tab, csr=csr, ib=ib, ob=ob, R=R)
+
+
+def _c2_cols():
+    cols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+    return cols + [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
+
+
+def test_full_size_sampled_cells_and_regions_match_oracle(setup):
+    s = setup
+    torch = s["torch"]
+    plan = hip.FusedPlan(T, C, hip.F64, s["ib"], s["ob"], _c2_cols(), exact_order=True)
+    out = plan.run(s["cube"], s["csr"], want_cells=True)
+    cells = out["cells"]                                            # [K, 1, C]
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(C, 96, replace=False))
+    sample = s["cube"].view(T, C)[:, torch.from_numpy(pick).cuda()].cpu().numpy().reshape(T, 1, -1)
+    dd = cport.resample(cport.resample(sample, s["ib"], "dd", [10, 30, 0]), s["ob"], "sum").reshape(-1)
+    got = cells[:, 0, torch.from_numpy(pick).cuda()].cpu().numpy()
+    np.testing.assert_array_equal(got[0], dd)                       # bit-exact (same order, exact_order)
+    m = cport.resample(sample, s["ib"], "mean")
+    for e in (1, 2, 3, 4):
+        want = cport.resample(np.power(m, e), s["ob"], "sum").reshape(-1)
+        np.testing.assert_allclose(got[e], want, rtol=4e-16, atol=0, equal_nan=True)
+    # regions: recompute sampled rows of the panel from the GPU's own cells, in table order
+    cells_h = cells[:, 0, :].cpu().numpy()
+    valid = ~np.isnan(cells_h).any(axis=0)
+    tab = s["tab"]
+    num = out["num"].cpu().numpy(); den = out["den"].cpu().numpy(); res = out["res"].cpu().numpy()
+    for r in rng.choice(s["R"], 40, replace=False):
+        sub = tab[tab["index_right"] == r]
+        c, w = sub["cell_id"].to_numpy(), sub["weight"].to_numpy()
+        d = 0.0
+        for ci, wi in zip(c, w):
+            d += wi * float(valid[ci])
+        assert den[r, 0] == d
+        for k in range(5):
+            n = 0.0
+            for ci, wi in zip(c, w):
+                n += wi * (cells_h[k, ci] if valid[ci] else 0.0)
+            assert num[k, r, 0] == n
+            assert (np.isnan(res[k, r, 0]) and d == 0) or res[k, r, 0] == n / d
+    # default (split) chunking agrees with the unsplit order to rounding
+    out2 = hip.FusedPlan(T, C, hip.F64, s["ib"], s["ob"], _c2_cols()).run(s["cube"], s["csr"])
+    np.testing.assert_allclose(out2["res"].cpu().numpy(), res, rtol=1e-12, equal_nan=True)
+
+
+def test_full_size_constant_field_and_linearity(setup):
+    s = setup
+    torch = s["torch"]
+    cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3)]
+    plan = hip.FusedPlan(T, C, hip.F64, s["ib"], s["ob"], cols)
+    const = _cube(torch, const=17.25)
+    res = plan.run(const, s["csr"])["res"].cpu().numpy()
+    den = plan.run(const, s["csr"])["den"].cpu().numpy()
+    for k, e in enumerate((1, 2, 3)):
+        ok = den[:, 0] != 0
+        np.testing.assert_allclose(res[k, ok, 0], 365 * 17.25 ** e, rtol=1e-13)   # a weighted mean of a constant
+        assert np.isnan(res[k, ~ok, 0]).all()
+    del const
+    # mean -> pow 1 -> sum is affine in the data: f(a x + b) = a f(x) + 365 b on every region
+    base = plan.run(s["cube"], s["csr"])["res"][0].clone()
+    s["cube"].mul_(1.5).add_(4.0)
+    moved = plan.run(s["cube"], s["csr"])["res"][0]
+    s["cube"].sub_(4.0).div_(1.5)
+    np.testing.assert_allclose(moved.cpu().numpy(), 1.5 * base.cpu().numpy() + 365 * 4.0, rtol=1e-11, equal_nan=True)
+
+
+def test_full_size_bins_partition_identity(setup):
+    s = setup
+    edges = [-99.0, 0.0, 10.0, 20.0, 30.0, 99.0]
+    cols = [dict(inner="mean", outer="bins", outer_args=(edges[i], edges[i + 1], 0)) for i in range(5)]
+    out = hip.FusedPlan(T, C, hip.F64, s["ib"], s["ob"], cols).run(s["cube"], s["csr"], want_cells=True)
+    cells = out["cells"][:, 0, :]
+    total = cells.sum(dim=0).cpu().numpy()
+    # every cell's daily means fall in exactly one bin, except NaN days, which fall in none
+    assert set(np.unique(total)).issubset(set(range(366)))
+    assert (total == 365).mean() > 0.9
+    res = out["res"].sum(dim=0).cpu().numpy()[:, 0]
+    assert np.nanmax(res) <= 365 + 1e-9
