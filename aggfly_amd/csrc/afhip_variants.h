@@ -24,7 +24,7 @@ struct Variant {
 const Variant* variants_table(int* n);   // generated (variants_table.hip)
 
 // tuning: 0 default | 1 force direct scalar loads | 2 direct vector loads (16 B per lane)
-//         | 4, 8, 16, 32 LDS ring of that depth
+//         | 4 (default), 8, 16 LDS ring of that depth
 inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning) {
     const Variant* best = nullptr;
     long best_cost = 0;
@@ -40,7 +40,7 @@ inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int 
         else {
             if (v.pipe != pipe) continue;
             if (pipe == 0 && v.vec != 1) continue;
-            if (pipe == 1 && v.depth != 8) continue;
+            if (pipe == 1 && v.depth != 4) continue;
         }
         const long cost = (long)v.nthr * 1000 + (long)v.kmax * 10 + v.stat;
         if (!best || cost < best_cost) { best = &v; best_cost = cost; }

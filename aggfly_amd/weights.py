@@ -119,3 +119,34 @@ def weights_from_feather(path: str, clim: Dataset, georegions: GeoRegions, zero_
     import pyarrow.feather as feather
     table = feather.read_feather(path)
     return weights_from_objects(clim, georegions, table=table, zero_weight=zero_weight)
+
+
+def _read_table(path: str) -> pd.DataFrame:
+    ext = path.rsplit(".", 1)[-1].lower()
+    if ext == "csv":
+        return pd.read_csv(path)
+    if ext in ("parquet", "pq"):
+        return pd.read_parquet(path)
+    if ext in ("feather", "arrow"):
+        import pyarrow.feather as feather
+        return feather.read_feather(path)
+    raise ValueError(f"unsupported table format: {path}")
+
+
+def georegions_from_path(path: str, regionid: str = "geoid", region_list=None, name=None) -> GeoRegions:
+    """`georegions_from_path` (`aggfly/regions/georegions.py:220-244`).  A region TABLE
+    (csv / parquet / feather: the id column, optionally minx, miny, maxx, maxy) is read
+    directly; a shapefile needs geopandas, which stays a CPU-side optional dependency."""
+    if path.lower().endswith((".shp", ".gpkg", ".geojson", ".json")):
+        try:
+            import geopandas as gpd
+        except ImportError as e:
+            raise ImportError(
+                f"reading {path} needs geopandas; export the attribute table (id column + bounds) to "
+                "csv/parquet, which is all the aggregation path uses of the regions") from e
+        shp = gpd.read_file(path)
+    else:
+        shp = _read_table(path)
+    if region_list is not None:
+        shp = shp[shp[regionid].astype(str).isin([str(r) for r in region_list])]
+    return GeoRegions(shp, regionid, name)

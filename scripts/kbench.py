@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--plan", default="c2")
     ap.add_argument("--tunings", default="0,1,2,4,16,32")
+    ap.add_argument("--spd", type=int, default=24, help="steps per inner group (24 hourly, 1 daily, 2 tmin/tmax)")
+    ap.add_argument("--periods", type=int, default=1, help="outer periods (years)")
+    ap.add_argument("--regions", type=int, default=3100)
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     C = a.ny * a.nx
@@ -36,16 +39,23 @@ def main():
     for k0 in range(0, a.T, 512):
         k1 = min(a.T, k0 + 512)
         cube[k0:k1] = (15 + 12 * torch.randn((k1 - k0, a.ny, a.nx), generator=g, device="cuda", dtype=torch.float32)).to(dt)
-    ib = synth.hourly_bounds(a.T)
-    ob = np.array([0, len(ib) - 1], dtype=np.int64)
-    if a.plan == "c2":
+    ib = synth.hourly_bounds(a.T, a.spd)
+    G1 = len(ib) - 1
+    ob = np.round(np.linspace(0, G1, a.periods + 1)).astype(np.int64)
+    if a.plan == "c4":      # 13 temperature bins per year straight on daily data (single level)
+        edges = np.arange(-20, 50, 5.0)
+        cols = [dict(inner="bins", inner_args=(edges[i], edges[i + 1], 0)) for i in range(13)]
+        ib, ob = ib[ob], np.arange(a.periods + 1, dtype=np.int64)
+    elif a.plan == "c5":    # sine-interpolated degree days from (tmin, tmax) pairs, annual sum
+        cols = [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum")]
+    elif a.plan == "c2":
         cols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
         cols += [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
     elif a.plan == "c1":
         cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)]
     else:
-        raise SystemExit("plan must be c1 or c2")
-    wdf = synth.weights_table(a.ny, a.nx, 3100, seed=7)
+        raise SystemExit("plan must be c1, c2, c4 or c5")
+    wdf = synth.weights_table(a.ny, a.nx, a.regions, seed=7)
     R = int(wdf["index_right"].max()) + 1
     csr = hip.CSR(wdf["index_right"].to_numpy(), wdf["cell_id"].to_numpy(), wdf["weight"].to_numpy(), R, C)
     code = hip.F64 if a.dtype == "f64" else hip.F32

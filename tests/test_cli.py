@@ -1,0 +1,214 @@
+"""CLI layer: config parsing/validation and the safe preprocess evaluator (CPU), the
+CLI == hand-written-API parity of `aggfly/tests/test_cli.py:426-458` (GPU), and the
+world_size-2 gloo gather of per-year panels."""
+import os
+import socket
+
+import numpy as np
+import pandas as pd
+import pytest
+import yaml
+from click.testing import CliRunner
+
+import aggfly_amd as af
+from aggfly_amd.cli import config as cfg, pipeline, preprocess as ppmod
+from aggfly_amd.cli.main import cli
+
+
+def _minimal(**over):
+    raw = {
+        "regions": {"path": "r.csv", "regionid": "geoid"},
+        "dataset": {"path": "d.zarr", "var": "t2m"},
+        "aggregate": {"variables": {"tavg": [["aggregate", {"calc": "mean", "groupby": "date"}],
+                                              ["transform", {"transform": "power", "exp": [1, 2]}],
+                                              ["aggregate", {"calc": "sum", "groupby": "year"}]]}},
+        "output": {"path": "out.parquet"},
+    }
+    raw.update(over)
+    return raw
+
+
+def test_parse_defaults_and_exp_normalisation():
+    c = cfg.parse_config(_minimal())
+    assert c.engine == "auto" and c.lon_is_360 and c.zero_weight == "nan" and c.output_format == "parquet"
+    ad = c.to_aggregator_dict()
+    exp = ad["tavg"][1][1]["exp"]
+    assert isinstance(exp, np.ndarray) and exp.tolist() == [1, 2]
+    assert cfg.parse_config(_minimal(aggregate={"engine": "hip", "variables": _minimal()["aggregate"]["variables"]})).engine == "hip"
+
+
+def test_years_templating():
+    raw = _minimal(dataset={"path": "era5_{year}.zarr", "var": "t2m"}, years="1990:1992")
+    c = cfg.parse_config(raw)
+    assert c.templated and c.resolved_paths() == ["era5_1990.zarr", "era5_1991.zarr", "era5_1992.zarr"]
+    with pytest.raises(cfg.ConfigError, match="no 'years' were given"):
+        cfg.parse_config(_minimal(dataset={"path": "era5_{year}.zarr", "var": "t2m"}))
+
+
+def test_all_errors_are_collected():
+    raw = {"regions": {}, "dataset": {"path": "x"}, "output": {"path": "o.xyz"},
+           "aggregate": {"engine": "gpu", "variables": {"a": [["aggregate", {"calc": "median", "groupby": "decade"}],
+                                                               ["transform", {"transform": "log"}]],
+                                                        "b": [["aggregate", {"calc": "dd", "groupby": "date"}]],
+                                                        "c": [["aggregate", {"calc": "mean", "groupby": "date"}],
+                                                              ["transform", {"transform": "power", "exp": [1, 2]}],
+                                                              ["aggregate", {"calc": "bins", "groupby": "year", "ddargs": [[0, 1, 0], [1, 2, 0]]}]]}}}
+    with pytest.raises(cfg.ConfigError) as e:
+        cfg.parse_config(raw)
+    msg = str(e.value)
+    for frag in ("regions.path is required", "regions.regionid is required", "dataset.var is required", "aggregate.engine",
+                 "calc 'median'", "groupby 'decade'", "transform step needs", "requires a non-empty 'ddargs'",
+                 "cannot combine a multi-'ddargs'", "output.format"):
+        assert frag in msg, frag
+    assert len(e.value.errors) >= 9
+
+
+def test_preprocess_builtins_and_expressions():
+    assert np.allclose(ppmod.resolve("kelvin_to_celsius")(np.array([273.15, 283.15])), [0.0, 10.0])
+    for expr, inp, want in [("x - 273.15", [273.15, 283.15], [0.0, 10.0]), ("(x - 32) * 5 / 9", [32.0, 212.0], [0.0, 100.0]),
+                            ("x ** 2", [2.0, 3.0], [4.0, 9.0]), ("-x", [1.0, -2.0], [-1.0, 2.0])]:
+        assert np.allclose(ppmod.resolve(expr)(np.array(inp)), want)
+    for bad in ("__import__('os').system('echo hi')", "x.values", "x[0]", "y + 1", "os", "1 + 2"):
+        with pytest.raises(ppmod.PreprocessError):
+            ppmod.resolve(bad)
+    assert ppmod.resolve(None, None) is None
+    with pytest.raises(ppmod.PreprocessError):
+        ppmod.resolve("x - 1", "prep.py:f")
+
+
+def test_preprocess_from_file(tmp_path):
+    mod = tmp_path / "prep.py"
+    mod.write_text("def clean(x):\n    return x - 273.15\n")
+    assert np.allclose(ppmod.resolve(None, f"{mod}:clean")(np.array([273.15, 300.15])), [0.0, 27.0])
+    with pytest.raises(ppmod.PreprocessError):
+        ppmod.resolve(None, f"{mod}:nope")
+
+
+def test_validate_command(tmp_path):
+    good = tmp_path / "good.yaml"
+    good.write_text(yaml.safe_dump(_minimal()))
+    r = CliRunner().invoke(cli, ["validate", str(good)])
+    assert r.exit_code == 0 and "OK" in r.output
+    bad = tmp_path / "bad.yaml"
+    bad.write_text(yaml.safe_dump({"regions": {}}))
+    r = CliRunner().invoke(cli, ["validate", str(bad)])
+    assert r.exit_code == 1
+
+
+def _write_run_inputs(tmp_path, years=(2000,)):
+    """8x8 grid, seed 7, a box region well inside it (test_cli.py:375-404); the weights table is
+    what aggfly's area weights give for that box: whole cells 1, edge cells their overlap."""
+    lon = np.arange(-100.0, -60.0, 5.0)
+    lat = np.arange(20.0, 60.0, 5.0)
+    np.random.seed(7)
+    paths = []
+    for y in years:
+        time = pd.date_range(f"{y}-07-01", periods=4, freq="12h")
+        arr = np.random.normal(20, 15, (len(time), len(lat), len(lon))) + 273.15
+        ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}),
+                        lon_is_360=False)
+        p = str(tmp_path / f"ds_{y}.zarr")
+        af.dataset_to_zarr(ds, p, var="t2m")
+        paths.append(p)
+    box = (-92.0, 28.0, -68.0, 52.0)
+    regions = pd.DataFrame({"geoid": ["r1"], "minx": [box[0]], "miny": [box[1]], "maxx": [box[2]], "maxy": [box[3]]})
+    rpath = str(tmp_path / "regions.csv")
+    regions.to_csv(rpath, index=False)
+    # clipped grid = cells whose centroid lies within half a cell of the box (grid.py:176-217)
+    keep_lon = lon[(lon >= box[0] - 2.5) & (lon <= box[2] + 2.5)]
+    keep_lat = lat[(lat >= box[1] - 2.5) & (lat <= box[3] + 2.5)]
+    rows = []
+    for iy, la in enumerate(keep_lat):
+        for ix, lo in enumerate(keep_lon):
+            ox = max(0.0, min(lo + 2.5, box[2]) - max(lo - 2.5, box[0])) / 5.0
+            oy = max(0.0, min(la + 2.5, box[3]) - max(la - 2.5, box[1])) / 5.0
+            if ox * oy > 0:
+                rows.append((iy * len(keep_lon) + ix, 0, ox * oy * np.cos(np.deg2rad(la))))
+    tab = pd.DataFrame(rows, columns=["cell_id", "index_right", "weight"])
+    wpath = str(tmp_path / "weights.parquet")
+    tab.to_parquet(wpath, index=False)
+    return paths, rpath, wpath
+
+
+def _run_config(dpath, rpath, wpath, out, **extra):
+    c = {"regions": {"path": rpath, "regionid": "geoid"},
+         "dataset": {"path": dpath, "var": "t2m", "lon_is_360": False, "preprocess": "kelvin_to_celsius"},
+         "weights": {"table": wpath},
+         "aggregate": {"engine": "auto", "variables": {"tavg": [["aggregate", {"calc": "mean", "groupby": "date"}],
+                                                                ["transform", {"transform": "power", "exp": [1, 2]}],
+                                                                ["aggregate", {"calc": "sum", "groupby": "month"}]]}},
+         "output": {"path": out}}
+    c.update(extra)
+    return c
+
+
+@pytest.mark.gpu
+def test_run_matches_direct_api(torch_cuda, tmp_path):
+    paths, rpath, wpath = _write_run_inputs(tmp_path, years=(2000, 2001))
+    out = str(tmp_path / "panel.parquet")
+    cpath = tmp_path / "config.yaml"
+    cpath.write_text(yaml.safe_dump(_run_config(str(tmp_path / "ds_{year}.zarr"), rpath, wpath, out, years="2000:2001")))
+    result = CliRunner().invoke(cli, ["run", str(cpath)])
+    assert result.exit_code == 0, result.output
+    actual = pd.read_parquet(out)
+    # the equivalent hand-written af.* script
+    gr = af.weights.georegions_from_path(rpath, "geoid")
+    frames = []
+    for p in paths:
+        ds = af.dataset_from_path(p, var="t2m", lon_is_360=False, georegions=gr, name="t2m", preprocess=lambda x: x - 273.15)
+        w = af.weights_from_objects(ds, gr, table=pd.read_parquet(wpath))
+        w.calculate_weights()
+        frames.append(af.aggregate_dataset(dataset=ds, weights=w,
+                                           tavg=[("aggregate", {"calc": "mean", "groupby": "date"}),
+                                                 ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                                                 ("aggregate", {"calc": "sum", "groupby": "month"})]))
+    expected = pd.concat(frames, ignore_index=True)
+    assert list(actual.columns) == list(expected.columns) and len(actual) == 2
+    assert np.allclose(actual[["tavg_1", "tavg_2"]].values, expected[["tavg_1", "tavg_2"]].values)
+    # clip on/off must not change results when the weights table addresses the unclipped grid... the
+    # table here addresses the CLIPPED grid, so only check the clipped run against the oracle
+    from oracle import ref_aggregate as ra
+    ds = af.dataset_from_path(paths[0], var="t2m", lon_is_360=False, georegions=gr, preprocess=lambda x: x - 273.15)
+    ow = ra.OWeights(pd.read_parquet(wpath), np.arange(len(ds.latitude) * len(ds.longitude)), gr.shp["geoid"], "geoid", "nan")
+    want = ra.aggregate_dataset(ow, ra.ODataset(ds.cube(), ds.time, ds.latitude, ds.longitude, False), engine="numba",
+                                **cfg.parse_config(yaml.safe_load(cpath.read_text())).to_aggregator_dict())
+    np.testing.assert_allclose(actual[["tavg_1", "tavg_2"]].values[:1], want[["tavg_1", "tavg_2"]].values, rtol=1e-12)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gather_worker(rank, ws, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        def frame(i):
+            t = pd.date_range(f"{2000 + i}-01-31", periods=2, freq="ME")
+            return pd.DataFrame({"geoid": ["a", "a", "b"][: 3 - (i % 2)], "time": list(t)[: 2] + list(t)[:1][: 1 - (i % 2)],
+                                 "v1": np.arange(3 - (i % 2)) + 0.5 + i, "v2": [np.nan, 1.0, 2.0][: 3 - (i % 2)]})
+        n = 5
+        mine = {i: frame(i) for i in range(n)[rank::ws]}
+        full = pipeline._gather_frames(mine, n, "geoid")
+        for i in range(n):
+            pd.testing.assert_frame_equal(full[i], frame(i))
+        q.put((rank, "ok"))
+    except Exception as e:
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_year_scheduler_gather_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(out) == [(0, "ok"), (1, "ok")], out
