@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -313,15 +314,20 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
     // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
     pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count()) ? 64 : WG;
+    if (const char* e = getenv("AFHIP_FORCE_WG")) { int w = atoi(e); if (w == 64 || w == 128 || w == 256) pl->wg = w; }   // experiment knob
     pl->tiles = (C + (int64_t)pl->wg * vec - 1) / ((int64_t)pl->wg * vec);
     // aim for ~16 workgroups per CU over the whole grid, never streaming fewer than 64 steps
-    const int64_t want_wgs = (int64_t)cu_count() * 16 * (WG / pl->wg);
+    int per_cu = 8;      // measured: 8 > 16 > 32 workgroups per CU with nt loads (profiles/r01_sweep_chunks.txt)
+    if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
+    const int64_t want_wgs = (int64_t)cu_count() * per_cu * (WG / pl->wg);
     const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
     const int64_t target_len = std::max<int64_t>(64, T / want_chunks);
     // splitting a period adds partial traffic (16 B per extra slot, column and cell, write +
     // read); keep it under ~2 % of the cube: extra_slots*K*16 <= 0.02*T*elem
     const int64_t elem = pl->desc.dtype == AFHIP_F32 ? 4 : 8;
-    int64_t split_budget = std::max<int64_t>(1, (int64_t)(0.02 * (double)T * (double)elem / (16.0 * std::max(1, pl->K))));
+    double split_frac = 0.02;
+    if (const char* e = getenv("AFHIP_SPLIT_FRAC")) split_frac = atof(e);   // experiment knob
+    int64_t split_budget = std::max<int64_t>(1, (int64_t)(split_frac * (double)T * (double)elem / (16.0 * std::max(1, pl->K))));
     const bool any_first = std::any_of(pl->cols.begin(), pl->cols.end(), [](const ColOp& c) { return c.outer == OUT_FIRST; });
     const bool may_split = !pl->desc.exact_order && !any_first;
 
@@ -429,13 +435,26 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->desc.inner_bounds = nullptr; pl->desc.outer_bounds = nullptr; pl->desc.columns = nullptr;
     if ((rc = lower_columns(pl))) { delete pl; return rc; }
 
-    // variant: LDS-DMA ring when rows are 16-byte multiples, else direct scalar loads
-    const int64_t elem = desc->dtype == AFHIP_F32 ? 4 : 8;
-    const bool rows16 = ((desc->n_cells * elem) % 16) == 0 && desc->n_cells * elem >= 16;
-    int want_pipe = rows16 ? 1 : 0;
-    if (desc->tuning == 1) want_pipe = 0;       // force direct scalar loads
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, desc->tuning);
-    if (!v && want_pipe == 1) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0);
+    // variant: the load path that measured fastest for the dtype and grid size
+    // (profiles/r01_sweep_load_arms.txt), subject to row alignment.
+    const int64_t C_ = desc->n_cells;
+    int want_pipe = 0, want_vec = 1;
+    if (desc->dtype == AFHIP_F64) {
+        if (C_ % 2 == 0 && C_ < 131072) { want_pipe = 1; want_vec = 2; }     // small grid: LDS-DMA ring
+    } else {
+        if (C_ % 2 == 0) want_vec = 2;
+    }
+    int tuning = desc->tuning;
+    if (tuning > 0) {
+        const int tvec = ((tuning % 10000) % 1000) / 100;
+        if (tvec <= 0 || C_ % tvec != 0) tuning = 0;          // a vector arm needs rows that are multiples of it
+    }
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec);
+    if (!v && tuning > 0) {
+        delete pl;
+        return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for tuning arm %d", tuning);
+    }
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);

@@ -149,6 +149,27 @@ template <> struct alignas(8) RawVec<double, 1> { double v[1]; };
 template <> struct alignas(16) RawVec<double, 2> { double v[2]; };
 template <> struct alignas(4) RawVec<float, 1> { float v[1]; };
 template <> struct alignas(16) RawVec<float, 4> { float v[4]; };
+template <> struct alignas(8) RawVec<float, 2> { float v[2]; };
+
+// One lane's VEC cells of a row, read once: non-temporal loads keep the stream from
+// displacing the plan tables and partials in L2 / Infinity Cache.
+template <typename TIn, int VEC, int AUX>
+__device__ __forceinline__ RawVec<TIn, VEC> ld_stream(const TIn* p) {
+    RawVec<TIn, VEC> r;
+    if constexpr (AUX != 0) {
+        typedef TIn vec_t __attribute__((ext_vector_type(VEC)));
+        if constexpr (VEC == 1) {
+            r.v[0] = __builtin_nontemporal_load(p);
+        } else {
+            vec_t t = __builtin_nontemporal_load((const vec_t*)p);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) r.v[i] = t[i];
+        }
+    } else {
+        r = *(const RawVec<TIn, VEC>*)p;
+    }
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------
 // k_fused_temporal
@@ -178,6 +199,7 @@ template <> struct alignas(16) RawVec<float, 4> { float v[4]; };
 // other, so small grids are launched as single-wave workgroups for a finer tail.
 template <typename TIn, int PIPE, int VEC, int STAT, int NTHR, int KMAX, int DEPTH, int FEAT>
 __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
+    constexpr int AUX = (FEAT & 4) ? 2 : 0;   // FEAT bit 2: non-temporal (nt) cache policy on the streaming loads
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
     const int64_t C = a.C;
     const int K = a.K;
@@ -353,18 +375,17 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         while (g < g_hi) {
             const int gend = (int)(ld_uniform(&a.inner_bounds[g + 1]) - k_lo);
             const int gbeg = kk;
-            // four rows in flight per lane inside a group
-            for (; kk + 4 <= gend; kk += 4) {
-                RawVec<TIn, VEC> r0, r1, r2, r3;
-                r0 = *(const RawVec<TIn, VEC>*)(p);
-                r1 = *(const RawVec<TIn, VEC>*)(p + C);
-                r2 = *(const RawVec<TIn, VEC>*)(p + 2 * C);
-                r3 = *(const RawVec<TIn, VEC>*)(p + 3 * C);
-                p += 4 * C;
-                consume(r0); consume(r1); consume(r2); consume(r3);
+            // DEPTH rows in flight per lane inside a group
+            for (; kk + DEPTH <= gend; kk += DEPTH) {
+                RawVec<TIn, VEC> r[DEPTH];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
+                p += (int64_t)DEPTH * C;
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) consume(r[d]);
             }
             for (; kk < gend; ++kk) {
-                RawVec<TIn, VEC> r0 = *(const RawVec<TIn, VEC>*)(p);
+                RawVec<TIn, VEC> r0 = ld_stream<TIn, VEC, AUX>(p);
                 p += C;
                 consume(r0);
             }
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         auto issue = [&](int row, int sl) {
             const int r = row < last ? row : last;                       // tail: re-load the last row
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(lane_base + (int64_t)r * row_bytes),
-                                             (lds_ptr_t)(uintptr_t)(wave_lds + (uint32_t)sl * 1024u), 16, 0, 0);
+                                             (lds_ptr_t)(uintptr_t)(wave_lds + (uint32_t)sl * 1024u), 16, 0, AUX);
         };
         int sl = 0;  // ring slot of row kk
         if (rows > 0) {

@@ -17,31 +17,35 @@ struct Variant {
     int nthr;     // threshold slots
     int kmax;     // columns
     int depth;    // LDS ring depth in rows (pipe 1)
+    int nt;       // 1: non-temporal cache policy on the streaming loads
+    int production;   // 1: part of the default menu; 0: tuning arm only
     const void* fn;
     const char* name;
 };
 
 const Variant* variants_table(int* n);   // generated (variants_table.hip)
 
-// tuning: 0 default | 1 force direct scalar loads | 2 direct vector loads (16 B per lane)
-//         | 4 (default), 8, 16 LDS ring of that depth
-inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning) {
+// tuning: 0 = the default choice below; otherwise an explicit arm
+//         pipe*1000 + vec*100 + depth  (+10000: default cache policy instead of nt)
+//         e.g. 1404 LDS ring, 4 cells per lane, depth 4;  108 direct loads, 1 cell per lane, 8 rows in flight
+inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning, int vec = 0) {
     const Variant* best = nullptr;
     long best_cost = 0;
-    const int want_vec16 = (dtype == 0) ? 4 : 2;
-    int g_n_variants = 0;
-    const Variant* g_variants = variants_table(&g_n_variants);
-    for (int i = 0; i < g_n_variants; ++i) {
-        const Variant& v = g_variants[i];
+    int n = 0;
+    const Variant* tab = variants_table(&n);
+    int want_nt = 1, want_pipe = pipe, want_vec = -1, want_depth = -1;
+    if (tuning > 0) {
+        int t = tuning;
+        if (t >= 10000) { want_nt = 0; t -= 10000; }
+        want_pipe = t / 1000; want_vec = (t % 1000) / 100; want_depth = t % 100;
+    }
+    for (int i = 0; i < n; ++i) {
+        const Variant& v = tab[i];
         if (v.dtype != dtype || v.stat < stat || v.nthr < nthr || v.kmax < K) continue;
-        if (tuning == 1) { if (v.pipe != 0 || v.vec != 1) continue; }
-        else if (tuning == 2) { if (v.pipe != 0 || v.vec != want_vec16) continue; }
-        else if (tuning >= 4) { if (v.pipe != 1 || v.depth != tuning) continue; }
-        else {
-            if (v.pipe != pipe) continue;
-            if (pipe == 0 && v.vec != 1) continue;
-            if (pipe == 1 && v.depth != 4) continue;
-        }
+        if (v.pipe != want_pipe || v.nt != want_nt) continue;
+        if (tuning > 0) {
+            if (v.vec != want_vec || v.depth != want_depth) continue;
+        } else if (!v.production || (vec > 0 && v.vec != vec)) continue;
         const long cost = (long)v.nthr * 1000 + (long)v.kmax * 10 + v.stat;
         if (!best || cost < best_cost) { best = &v; best_cost = cost; }
     }

@@ -188,6 +188,12 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        traffic = None
+        try:   # PMC-derived HBM bytes per launch for this workload, collected in a separate rocprofv3 --pmc pass
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get(f"c2_{args.dtype}_T{T}_C{C}", {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         ms_per_step = dt / args.steps * 1e3
         value = world * T * C * args.steps / dt
         k_ms = float(np.mean(kms)) if kms else float("nan")
@@ -204,7 +210,7 @@ def main():
                        "sharding": "time axis, one year per GPU; RCCL all-gather of the panel" if world > 1 else "single GPU",
                        "plan": plan.describe()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_fused_temporal", "kernel_ms_mean": k_ms, "launches": len(kms),
                          "algorithmic_bytes_per_launch": T * C * elem},
         }
