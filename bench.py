@@ -137,10 +137,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)          # rehearsal of N > 1 on a 1-GPU box shares the card
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL needs one GPU per rank; AGGFLY_BENCH_BACKEND=gloo rehearses the N > 1 code path on one card
+        backend = os.environ.get("AGGFLY_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     hip.require_gpu()
 
     T, ny, nx = args.T, args.ny, args.nx
