@@ -442,19 +442,27 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     if (desc->dtype == AFHIP_F64) {
         if (C_ % 2 == 0 && C_ < 131072) { want_pipe = 1; want_vec = 2; }     // small grid: LDS-DMA ring
     } else {
-        if (C_ % 2 == 0) want_vec = 2;
+        // two cells per lane, unless the plan carries many accumulators (register pressure):
+        // one cell per lane measured 1.6x faster on the 13-bin plan (profiles/r01_kbench_c4_f32.json)
+        if (C_ % 2 == 0 && pl->nthr < 4 && pl->K < 8) want_vec = 2;
     }
     int tuning = desc->tuning;
     if (tuning > 0) {
         const int tvec = ((tuning % 10000) % 1000) / 100;
         if (tvec <= 0 || C_ % tvec != 0) tuning = 0;          // a vector arm needs rows that are multiples of it
     }
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec);
+    // specialisations the lowered plan qualifies for
+    bool all_bins = pl->nthr > 0;
+    for (const ThrSlot& t : pl->thr) all_bins = all_bins && t.nan_poisons == 0;
+    bool single_level = desc->P == desc->G1;
+    for (int64_t p = 0; single_level && p <= desc->P; ++p) single_level = pl->ob[(size_t)p] == p;
+    for (const ColOp& c : pl->cols) single_level = single_level && c.outer == OUT_FIRST;
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level);
     if (!v && tuning > 0) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for tuning arm %d", tuning);
     }
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);

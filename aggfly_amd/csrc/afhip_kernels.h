@@ -103,14 +103,22 @@ __device__ __forceinline__ double powi_dd(double x, int e) {
     return e < 0 ? 1.0 / r : r;
 }
 
-// Single-sine degree-day "parts" (nb_kernels.py:224-249).
+// Single-sine degree-day "parts" (nb_kernels.py:224-249), with the reference's nested
+// transcendentals folded by identities that hold on the branch's domain:
+//   cooling: a = acos(z), |z| <= 1:  sin(a) = sqrt(1 - z^2)
+//   heating: at = atan(r / sqrt(1 - r^2)) = asin(r),  cos(at) = sqrt(1 - r^2)
+// (|r| > 1 gives NaN in both forms, as in the reference).  One transcendental per part
+// instead of two; results agree with the reference's form to ~1e-15, inside the 1e-10
+// contract for sine_dd.
 __device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg) {
     const double PI = 3.14159265358979323846;
     if (thr <= tmin) return tavg - thr;
     if (thr < tmax && tmin < thr) {
-        double rng = tmax - tmin;
-        double a = acos((2.0 * thr - tmax - tmin) / rng);
-        return ((tavg - thr) * a + rng * sin(a) / 2.0) / PI;
+        const double rng = tmax - tmin;
+        const double z = (2.0 * thr - tmax - tmin) / rng;
+        const double a = acos(z);
+        const double sa = sqrt((1.0 - z) * (1.0 + z));
+        return ((tavg - thr) * a + rng * sa / 2.0) / PI;
     }
     return 0.0;
 }
@@ -118,10 +126,11 @@ __device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax
     const double PI = 3.14159265358979323846;
     if (thr >= tmax) return thr - tavg;
     if (thr < tmax && tmin < thr) {
-        double alpha = (tmax - tmin) / 2.0;
-        double r = (thr - tavg) / alpha;
-        double at = atan(r / sqrt(1.0 - r * r));
-        return (1.0 / PI) * ((thr - tavg) * (at + PI / 2.0) + alpha * cos(at));
+        const double alpha = (tmax - tmin) / 2.0;
+        const double r = (thr - tavg) / alpha;
+        const double at = asin(r);
+        const double ca = sqrt((1.0 - r) * (1.0 + r));
+        return (1.0 / PI) * ((thr - tavg) * (at + PI / 2.0) + alpha * ca);
     }
     return 0.0;
 }
@@ -200,6 +209,12 @@ __device__ __forceinline__ RawVec<TIn, VEC> ld_stream(const TIn* p) {
 template <typename TIn, int PIPE, int VEC, int STAT, int NTHR, int KMAX, int DEPTH, int FEAT>
 __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     constexpr int AUX = (FEAT & 4) ? 2 : 0;   // FEAT bit 2: non-temporal (nt) cache policy on the streaming loads
+    // FEAT bit 3: every threshold slot is a bin count -> 32-bit integer counters (one
+    //             v_addc per slot and element instead of fma + select + f64 add)
+    // FEAT bit 4: single-level plan (every inner group is an output period, every column
+    //             passes its inner value through): no outer accumulators at all
+    constexpr bool TKI = (FEAT & 8) != 0;
+    constexpr bool SL = (FEAT & 16) != 0;
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
     const int64_t C = a.C;
     const int K = a.K;
@@ -224,16 +239,18 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     double s[VEC], mn[VEC], mx[VEC];
     int cnt[VEC];
     unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
-    double acc[NTHR > 0 ? NTHR : 1][VEC];
-    double os[KMAX][VEC];
+    double acc[(NTHR > 0 && !TKI) ? NTHR : 1][VEC];
+    int cthr[(NTHR > 0 && TKI) ? NTHR : 1][VEC];
+    double os[SL ? 1 : KMAX][VEC];
 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
-        for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
+        for (int j = 0; j < NTHR; ++j) { if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
     }
     auto reset_outer = [&]() {
+        if (SL) return;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
@@ -271,8 +288,12 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 bool m;                                                   // strict, NaN -> false
                 if constexpr (sizeof(TIn) == 4) m = (vr > a.thr[j].t0f) && (vr < a.thr[j].t1f);
                 else m = (v > a.thr[j].t0) && (v < a.thr[j].t1);
-                const double w = __fma_rn(a.thr[j].A, v, a.thr[j].B);
-                acc[j][i] += m ? w : 0.0;
+                if constexpr (TKI) {
+                    cthr[j][i] += m ? 1 : 0;
+                } else {
+                    const double w = __fma_rn(a.thr[j].A, v, a.thr[j].B);
+                    acc[j][i] += m ? w : 0.0;
+                }
             }
         }
     };
@@ -308,7 +329,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         bool poisons = false;
 #pragma unroll
                         for (int q = 0; q < NTHR; ++q)
-                            if (q == co.src_idx) { t = acc[q][i]; poisons = a.thr[q].nan_poisons != 0; }
+                            if (q == co.src_idx) {
+                                t = TKI ? (double)cthr[q][i] : acc[q][i];
+                                poisons = a.thr[q].nan_poisons != 0;
+                            }
                         x = (empty || (poisons && hasnan[i])) ? nan64() : t;
                     } else if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {   // nb_kernels.py:218-251
                         if (!bad) {
@@ -323,6 +347,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if (tf == TF_POWI) x = powi_dd(x, co.tf_iarg);
                     else if (tf == TF_HINGE) x = ((x > co.tf_arg) ? 1.0 : 0.0) * (x - co.tf_arg);
                     else if ((FEAT & 2) && tf == TF_POW) x = pow(x, co.tf_arg);
+                    if constexpr (SL) {
+                        if (active) a.partial[((int64_t)slot * K + j) * C + c0 + i] = x;
+                        continue;
+                    }
                     double o = os[j][i];
                     switch (co.outer) {
                         case OUT_FIRST: o = x; break;
@@ -349,9 +377,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         for (int i = 0; i < VEC; ++i) {
             s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
-            for (int j = 0; j < NTHR; ++j) acc[j][i] = 0.0;
+            for (int j = 0; j < NTHR; ++j) { if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
         }
-        if (ld_uniform(&a.emit[g])) {
+        if constexpr (SL) {
+            ++slot;
+        } else if (ld_uniform(&a.emit[g])) {
             if (active) {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
