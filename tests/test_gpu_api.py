@@ -319,3 +319,44 @@ def test_daily_data_two_level_specs_collapse_to_one_level(torch_cuda):
         assert list(got.columns) == list(want.columns) and len(got) == len(want) == 3 * len(gr.shp)
         cols = [c for c in got.columns if c not in ("geoid", "time")]
         np.testing.assert_allclose(got[cols].values, want[cols].values, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_interact_and_spline_transforms(torch_cuda):
+    """X2: `inter` (element-wise product with a second dataset, dataset.py:483-563) runs staged in
+    HBM; `spline` (hinge at 20, dataset.py:475-481) is fused.  Both against the oracle."""
+    ds, w, ods, ow = _mid_case(np.float64)
+    daily = af.aggregate_time(dataset=ds, weights=None, p=[("aggregate", {"calc": "max", "groupby": "date"})])["p"]
+    odaily = ra.aggregate_time(ods, {"p": [("aggregate", {"calc": "max", "groupby": "date"})]})["p"]
+    spec = lambda other: dict(
+        tx=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "inter", "inter": other}),
+            ("aggregate", {"calc": "sum", "groupby": "month"})],
+        sp=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "spline"}),
+            ("aggregate", {"calc": "sum", "groupby": "month"})])
+    got = af.aggregate_dataset(dataset=ds, weights=w, **spec(daily))
+    want = ra.aggregate_dataset(ow, ods, engine="numba", **spec(odaily))
+    assert list(got.columns) == list(want.columns) == ["geoid", "time", "tx", "sp_spline1", "sp_spline2"]
+    assert len(got) == len(want)
+    np.testing.assert_allclose(got[["tx", "sp_spline1", "sp_spline2"]].values, want[["tx", "sp_spline1", "sp_spline2"]].values,
+                               rtol=1e-12, equal_nan=True)
+
+
+def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
+    """N2: a float Zarr store decoded chunk-parallel into pinned slabs and uploaded while the
+    next slab decodes gives the same cube (and the same panel) as the host path."""
+    T, ny, nx = 24 * 40, 9, 14
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=51, scattered_nan=20) + np.float32(273.15)
+    time = pd.date_range("2002-01-01", periods=T, freq="h")
+    lat, lon = 30 + 0.5 * np.arange(ny), 200 + 0.5 * np.arange(nx)
+    ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
+    store = str(tmp_path / "t.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 100, "latitude": 4, "longitude": 5})
+    host = af.dataset_from_path(store, "t2m", preprocess=lambda x: x - 273.15)
+    dev = af.dataset_from_path(store, "t2m", preprocess=lambda x: x - 273.15, device="cuda")
+    assert dev.cube().is_cuda and dev.time.equals(time)
+    np.testing.assert_array_equal(dev.cube().cpu().numpy(), host.cube())
+    tab = synth.weights_table(ny, nx, 5, seed=52)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    spec = dict(t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("aggregate", {"calc": "sum", "groupby": "month"})])
+    a = af.aggregate_dataset(dataset=dev, weights=af.weights_from_objects(dev, gr, table=tab), **spec)
+    b = af.aggregate_dataset(dataset=host, weights=af.weights_from_objects(host, gr, table=tab), **spec)
+    pd.testing.assert_frame_equal(a, b)
