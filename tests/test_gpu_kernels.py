@@ -197,3 +197,64 @@ def test_fused_plan_bins_of_daily_means_and_single_level(torch_cuda):
     want2 = _oracle_two_level(cube, ib2, None, cols2)
     np.testing.assert_array_equal(got2[1:], want2[1:])
     np.testing.assert_allclose(got2[0], want2[0], rtol=1e-10, atol=1e-10, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_every_load_path_arm_gives_identical_cells(torch_cuda, dtype):
+    """Direct loads (1/2/4 cells per lane, 4/8 rows in flight) and the LDS-DMA ring (depth 4/8/16,
+    nt and default cache policy) are the same arithmetic: cells must match bit for bit."""
+    from aggfly_amd import hip
+    T, ny, nx = 24 * 33 + 11, 12, 44          # rows are 16-byte multiples for both dtypes
+    cube = _cube(T, ny, nx, dtype, seed=13)
+    ib = synth.hourly_bounds(T)
+    ob = np.array([0, 9, 20, len(ib) - 1], dtype=np.int64)
+    cols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+    cols += [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    d = torch_cuda.from_numpy(cube).cuda()
+    ref = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True).run_temporal(d).cpu().numpy()
+    want = _oracle_two_level(cube.astype(np.float64), ib, ob, cols)
+    np.testing.assert_array_equal(ref[:2], want[:2])
+    arms = [104, 108, 204, 208, 1204, 1208, 1216, 11204] if dtype == np.float64 else [104, 108, 204, 208, 404, 408, 1404, 1408, 1416, 11404]
+    seen = set()
+    for arm in arms:
+        plan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True, tuning=arm)
+        seen.add(plan.describe().split()[0])
+        np.testing.assert_array_equal(plan.run_temporal(d).cpu().numpy(), ref, err_msg=f"arm {arm}")
+    assert len(seen) == len(arms), seen          # every arm resolved to its own kernel
+
+
+def test_edge_shapes(torch_cuda):
+    """Ragged and degenerate inputs: odd row length (scalar-load fallback), one time step, groups
+    shorter than the prefetch depth, an all-NaN cube, a weights table with a region whose cells
+    are all absent and one with no entries at all."""
+    from aggfly_amd import hip
+    rng = np.random.default_rng(3)
+    for (T, ny, nx) in [(1, 3, 5), (7, 1, 1), (50, 7, 9)]:
+        cube = rng.normal(15, 10, (T, ny, nx))
+        b = np.array(sorted(set([0, T] + list(range(0, T, 3)))), dtype=np.int64)
+        for dt in (np.float64, np.float32):
+            c = cube.astype(dt)
+            d = torch_cuda.from_numpy(c).cuda()
+            np.testing.assert_array_equal(hip.group_stat(d, b, "mean").cpu().numpy(), cport.block_stat(c, b, "mean"))
+            np.testing.assert_array_equal(hip.group_bins(d, b, [[0, 15, 0], [15, 99, 0]]).cpu().numpy(),
+                                          cport.block_bins(c, b, [[0, 15, 0], [15, 99, 0]]))
+    # all-NaN cube: every statistic NaN, bins zero, panel rows all NaN
+    T, ny, nx = 48, 4, 6
+    nan_cube = np.full((T, ny, nx), np.nan)
+    d = torch_cuda.from_numpy(nan_cube).cuda()
+    ib = synth.hourly_bounds(T)
+    assert np.isnan(hip.group_stat(d, ib, "sum").cpu().numpy()).all()
+    assert (hip.group_bins(d, ib, [0, 15, 0]).cpu().numpy() == 0).all()
+    # CSR with an empty region (row 1 has no entries) and an out-of-grid cell dropped by the host
+    csr = hip.CSR([0, 0, 2], [0, 5, 23], [0.5, 0.5, 1.0], 3, ny * nx)
+    plan = hip.FusedPlan(T, ny * nx, hip.F64, ib, np.array([0, 2]), [dict(inner="mean", outer="sum")])
+    good = torch_cuda.from_numpy(rng.normal(10, 1, (T, ny, nx))).cuda()
+    out = plan.run(good, csr)
+    den = out["den"].cpu().numpy()[:, 0]
+    res = out["res"].cpu().numpy()[0, :, 0]
+    assert den.tolist() == [1.0, 0.0, 1.0] and np.isnan(res[1]) and np.isfinite(res[[0, 2]]).all()
+    with pytest.raises(ValueError):
+        hip.CSR([0], [ny * nx], [1.0], 1, ny * nx)            # column out of range is refused before upload
+    with pytest.raises(ValueError):
+        hip.FusedPlan(T, ny * nx, hip.F64, np.array([0, 30, 20, T]), np.array([0, 3]), [dict(inner="mean")])   # non-monotone bounds
