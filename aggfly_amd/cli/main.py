@@ -118,10 +118,12 @@ def _maybe_init_distributed():
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            use_gpu = torch.cuda.is_available()
-            if use_gpu:
-                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-            dist.init_process_group("nccl" if use_gpu else "gloo")
+            ndev = torch.cuda.device_count()
+            if ndev:
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+            # RCCL needs one GPU per rank; fewer GPUs than ranks (a rehearsal box) falls back to gloo
+            backend = os.environ.get("AGGFLY_DIST_BACKEND", "nccl" if ndev >= int(os.environ["WORLD_SIZE"]) else "gloo")
+            dist.init_process_group(backend)
 
 
 if __name__ == "__main__":

@@ -183,6 +183,7 @@ def _hash(*arrs) -> str:
 
 _PLAN_CACHE: dict = {}
 _PLAN_CACHE_MAX = 32
+_PLAN_CACHE_BYTES = 16 << 30        # plans own their scratch in HBM: bound what the cache pins
 
 
 def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=None) -> hip.FusedPlan:
@@ -192,8 +193,10 @@ def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=N
     p = _PLAN_CACHE.get(ckey)
     if p is None:
         p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune)
-        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
-            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        held = sum(q.workspace_bytes() for q in _PLAN_CACHE.values())
+        while _PLAN_CACHE and (len(_PLAN_CACHE) >= _PLAN_CACHE_MAX or held + p.workspace_bytes() > _PLAN_CACHE_BYTES):
+            old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+            held -= old.workspace_bytes()
         _PLAN_CACHE[ckey] = p
     return p
 

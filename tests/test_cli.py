@@ -212,3 +212,25 @@ def test_year_scheduler_gather_world2():
     for p in procs:
         p.join(30)
     assert sorted(out) == [(0, "ok"), (1, "ok")], out
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_equals_one(torch_cuda, tmp_path):
+    """The year loop as a 2-rank job (ranks share the box's GPU, gloo exchange) writes the same
+    panel as the single-process run."""
+    import subprocess
+    import sys
+    paths, rpath, wpath = _write_run_inputs(tmp_path, years=(2000, 2001, 2002))
+    outs = []
+    for tag, cmd in (("one", [sys.executable, "-m", "aggfly_amd.cli.main"]),
+                     ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "aggfly_amd.cli.main"])):
+        out = str(tmp_path / f"panel_{tag}.csv")
+        cpath = tmp_path / f"config_{tag}.yaml"
+        cpath.write_text(yaml.safe_dump(_run_config(str(tmp_path / "ds_{year}.zarr"), rpath, wpath, out, years="2000:2002")))
+        env = dict(os.environ, AGGFLY_DIST_BACKEND="gloo", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run(cmd + ["run", str(cpath), "--quiet"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(pd.read_csv(out))
+    pd.testing.assert_frame_equal(outs[0], outs[1])
+    assert len(outs[0]) == 3
