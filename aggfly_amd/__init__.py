@@ -26,7 +26,13 @@ from .io import dataset_from_path, dataset_to_zarr, zarr_from_path  # noqa: F401
 from .weights import (  # noqa: F401
     GeoRegions,
     GridWeights,
+    crop_weights_from_path,
+    georegions_from_gdf,
+    georegions_from_path,
     georegions_from_table,
+    pop_weights_from_path,
+    secondary_weights_from_path,
+    shapefile_info,
     weights_from_feather,
     weights_from_objects,
 )

@@ -150,3 +150,28 @@ def georegions_from_path(path: str, regionid: str = "geoid", region_list=None, n
     if region_list is not None:
         shp = shp[shp[regionid].astype(str).isin([str(r) for r in region_list])]
     return GeoRegions(shp, regionid, name)
+
+
+def georegions_from_gdf(gdf, regionid: str = "geoid", region_list=None, name=None) -> GeoRegions:
+    """`georegions_from_gdf` (`aggfly/regions/georegions.py:246-270`): any (Geo)DataFrame with the id column."""
+    if region_list is not None:
+        gdf = gdf[gdf[regionid].astype(str).isin([str(r) for r in region_list])]
+    return GeoRegions(gdf, regionid, name)
+
+
+def _cpu_side_only(name):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(
+            f"{name} belongs to aggfly's CPU-side weights pipeline (geopandas / rasterio), which this engine does not "
+            "reimplement: compute the weights with aggfly once, then hand the cached table to weights_from_objects(table=...) "
+            "or weights_from_feather().")
+    stub.__name__ = name
+    return stub
+
+
+# names of the reference's weights producers (`aggfly/__init__.py:13-22`), present so that
+# `import aggfly_amd as af` scripts fail with a pointer instead of an AttributeError
+pop_weights_from_path = _cpu_side_only("pop_weights_from_path")
+crop_weights_from_path = _cpu_side_only("crop_weights_from_path")
+secondary_weights_from_path = _cpu_side_only("secondary_weights_from_path")
+shapefile_info = _cpu_side_only("shapefile_info")

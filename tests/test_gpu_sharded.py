@@ -1,0 +1,65 @@
+"""aggregate_dataset_sharded on the GPU box: two ranks (sharing the card, gloo exchange) must
+reproduce the single-process panel for both sharding modes."""
+import os
+import socket
+import subprocess
+import sys
+
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import os, sys
+import numpy as np, pandas as pd, torch, torch.distributed as dist
+import aggfly_amd as af
+from aggfly_amd import synth, distributed as D
+
+mode, out = sys.argv[1], sys.argv[2]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    dist.init_process_group("gloo")
+T, ny, nx = 24 * 400, 10, 12
+cube = synth.temperature_cube(T, ny, nx, seed=61, ocean_frac=0.1, scattered_nan=30)
+time = pd.date_range("2003-03-01", periods=T, freq="h")
+ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                             {"time": time, "latitude": 30 + 0.25 * np.arange(ny), "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+tab = synth.weights_table(ny, nx, 6, seed=62, secondary=True)
+gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+w = af.weights_from_objects(ds, gr, table=tab)
+freq = "month" if mode == "time" else "year"
+spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": freq})],
+            t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+               ("aggregate", {"calc": "sum", "groupby": freq})])
+if dist.is_initialized():
+    df = D.aggregate_dataset_sharded(w, ds, spec, shard=mode)
+else:
+    df = af.aggregate_dataset(dataset=ds, weights=w, aggregator_dict=spec)
+if D.world()[0] == 0:
+    df.to_csv(out, index=False)
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("mode", ["time", "cells"])
+def test_sharded_equals_single(torch_cuda, tmp_path, mode):
+    script = tmp_path / "job.py"
+    script.write_text(SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # with exact_order no period is ever split, so a period's sums do not depend on which shard
+    # (or how long a cube) it is computed in: the time-sharded panel is bit-identical
+    env = dict(os.environ, PYTHONPATH=root, AGGFLY_HIP_EXACT_ORDER="1")
+    one, two = str(tmp_path / "one.csv"), str(tmp_path / "two.csv")
+    r = subprocess.run([sys.executable, str(script), mode, one], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script), mode, two], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = pd.read_csv(one), pd.read_csv(two)
+    assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
+    pd.testing.assert_frame_equal(a, b, rtol=1e-12 if mode == "cells" else 0, atol=0, check_exact=(mode == "time"))
