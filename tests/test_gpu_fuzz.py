@@ -1,0 +1,95 @@
+"""Randomised spec fuzz: specs drawn from the DSL grammar (inner reducer x transform x outer
+reducer x groupby pairs, multi-row ddargs, several names per call) on seeded data, the whole
+public path against the oracle.  Catches lowering / variant-selection / chunk-merge bugs that
+hand-written cases miss."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import aggfly_amd as af
+from aggfly_amd import synth
+from oracle import ref_aggregate as ra
+
+pytestmark = pytest.mark.gpu
+
+STATS = ["mean", "sum", "min", "max", "nanmean"]
+PAIRS = [("date", "month"), ("date", "year"), ("month", "year"), ("date", "week"), ("week", "month")]
+
+
+def _dd(rng, multi):
+    def row():
+        lo = float(rng.choice([-5, 0, 5, 10, 12.5, 18]))
+        return [lo, lo + float(rng.choice([5, 10, 20, 90])), int(rng.integers(0, 2))]
+    return [row() for _ in range(int(rng.integers(2, 4)))] if multi else row()
+
+
+def _random_steps(rng):
+    g1, g2 = PAIRS[int(rng.integers(0, len(PAIRS)))]
+    kind = int(rng.integers(0, 8))
+    if kind == 0:      # single level
+        calc = str(rng.choice(STATS + ["dd", "bins", "sine_dd"]))
+        p = {"calc": calc, "groupby": str(rng.choice([g1, g2]))}
+        if calc in ("dd", "bins", "sine_dd"):
+            p["ddargs"] = _dd(rng, rng.random() < 0.4)
+            if calc == "sine_dd":
+                p["ddargs"] = [r[:2] + [r[2] % 2] for r in p["ddargs"]] if isinstance(p["ddargs"][0], list) else p["ddargs"]
+        return [("aggregate", p)]
+    inner = str(rng.choice(STATS + ["dd", "bins", "sine_dd"]))
+    p1 = {"calc": inner, "groupby": g1}
+    multi1 = False
+    if inner in ("dd", "bins", "sine_dd"):
+        multi1 = rng.random() < 0.3
+        p1["ddargs"] = _dd(rng, multi1)
+    steps = [("aggregate", p1)]
+    fan = multi1
+    if kind in (2, 3) and not multi1:
+        if rng.random() < 0.7:
+            steps.append(("transform", {"transform": "power", "exp": np.arange(1, int(rng.integers(2, 5)))}))
+            fan = True
+        else:
+            steps.append(("transform", {"transform": "spline"}))
+            fan = True
+    outer = str(rng.choice(["sum", "mean", "min", "max", "dd", "bins", "nanmean"]))
+    p2 = {"calc": outer, "groupby": g2}
+    if outer in ("dd", "bins"):
+        p2["ddargs"] = _dd(rng, (not fan) and rng.random() < 0.3)
+    steps.append(("aggregate", p2))
+    if kind == 7 and g2 == "month":
+        steps.append(("aggregate", {"calc": "sum", "groupby": "year"}))
+    return steps
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_specs_match_oracle(torch_cuda, seed):
+    rng = np.random.default_rng(1000 + seed)
+    dtype = np.float64 if seed % 2 == 0 else np.float32
+    T, ny, nx = 24 * int(rng.integers(70, 130)) + int(rng.integers(0, 24)), int(rng.integers(3, 9)), int(rng.integers(3, 12))
+    cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=seed, ocean_frac=0.1, scattered_nan=15)
+    time = pd.date_range("2001-11-17 05:00", periods=T, freq="h")
+    lon360 = bool(seed % 3 == 0)
+    lat, lon = -10 + 0.5 * np.arange(ny), (170.0 if lon360 else -30.0) + 0.5 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, max(2, ny * nx // 9), seed=seed, secondary=bool(seed % 2), zero_frac=0.15)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=lon360)
+    w = af.weights_from_objects(ds, gr, table=tab)
+    ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
+    ods = ra.ODataset(cube.astype(np.float64), time, lat, lon, lon360)
+    for trial in range(7):
+        # all names of one call must share the output frequency (one panel time axis)
+        out_freq, spec = None, {}
+        for v in range(int(rng.integers(1, 4))):
+            for _ in range(20):
+                steps = _random_steps(rng)
+                last = [p["groupby"] for k, p in steps if k == "aggregate"][-1]
+                if out_freq in (None, last):
+                    out_freq = last
+                    spec[f"v{v}"] = steps
+                    break
+        want = ra.aggregate_dataset(ow, ods, engine="numba", **spec)
+        got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+        assert list(got.columns) == list(want.columns), spec
+        assert len(got) == len(want), spec
+        assert (got["geoid"].values == want["geoid"].values).all() and (got["time"].values == want["time"].values).all(), spec
+        cols = [c for c in got.columns if c not in ("geoid", "time")]
+        np.testing.assert_allclose(got[cols].values.astype(float), want[cols].values.astype(float), rtol=1e-10, atol=1e-10,
+                                   equal_nan=True, err_msg=repr(spec))
