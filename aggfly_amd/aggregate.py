@@ -238,6 +238,26 @@ def _label_values(labels):
     return pd.DatetimeIndex(labels).values
 
 
+_ZERO_REGIONS: dict = {}
+
+
+def _zero_weight_regions(wdf) -> set:
+    """Regions whose weights sum to zero (`spatial.py:148-150`), cached per table object."""
+    key = id(wdf)
+    hit = _ZERO_REGIONS.get(key)
+    if hit is not None and hit[0] == len(wdf):
+        return hit[1]
+    wsum = wdf.groupby("index_right")["weight"].sum()
+    zr = set(wsum.index[~(wsum > 0)])
+    try:
+        import weakref
+        weakref.finalize(wdf, _ZERO_REGIONS.pop, key, None)
+        _ZERO_REGIONS[key] = (len(wdf), zr)
+    except TypeError:
+        pass
+    return zr
+
+
 def _assemble_frame(res: np.ndarray, names, region_ids, labels, weights) -> pd.DataFrame:
     """Long frame + NaN-row policy (`spatial.py:136-154`).  res: [K, R, P]."""
     n_regions, n_time = res.shape[1], res.shape[2]
@@ -246,8 +266,7 @@ def _assemble_frame(res: np.ndarray, names, region_ids, labels, weights) -> pd.D
     for k, nm in enumerate(names):
         out[nm] = res[k].reshape(-1)
     if getattr(weights, "zero_weight", "area") == "nan":
-        wsum = weights.weights.groupby("index_right")["weight"].sum()
-        zero_regions = set(wsum.index[~(wsum > 0)])
+        zero_regions = _zero_weight_regions(weights.weights)
         keep = out["region_id"].isin(zero_regions) | out[list(names)].notna().all(axis=1)
         return out.loc[keep].reset_index(drop=True)
     return out.dropna(subset=list(names)).reset_index(drop=True)
