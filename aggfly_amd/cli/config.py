@@ -1,14 +1,19 @@
-"""Config loading and validation (`aggfly/cli/config.py:1-400` schema).
+"""YAML config -> ``RunConfig`` for the CLI.
 
-Pure: parses YAML into ``RunConfig`` and reports EVERY problem at once (``ConfigError``),
-without touching climate data.  Accepted beyond the reference's schema: ``aggregate.engine:
-hip`` and ``weights.table`` (path to the precomputed weights table).
+Accepts the reference CLI's schema (`aggfly/cli/config.py:214-386`; example
+`examples/era5_counties_area.yaml`) so existing configs keep working, plus two extensions:
+``aggregate.engine: hip`` and ``weights.table`` (path of the precomputed weights table).
+
+Design: the schema is DATA (``SCHEMA`` below: section -> field -> rule), and one generic walker
+validates it, so that every problem in a file is reported in one pass (``ConfigError.errors``)
+and adding a field is a one-line change.  Only the step lists under ``aggregate.variables``
+need hand-written checks.  Nothing here touches climate data.
 """
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from dataclasses import dataclass, field, fields
+from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 import yaml
@@ -33,6 +38,61 @@ class ConfigError(Exception):
 
 
 @dataclass
+class Rule:
+    """How one ``section.key`` maps onto a RunConfig attribute."""
+    attr: str
+    default: Any = None
+    required: bool = False
+    choices: Optional[set] = None
+    kind: Optional[type] = None          # dict / str / list: checked when the value is present
+    kind_hint: str = ""
+    cast: Optional[type] = None
+
+
+# section -> yaml key -> rule
+SCHEMA: Dict[str, Dict[str, Rule]] = {
+    "regions": {
+        "path": Rule("regions_path", required=True),
+        "regionid": Rule("regionid", required=True),
+        "region_list": Rule("region_list"),
+    },
+    "dataset": {
+        "path": Rule("dataset_path", required=True),
+        "var": Rule("var", required=True),
+        "preprocess": Rule("preprocess"),
+        "preprocess_from": Rule("preprocess_from"),
+        "lon_is_360": Rule("lon_is_360", default=True, cast=bool),
+        "timecoord": Rule("timecoord", default="time"),
+        "xycoords": Rule("xycoords", default=["longitude", "latitude"]),
+        "time_sel": Rule("time_sel"),
+        "chunks": Rule("chunks"),
+        "clip_to_regions": Rule("clip_to_regions", default=True, cast=bool),
+        "storage_options": Rule("storage_options", kind=dict, kind_hint="a mapping"),
+        "engine": Rule("reader_engine", kind=str, kind_hint="a string (e.g. 'zarr')"),
+    },
+    "weights": {
+        "project_dir": Rule("project_dir"),
+        "table": Rule("weights_table"),
+        "zero_weight": Rule("zero_weight", default="nan", choices=ALLOWED_ZERO_WEIGHT),
+        "secondary": Rule("secondary"),
+    },
+    "aggregate": {
+        "engine": Rule("engine", default="auto", choices=ALLOWED_ENGINE),
+        "variables": Rule("variables"),
+    },
+    "execution": {
+        "backend": Rule("backend", default="threads", choices=ALLOWED_BACKEND),
+        "n_workers": Rule("n_workers", default=1, cast=int),
+        "threads_per_worker": Rule("threads_per_worker", default=1, cast=int),
+    },
+    "output": {
+        "path": Rule("output_path", required=True),
+        "format": Rule("output_format"),
+    },
+}
+
+
+@dataclass
 class SecondaryWeightsConfig:
     type: str
     path: str
@@ -42,33 +102,33 @@ class SecondaryWeightsConfig:
 
 @dataclass
 class RunConfig:
-    regions_path: str
-    regionid: str
-    region_list: Optional[List[str]]
-    dataset_path: str
-    var: str
-    preprocess: Optional[str]
-    preprocess_from: Optional[str]
-    lon_is_360: bool
-    timecoord: str
-    xycoords: Tuple[str, str]
-    time_sel: Optional[str]
-    chunks: Optional[Dict[str, object]]
-    clip_to_regions: bool
-    storage_options: Optional[Dict[str, object]]
-    reader_engine: Optional[str]
-    project_dir: Optional[str]
-    weights_table: Optional[str]
-    secondary: Optional[SecondaryWeightsConfig]
-    zero_weight: str
-    engine: str
-    variables: Dict[str, List]
-    years: Optional[List[int]]
-    backend: str
-    n_workers: int
-    threads_per_worker: int
-    output_path: str
-    output_format: str
+    regions_path: str = ""
+    regionid: str = ""
+    region_list: Optional[List[str]] = None
+    dataset_path: str = ""
+    var: str = ""
+    preprocess: Optional[str] = None
+    preprocess_from: Optional[str] = None
+    lon_is_360: bool = True
+    timecoord: str = "time"
+    xycoords: Tuple[str, str] = ("longitude", "latitude")
+    time_sel: Optional[str] = None
+    chunks: Optional[Dict[str, object]] = None
+    clip_to_regions: bool = True
+    storage_options: Optional[Dict[str, object]] = None
+    reader_engine: Optional[str] = None
+    project_dir: Optional[str] = None
+    weights_table: Optional[str] = None
+    secondary: Optional[SecondaryWeightsConfig] = None
+    zero_weight: str = "nan"
+    engine: str = "auto"
+    variables: Dict[str, List] = field(default_factory=dict)
+    years: Optional[List[int]] = None
+    backend: str = "threads"
+    n_workers: int = 1
+    threads_per_worker: int = 1
+    output_path: str = ""
+    output_format: str = ""
 
     @property
     def templated(self) -> bool:
@@ -80,191 +140,155 @@ class RunConfig:
         return [self.dataset_path.format(year=y) for y in (self.years or [])]
 
     def to_aggregator_dict(self) -> Dict[str, List]:
-        """``variables`` -> the aggregator_dict aggregate_dataset takes.  A transform's ``exp``
-        becomes a NumPy array: the library indexes ``exp[0]`` after wrapping non-lists, so a
-        bare list [1, 2] would be read as the scalar 1 (`config.py:98-113`)."""
-        out = {}
-        for name, steps in self.variables.items():
-            norm = []
-            for step_type, params in steps:
-                params = dict(params)
-                if step_type == "transform" and "exp" in params:
-                    params["exp"] = np.array(params["exp"])
-                norm.append((step_type, params))
-            out[name] = norm
-        return out
+        """``variables`` as the ``aggregator_dict`` of aggregate_dataset.  A power transform's
+        ``exp`` is handed over as a NumPy array: the library wraps non-lists and then indexes
+        ``[0]``, so a plain list [1, 2] would be read as the scalar 1 (`config.py:98-113`)."""
+        def norm(kind, params):
+            params = dict(params)
+            if kind == "transform" and "exp" in params:
+                params["exp"] = np.array(params["exp"])
+            return kind, params
+        return {name: [norm(k, p) for k, p in steps] for name, steps in self.variables.items()}
 
 
+# --------------------------------------------------------------------------------------
+# field-level helpers
+# --------------------------------------------------------------------------------------
 def _parse_years(spec, errors):
+    """``"1980:1990"`` (inclusive) | list | int | None -> list of ints."""
     if spec is None:
         return None
-    if isinstance(spec, bool):
-        errors.append("years: must be a range 'start:end', a list, or an int")
-        return None
-    if isinstance(spec, int):
-        return [spec]
-    if isinstance(spec, list):
-        try:
+    try:
+        if isinstance(spec, bool):
+            raise TypeError
+        if isinstance(spec, int):
+            return [spec]
+        if isinstance(spec, list):
             return [int(y) for y in spec]
-        except (TypeError, ValueError):
-            errors.append(f"years: list must contain integers, got {spec!r}")
-            return None
-    if isinstance(spec, str):
-        try:
-            if ":" in spec:
-                a, b = spec.split(":")
-                return list(range(int(a), int(b) + 1))
-            return [int(spec)]
-        except ValueError:
-            errors.append(f"years: could not parse {spec!r} (use 'start:end' or an int)")
-            return None
-    errors.append(f"years: unsupported type {type(spec).__name__}")
+        if isinstance(spec, str):
+            lo, sep, hi = spec.partition(":")
+            return list(range(int(lo), int(hi) + 1)) if sep else [int(lo)]
+    except (TypeError, ValueError):
+        pass
+    errors.append(f"years: could not parse {spec!r} (use a range 'start:end', a list, or an int)")
     return None
 
 
-def _validate_steps(name, steps, errors):
+def _check_steps(name, steps, errors):
+    where = f"aggregate.variables.{name}"
     if not isinstance(steps, list) or not steps:
-        errors.append(f"aggregate.variables.{name}: must be a non-empty list of steps")
+        errors.append(f"{where}: must be a non-empty list of steps")
         return
-    fan, conflict = 1, False
+    fan_out = 1
     for i, step in enumerate(steps):
-        loc = f"aggregate.variables.{name}[{i}]"
+        loc = f"{where}[{i}]"
         if not (isinstance(step, (list, tuple)) and len(step) == 2):
             errors.append(f"{loc}: each step must be [step_type, params]")
             continue
-        step_type, params = step
-        if step_type not in ALLOWED_STEP_TYPES:
-            errors.append(f"{loc}: unknown step type {step_type!r} (expected one of {sorted(ALLOWED_STEP_TYPES)})")
-            continue
-        if not isinstance(params, dict):
+        kind, params = step
+        if kind not in ALLOWED_STEP_TYPES:
+            errors.append(f"{loc}: unknown step type {kind!r} (expected one of {sorted(ALLOWED_STEP_TYPES)})")
+        elif not isinstance(params, dict):
             errors.append(f"{loc}: params must be a mapping")
-            continue
-        if step_type == "aggregate":
-            calc, groupby = params.get("calc"), params.get("groupby")
+        elif kind == "aggregate":
+            calc, dd = params.get("calc"), params.get("ddargs")
             if calc not in ALLOWED_CALCS:
                 errors.append(f"{loc}: calc {calc!r} not in {sorted(ALLOWED_CALCS)}")
-            if groupby not in ALLOWED_GROUPBY:
-                errors.append(f"{loc}: groupby {groupby!r} not in {sorted(ALLOWED_GROUPBY)}")
+            if params.get("groupby") not in ALLOWED_GROUPBY:
+                errors.append(f"{loc}: groupby {params.get('groupby')!r} not in {sorted(ALLOWED_GROUPBY)}")
             if calc in CALCS_NEEDING_DDARGS:
-                dd = params.get("ddargs")
                 if not isinstance(dd, list) or not dd:
                     errors.append(f"{loc}: calc {calc!r} requires a non-empty 'ddargs' list")
-                elif isinstance(dd[0], list) and fan > 1:
-                    conflict = True
+                elif isinstance(dd[0], list) and fan_out > 1:
+                    errors.append(f"{where}: cannot combine a multi-'ddargs' (bins) step with a multi-output "
+                                  "transform (e.g. multiple exponents) — the library rejects this at runtime")
         else:
-            has_exp, has_inter = "exp" in params, "inter" in params
-            is_spline = params.get("transform") == "spline" or "spline" in params
-            if not (has_exp or has_inter or is_spline):
+            spline = params.get("transform") == "spline" or "spline" in params
+            if not ("exp" in params or "inter" in params or spline):
                 errors.append(f"{loc}: transform step needs one of 'exp' (power), 'inter', or transform: spline")
-            if has_exp and not isinstance(params["exp"], (list, int)):
+            exp = params.get("exp")
+            if exp is not None and not isinstance(exp, (list, int)):
                 errors.append(f"{loc}: 'exp' must be an int or a list of ints")
-            if has_exp and isinstance(params["exp"], list):
-                fan = len(params["exp"])
-    if conflict:
-        errors.append(f"aggregate.variables.{name}: cannot combine a multi-'ddargs' (bins) step with a "
-                      "multi-output transform (e.g. multiple exponents) — the library rejects this at runtime")
+            if isinstance(exp, list):
+                fan_out = len(exp)
 
 
+def _secondary(raw, errors):
+    if raw is None:
+        return None
+    if not isinstance(raw, dict):
+        errors.append("weights.secondary must be a mapping")
+        return None
+    if raw.get("type") not in ALLOWED_SECONDARY:
+        errors.append(f"weights.secondary.type {raw.get('type')!r} not in {sorted(ALLOWED_SECONDARY)}")
+    if not raw.get("path"):
+        errors.append("weights.secondary.path is required")
+    return SecondaryWeightsConfig(raw.get("type"), raw.get("path"), raw.get("crop"), raw.get("feed"))
+
+
+# --------------------------------------------------------------------------------------
+# the walker
+# --------------------------------------------------------------------------------------
 def parse_config(raw) -> RunConfig:
-    errors: List[str] = []
-    if raw is None or not isinstance(raw, dict):
+    """Validate a parsed YAML mapping; raise ConfigError listing EVERY problem found."""
+    if not isinstance(raw, dict) or not raw:
         raise ConfigError(["config must be a non-empty YAML mapping"])
+    errors: List[str] = []
+    values: Dict[str, Any] = {}
+    for section, rules in SCHEMA.items():
+        body = raw.get(section) or {}
+        if not isinstance(body, dict):
+            errors.append(f"{section}: must be a mapping")
+            body = {}
+        for key, rule in rules.items():
+            val = body.get(key, rule.default)
+            if rule.required and not val:
+                errors.append(f"{section}.{key} is required")
+            if val is not None and rule.kind is not None and not isinstance(val, rule.kind):
+                errors.append(f"{section}.{key} must be {rule.kind_hint}")
+                val = None
+            if val is not None and rule.choices is not None and val not in rule.choices:
+                errors.append(f"{section}.{key} {val!r} not in {sorted(rule.choices)}")
+                val = rule.default
+            if val is not None and rule.cast is not None:
+                val = rule.cast(val)
+            values[rule.attr] = val
 
-    def section(key):
-        val = raw.get(key)
-        if val is None:
-            return {}
-        if not isinstance(val, dict):
-            errors.append(f"{key}: must be a mapping")
-            return {}
-        return val
-
-    regions, dataset, weights = section("regions"), section("dataset"), section("weights")
-    aggregate, execution, output = section("aggregate"), section("execution"), section("output")
-
-    if not regions.get("path"):
-        errors.append("regions.path is required")
-    if not regions.get("regionid"):
-        errors.append("regions.regionid is required")
-    if not dataset.get("path"):
-        errors.append("dataset.path is required")
-    if not dataset.get("var"):
-        errors.append("dataset.var is required")
-    preprocess, preprocess_from = dataset.get("preprocess"), dataset.get("preprocess_from")
-    if preprocess is not None and preprocess_from is not None:
+    # cross-field rules
+    if values["preprocess"] is not None and values["preprocess_from"] is not None:
         errors.append("dataset: set at most one of 'preprocess' and 'preprocess_from'")
-    if preprocess_from is not None and ":" not in str(preprocess_from):
+    if values["preprocess_from"] is not None and ":" not in str(values["preprocess_from"]):
         errors.append("dataset.preprocess_from must be 'path/to/file.py:function'")
-    xycoords = dataset.get("xycoords", ["longitude", "latitude"])
-    if not (isinstance(xycoords, list) and len(xycoords) == 2):
+    xy = values["xycoords"]
+    if not (isinstance(xy, list) and len(xy) == 2):
         errors.append("dataset.xycoords must be a 2-item list [lon_name, lat_name]")
-        xycoords = ["longitude", "latitude"]
-    storage_options = dataset.get("storage_options")
-    if storage_options is not None and not isinstance(storage_options, dict):
-        errors.append("dataset.storage_options must be a mapping")
-        storage_options = None
-    reader_engine = dataset.get("engine")
-    if reader_engine is not None and not isinstance(reader_engine, str):
-        errors.append("dataset.engine must be a string (e.g. 'zarr')")
-        reader_engine = None
+        xy = ["longitude", "latitude"]
+    values["xycoords"] = (xy[0], xy[1])
+    values["secondary"] = _secondary(values["secondary"], errors)
 
-    zero_weight = weights.get("zero_weight", "nan")
-    if zero_weight not in ALLOWED_ZERO_WEIGHT:
-        errors.append(f"weights.zero_weight {zero_weight!r} not in {sorted(ALLOWED_ZERO_WEIGHT)}")
-        zero_weight = "nan"
-    secondary = None
-    sraw = weights.get("secondary")
-    if sraw is not None:
-        if not isinstance(sraw, dict):
-            errors.append("weights.secondary must be a mapping")
-        else:
-            if sraw.get("type") not in ALLOWED_SECONDARY:
-                errors.append(f"weights.secondary.type {sraw.get('type')!r} not in {sorted(ALLOWED_SECONDARY)}")
-            if not sraw.get("path"):
-                errors.append("weights.secondary.path is required")
-            secondary = SecondaryWeightsConfig(sraw.get("type"), sraw.get("path"), sraw.get("crop"), sraw.get("feed"))
-
-    engine = aggregate.get("engine", "auto")
-    if engine not in ALLOWED_ENGINE:
-        errors.append(f"aggregate.engine {engine!r} not in {sorted(ALLOWED_ENGINE)}")
-    variables = aggregate.get("variables")
+    variables = values["variables"]
     if not isinstance(variables, dict) or not variables:
         errors.append("aggregate.variables must be a non-empty mapping of name -> steps")
-        variables = {}
+        values["variables"] = {}
     else:
         for name, steps in variables.items():
-            _validate_steps(name, steps, errors)
+            _check_steps(name, steps, errors)
 
-    years = _parse_years(raw.get("years"), errors)
-    backend = execution.get("backend", "threads")
-    if backend not in ALLOWED_BACKEND:
-        errors.append(f"execution.backend {backend!r} not in {sorted(ALLOWED_BACKEND)}")
-
-    output_path = output.get("path")
-    if not output_path:
-        errors.append("output.path is required")
-    output_format = output.get("format")
-    if output_format is None and output_path:
-        ext = os.path.splitext(str(output_path))[1].lstrip(".").lower()
-        output_format = {"pq": "parquet"}.get(ext, ext)
-    if output_format not in ALLOWED_FORMAT:
-        errors.append(f"output.format {output_format!r} not in {sorted(ALLOWED_FORMAT)} "
+    values["years"] = _parse_years(raw.get("years"), errors)
+    out_path, fmt = values["output_path"], values["output_format"]
+    if fmt is None and out_path:
+        ext = os.path.splitext(str(out_path))[1].lstrip(".").lower()
+        fmt = {"pq": "parquet"}.get(ext, ext)
+    if fmt not in ALLOWED_FORMAT:
+        errors.append(f"output.format {fmt!r} not in {sorted(ALLOWED_FORMAT)} "
                       "(set output.format or use a .parquet/.feather/.csv extension)")
-    if dataset.get("path") and "{year}" in str(dataset.get("path")) and not years:
+    values["output_format"] = fmt
+    if values["dataset_path"] and "{year}" in str(values["dataset_path"]) and not values["years"]:
         errors.append("dataset.path contains '{year}' but no 'years' were given (add years: 'start:end')")
     if errors:
         raise ConfigError(errors)
-    return RunConfig(
-        regions_path=regions["path"], regionid=regions["regionid"], region_list=regions.get("region_list"),
-        dataset_path=dataset["path"], var=dataset["var"], preprocess=preprocess, preprocess_from=preprocess_from,
-        lon_is_360=bool(dataset.get("lon_is_360", True)), timecoord=dataset.get("timecoord", "time"),
-        xycoords=(xycoords[0], xycoords[1]), time_sel=dataset.get("time_sel"), chunks=dataset.get("chunks"),
-        clip_to_regions=bool(dataset.get("clip_to_regions", True)), storage_options=storage_options,
-        reader_engine=reader_engine, project_dir=weights.get("project_dir"), weights_table=weights.get("table"),
-        secondary=secondary, zero_weight=zero_weight, engine=engine, variables=variables, years=years,
-        backend=backend, n_workers=int(execution.get("n_workers", 1)),
-        threads_per_worker=int(execution.get("threads_per_worker", 1)),
-        output_path=output_path, output_format=output_format)
+    known = {f.name for f in fields(RunConfig)}
+    return RunConfig(**{k: v for k, v in values.items() if k in known})
 
 
 def load_config(path) -> RunConfig:
