@@ -6,6 +6,8 @@ linearity of the mean columns, the bins partition identity, split-vs-unsplit chu
 import numpy as np
 import pytest
 
+import pandas as pd
+
 from aggfly_amd import hip, synth
 from oracle import cport
 
@@ -120,3 +122,98 @@ def test_full_size_bins_partition_identity(setup):
     assert (total == 365).mean() > 0.9
     res = out["res"].sum(dim=0).cpu().numpy()[:, 0]
     assert np.nanmax(res) <= 365 + 1e-9
+
+
+# ---------------------------------------------------------------------------------------
+# the other BASELINE.json configs at their full sizes: sampled cells against the oracle
+# ---------------------------------------------------------------------------------------
+def _fill(torch, T, ny, nx, dtype, seed, spd):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    cube = torch.empty((T, ny, nx), dtype=dtype, device="cuda")
+    for k0 in range(0, T, 512):
+        k1 = min(T, k0 + 512)
+        k = torch.arange(k0, k1, device="cuda", dtype=torch.float32)
+        base = 14.0 + 11.0 * torch.sin(2 * np.pi * torch.floor(k / spd) / 365.0)
+        cube[k0:k1] = (base[:, None, None] + 6.0 * torch.randn((k1 - k0, ny, nx), generator=g, device="cuda", dtype=torch.float32)).to(dtype)
+    idx = torch.randint(0, T * ny * nx, (500,), generator=g, device="cuda")
+    cube.view(-1)[idx] = float("nan")
+    return cube
+
+
+def _sample_cells(torch, cube, n, seed):
+    T = cube.shape[0]
+    C = cube[0].numel()
+    pick = np.sort(np.random.default_rng(seed).choice(C, n, replace=False))
+    host = cube.view(T, C)[:, torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.float64).reshape(T, 1, -1)
+    return pick, host
+
+
+def _need(torch, gb):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gb * 1e9:
+        pytest.skip(f"needs {gb} GB of free HBM")
+
+
+def test_c3_forty_years_hourly_f32(torch_cuda):
+    """configs[2]: ERA5 hourly, 40 years (T = 350,640) on the CONUS window, f32 storage, P = 40."""
+    torch = torch_cuda
+    _need(torch, 45)
+    T, ny, nx = 350640, 104, 236
+    cube = _fill(torch, T, ny, nx, torch.float32, 11, 24)
+    ib = synth.hourly_bounds(T)
+    years = pd.date_range("1981-01-01", periods=T, freq="h").year.values[ib[:-1]]
+    ob = np.concatenate([[0], np.nonzero(np.diff(years))[0] + 1, [len(ib) - 1]]).astype(np.int64)
+    assert len(ob) - 1 == 41 or len(ob) - 1 == 40
+    cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)] + \
+           [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+    plan = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, cols, exact_order=True)
+    cells = plan.run_temporal(cube)
+    pick, host = _sample_cells(torch, cube, 24, 12)
+    got = cells[:, :, torch.from_numpy(pick).cuda()].cpu().numpy()
+    m = cport.resample(host, ib, "mean")
+    for k, e in enumerate((1, 2)):
+        want = cport.resample(np.power(m, e), ob, "sum").reshape(len(ob) - 1, -1)
+        np.testing.assert_allclose(got[k], want, rtol=4e-16, atol=0, equal_nan=True)
+    want = cport.resample(cport.resample(host, ib, "dd", [10, 30, 0]), ob, "sum").reshape(len(ob) - 1, -1)
+    np.testing.assert_array_equal(got[2], want)
+
+
+def test_c4_cmip6_daily_bins_251_years(torch_cuda):
+    """configs[3]: daily tas 1850-2100 on a noleap calendar (T = 91,615), 180 x 288 cells, 13 bins/yr."""
+    torch = torch_cuda
+    _need(torch, 30)
+    import aggfly_amd as af
+    from aggfly_amd.timegroups import resample_groups
+    T, ny, nx = 91615, 180, 288
+    cube = _fill(torch, T, ny, nx, torch.float32, 21, 1)
+    time = af.cf_range("1850-01-01", T, "D", "noleap")
+    ob, labels = resample_groups(time, "YE")
+    assert len(labels) == 251 and set(np.diff(ob).tolist()) == {365}
+    edges = np.arange(-20, 50, 5.0)
+    dda = [[edges[i], edges[i + 1], 0] for i in range(13)]
+    plan = hip.FusedPlan(T, ny * nx, hip.F32, ob, np.arange(252), [dict(inner="bins", inner_args=r) for r in dda])
+    assert "ibins_sl" in plan.describe()
+    cells = plan.run_temporal(cube)
+    pick, host = _sample_cells(torch, cube, 32, 22)
+    want = cport.block_bins(host, ob, dda)[:, 0]                    # [G, cells, D]
+    got = cells[:, :, torch.from_numpy(pick).cuda()].cpu().numpy()  # [D, G, cells]
+    np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want)
+    assert (got.sum(axis=0) <= 365).all()
+
+
+def test_c5_sine_dd_tenth_degree_global(torch_cuda):
+    """configs[4]: 0.1 deg global grid (1801 x 3600), (tmin, tmax) pairs per day, sine_dd -> annual sum."""
+    torch = torch_cuda
+    _need(torch, 30)
+    T, ny, nx = 730, 1801, 3600
+    cube = _fill(torch, T, ny, nx, torch.float32, 31, 2)
+    ib = synth.hourly_bounds(T, 2)
+    ob = np.array([0, 365], dtype=np.int64)
+    plan = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"),
+                                                         dict(inner="sine_dd", inner_args=(0, 18, 1), outer="sum")], exact_order=True)
+    cells = plan.run_temporal(cube)
+    pick, host = _sample_cells(torch, cube, 48, 32)
+    got = cells[:, 0, torch.from_numpy(pick).cuda()].cpu().numpy()
+    for k, dd in enumerate(([10, 30, 0], [0, 18, 1])):
+        want = cport.resample(cport.resample(host, ib, "sine_dd", dd), ob, "sum").reshape(-1)
+        np.testing.assert_allclose(got[k], want, rtol=1e-10, atol=1e-9, equal_nan=True)
