@@ -80,6 +80,9 @@ def _dataset_from_cells(template: Dataset, cells_pc, labels, history) -> Dataset
     """Wrap a [P, n_cells] device tensor as a Dataset on the template's grid."""
     ny, nx = len(template.latitude), len(template.longitude)
     data = cells_pc.reshape(cells_pc.shape[0], ny, nx)
+    if eng.config.match_reference_f32 and str(template.da.dtype).endswith("float32"):
+        import torch
+        data = data.to(torch.float32)      # values are already float32-rounded: the cast is exact
     da = DataArray(data, ("time", "latitude", "longitude"),
                    {"time": labels, "latitude": template.latitude, "longitude": template.longitude})
     new = template.deepcopy()

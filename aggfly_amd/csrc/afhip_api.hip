@@ -252,6 +252,7 @@ static int lower_columns(afhip_plan* pl) {
     for (int j = 0; j < K; ++j) {
         const afhip_column& c = pl->columns[j];
         ColOp co{};
+        co.rounding = c.rounding;
         switch (c.inner) {
             case AFHIP_MEAN: co.src = SRC_MEAN; stat = std::max(stat, 1); break;
             case AFHIP_SUM: co.src = SRC_SUM; stat = std::max(stat, 1); break;
@@ -533,7 +534,10 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
     CombineArgs ca{};
     ca.partial = partial; ca.slot_ptr = pl->d_slot_ptr.p; ca.outer_bounds = pl->d_ob.p;
     ca.cells_out = cells; ca.panel = panel; ca.C = C; ca.P = P; ca.K = pl->K;
-    for (int j = 0; j < pl->K; ++j) ca.outer[j] = pl->cols[(size_t)j].outer;
+    for (int j = 0; j < pl->K; ++j) {
+        ca.outer[j] = pl->cols[(size_t)j].outer;
+        ca.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
+    }
     dim3 grid((unsigned)P, (unsigned)((C + WG - 1) / WG));
     hipLaunchKernelGGL(k_combine_slots, grid, dim3(WG), 0, st, ca);
     HIP_TRY(hipGetLastError());

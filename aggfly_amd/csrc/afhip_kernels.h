@@ -53,6 +53,7 @@ struct ColOp {
     int32_t src, src_idx;      // SRC_*; slot index for SRC_THR
     int32_t tf, tf_iarg;       // TF_*; integer exponent for TF_POWI
     int32_t outer, skind;      // OUT_*; sine_dd kind flag (0 cooling, 1 heating)
+    int32_t rounding, pad;     // AFHIP_ROUND_* bits (float32 intermediates like the reference)
     double s0, s1;             // sine_dd thresholds
     double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
     double o0, o1, obase;      // outer dd/bins thresholds
@@ -343,9 +344,17 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                                 x = -sine_heat(co.s0, mn[i], mx[i], tavg) + sine_heat(co.s1, mn[i], mx[i], tavg);
                         }
                     }
+                    if (co.rounding & 1) x = (double)(float)x;        // the reference stored this step in float32
                     const int tf = co.tf;
                     if (tf == TF_POWI) x = powi_dd(x, co.tf_iarg);
-                    else if (tf == TF_HINGE) x = ((x > co.tf_arg) ? 1.0 : 0.0) * (x - co.tf_arg);
+                    else if (tf == TF_HINGE) {
+                        if (co.rounding & 2) {
+                            const float xf = (float)x, kf = (float)co.tf_arg;
+                            x = (double)(((xf > kf) ? 1.0f : 0.0f) * (xf - kf));
+                        } else {
+                            x = ((x > co.tf_arg) ? 1.0 : 0.0) * (x - co.tf_arg);
+                        }
+                    }
                     else if ((FEAT & 2) && tf == TF_POW) x = pow(x, co.tf_arg);
                     if constexpr (SL) {
                         if (active) a.partial[((int64_t)slot * K + j) * C + c0 + i] = x;

@@ -24,6 +24,7 @@ struct CombineArgs {
     int64_t C, P;
     int32_t K;
     int32_t outer[MAX_COLS];
+    int32_t round_final[MAX_COLS];   // 1: round the merged value to float32 (reference dtype rule)
 };
 
 __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
                 else v += x;
             }
             if (o == OUT_MEAN) v = v / ng;
+            if (a.round_final[j]) v = (double)(float)v;
         }
         valid = valid && (v == v);
         if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;

@@ -234,7 +234,13 @@ class Dataset:
 
     def power(self, exp, update=False):
         """`dataset.py:442-473` (`np.power` per block, `:527-543`)."""
-        data = self.da.data ** exp if _is_torch(self.da.data) else np.power(self.da.data, exp)
+        if _is_torch(self.da.data):
+            base = self.da.data
+            if isinstance(exp, np.generic) and str(base.dtype).endswith("float32"):
+                base = base.double()       # NumPy 2 promotion: float32 ** np.int64 -> float64 (np.power, dataset.py:543)
+            data = base ** (exp.item() if isinstance(exp, np.generic) else exp)
+        else:
+            data = np.power(self.da.data, exp)
         if update:
             self.da = self.da._replace(data=data)
             self.history.append(f"power{exp}")

@@ -45,6 +45,10 @@ class config:
     #: reference's k-ascending order (bit-exact sums) at the cost of parallelism when there
     #: are few outer periods.
     exact_order = os.environ.get("AGGFLY_HIP_EXACT_ORDER", "0") == "1"
+    #: float32 cubes: reproduce the reference's float32 intermediates (every step's output stored
+    #: in its input dtype, `aggfly/aggregate/nb_kernels.py:257-262`; `np.power` with an int64
+    #: exponent promotes to float64 under NumPy 2) instead of keeping float64 throughout
+    match_reference_f32 = os.environ.get("AGGFLY_HIP_MATCH_F32", "0") == "1"
     #: kernel tuning arm (see include/aggfly_hip.h, afhip_plan_desc.tuning)
     tuning = int(os.environ.get("AGGFLY_HIP_TUNING", "0"))
 
@@ -265,8 +269,19 @@ def get_csr(weights, dataset: Dataset):
 # --------------------------------------------------------------------------------------
 # fused execution
 # --------------------------------------------------------------------------------------
-def _column_dict(c: ColumnProg) -> dict:
+def _column_dict(c: ColumnProg, f32_rules: bool = False) -> dict:
     d = {"inner": c.inner.calc}
+    if f32_rules:
+        # dtype walk of the reference's numba path on a float32 cube: an aggregate step stores its
+        # output in its input's dtype; np.power with an int64 exponent promotes to float64
+        # (NumPy 2 promotion); the hinge stays float32
+        r = hip.ROUND_INNER
+        is64 = c.tf is not None and c.tf[0] == "pow"
+        if c.tf is not None and c.tf[0] == "hinge":
+            r |= hip.ROUND_HINGE
+        if c.outer is not None and not is64:
+            r |= hip.ROUND_FINAL
+        d["rounding"] = r
     if c.inner.ddargs is not None:
         d["inner_args"] = c.inner.ddargs
         if c.inner.calc == "sine_dd" and c.inner.ddargs[2] not in (0.0, 1.0):
@@ -330,7 +345,8 @@ def run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=No
     T = int(cube.shape[0])
     n_cells = int(cube[0].numel()) if T else int(np.prod(cube.shape[1:]))
     code = hip._dtype_code(cube)
-    cdicts = [_column_dict(c) for c in cols]
+    f32_rules = config.match_reference_f32 and code == hip.F32
+    cdicts = [_column_dict(c, f32_rules) for c in cols]
     try:
         plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order)
     except hip.HipUnsupported:

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libaggfly_hip.so")
 F32, F64 = 0, 1
 MEAN, SUM, MIN, MAX, NANMEAN, DD, BINS, SINE_DD, IDENTITY = range(9)
 TF_NONE, TF_POW, TF_HINGE = 0, 1, 2
+ROUND_INNER, ROUND_HINGE, ROUND_FINAL = 1, 2, 4
 CALC_CODE = {"mean": MEAN, "sum": SUM, "min": MIN, "max": MAX, "nanmean": NANMEAN,
              "dd": DD, "bins": BINS, "sine_dd": SINE_DD}
 E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4
@@ -46,7 +47,7 @@ class HipUnsupported(HipEngineError):
 
 class Column(C.Structure):
     _fields_ = [("inner", C.c_int32), ("transform", C.c_int32), ("outer", C.c_int32),
-                ("reserved", C.c_int32), ("inner_args", C.c_double * 3),
+                ("rounding", C.c_int32), ("inner_args", C.c_double * 3),
                 ("transform_arg", C.c_double), ("outer_args", C.c_double * 3)]
 
 
@@ -309,6 +310,7 @@ class FusedPlan:
             cols[j].transform_arg = float(c.get("transform_arg", 0.0))
             outer = c.get("outer", "identity")
             cols[j].outer = IDENTITY if outer == "identity" else CALC_CODE[outer]
+            cols[j].rounding = int(c.get("rounding", 0))
             for i, v in enumerate(c.get("inner_args", (0.0, 0.0, 0.0))):
                 cols[j].inner_args[i] = float(v)
             for i, v in enumerate(c.get("outer_args", (0.0, 0.0, 0.0))):

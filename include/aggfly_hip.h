@@ -57,6 +57,13 @@ extern "C" {
 #define AFHIP_TF_POW   1   /* Dataset.power / _power  aggfly/dataset/dataset.py:442-473,527-543 */
 #define AFHIP_TF_HINGE 2   /* Dataset.spline hinge (x>knot)*(x-knot), dataset.py:475-481 (knot 20) */
 
+/* The reference stores every step's output in its input dtype (nb_kernels.py:257-262), so on a
+ * float32 cube its intermediates are float32.  This engine keeps float64 throughout unless a
+ * column asks for the reference's roundings: */
+#define AFHIP_ROUND_INNER 1   /* round the inner reducer's value to float32                  */
+#define AFHIP_ROUND_HINGE 2   /* evaluate the hinge transform in float32                     */
+#define AFHIP_ROUND_FINAL 4   /* round the column's final (outer) value to float32           */
+
 const char* afhip_last_error(void);
 int afhip_abi_version(void);
 /* Number of visible GPUs (hipGetDeviceCount); 0 when there is none. */
@@ -138,7 +145,7 @@ typedef struct afhip_column {
     int32_t inner;          /* AFHIP_MEAN..AFHIP_SINE_DD                                   */
     int32_t transform;      /* AFHIP_TF_*                                                   */
     int32_t outer;          /* AFHIP_MEAN, SUM, MIN, MAX, DD, BINS or AFHIP_IDENTITY        */
-    int32_t reserved;
+    int32_t rounding;       /* AFHIP_ROUND_* bits: emulate the reference's float32 intermediates (0 = all float64) */
     double inner_args[3];   /* (t0, t1, flag) for DD / BINS / SINE_DD                       */
     double transform_arg;   /* exponent (POW) or knot (HINGE)                               */
     double outer_args[3];   /* (t0, t1, flag) for an outer DD / BINS                        */

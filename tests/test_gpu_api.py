@@ -360,3 +360,31 @@ def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
     a = af.aggregate_dataset(dataset=dev, weights=af.weights_from_objects(dev, gr, table=tab), **spec)
     b = af.aggregate_dataset(dataset=host, weights=af.weights_from_objects(host, gr, table=tab), **spec)
     pd.testing.assert_frame_equal(a, b)
+
+
+def test_float32_reference_rounding_mode(torch_cuda):
+    """On float32 cubes the reference's intermediates are float32 (each step stores its output in
+    its input dtype, nb_kernels.py:257-262).  By default this engine keeps float64 (more accurate,
+    ~1e-7 away from an all-float32 reference run); with match_reference_f32 it reproduces the
+    reference's roundings and must agree with the oracle's numba path RUN ON THE FLOAT32 INPUT."""
+    from aggfly_amd import engine as eng
+    ds, w, ods64, ow = _mid_case(np.float32)
+    ods32 = ra.ODataset(ds.cube().copy(), ods64.time, ods64.latitude, ods64.longitude, ods64.lon_is_360)
+    spec = dict(C2_SPEC,
+                mx=[("aggregate", {"calc": "max", "groupby": "date"}), ("aggregate", {"calc": "mean", "groupby": "month"})],
+                sp=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "spline"}),
+                    ("aggregate", {"calc": "sum", "groupby": "month"})])
+    want32 = ra.aggregate_dataset(ow, ods32, engine="numba", **spec)
+    cols = [c for c in want32.columns if c not in ("geoid", "time")]
+    old = (eng.config.match_reference_f32, eng.config.exact_order)
+    try:
+        eng.config.match_reference_f32, eng.config.exact_order = True, True
+        got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+        np.testing.assert_allclose(got[cols].values, want32[cols].values, rtol=1e-12, atol=0, equal_nan=True)
+        eng.config.match_reference_f32 = False
+        plain = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+    finally:
+        eng.config.match_reference_f32, eng.config.exact_order = old
+    # the default (all-float64) results sit ~1e-7 from the float32 reference run, as documented
+    rel = np.nanmax(np.abs(plain[cols].values - want32[cols].values) / np.maximum(np.abs(want32[cols].values), 1e-30))
+    assert 1e-12 < rel < 1e-4
