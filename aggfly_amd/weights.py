@@ -116,9 +116,7 @@ def weights_from_objects(clim: Dataset, georegions: GeoRegions, secondary_weight
 def weights_from_feather(path: str, clim: Dataset, georegions: GeoRegions, zero_weight: str = "nan") -> GridWeights:
     """Read a weights table the reference cached as feather
     (`aggfly/cache/project_cache.py:72-100`, layout ``{project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather``)."""
-    import pyarrow.feather as feather
-    table = feather.read_feather(path)
-    return weights_from_objects(clim, georegions, table=table, zero_weight=zero_weight)
+    return weights_from_objects(clim, georegions, table=pd.read_feather(path), zero_weight=zero_weight)
 
 
 def _read_table(path: str) -> pd.DataFrame:
@@ -128,8 +126,7 @@ def _read_table(path: str) -> pd.DataFrame:
     if ext in ("parquet", "pq"):
         return pd.read_parquet(path)
     if ext in ("feather", "arrow"):
-        import pyarrow.feather as feather
-        return feather.read_feather(path)
+        return pd.read_feather(path)
     raise ValueError(f"unsupported table format: {path}")
 
 

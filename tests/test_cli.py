@@ -234,3 +234,39 @@ def test_cli_two_ranks_equals_one(torch_cuda, tmp_path):
         outs.append(pd.read_csv(out))
     pd.testing.assert_frame_equal(outs[0], outs[1])
     assert len(outs[0]) == 3
+
+
+def test_info_regions_weights_commands_need_no_gpu(tmp_path):
+    paths, rpath, wpath = _write_run_inputs(tmp_path)
+    r = CliRunner().invoke(cli, ["info", paths[0], "--var", "t2m"])
+    assert r.exit_code == 0, r.output
+    assert "zarr store" in r.output and "t2m" in r.output and "lon_is_360: False" in r.output and "4 steps" in r.output
+    r = CliRunner().invoke(cli, ["regions", rpath, "--regionid", "geoid"])
+    assert r.exit_code == 0 and "1 regions" in r.output and "r1" in r.output
+    cpath = tmp_path / "c.yaml"
+    cpath.write_text(yaml.safe_dump(_run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv"))))
+    r = CliRunner().invoke(cli, ["weights", str(cpath)])
+    assert r.exit_code == 0, r.output
+    assert "(cell, region) pairs" in r.output and "1 regions" in r.output
+    # a config without any weights source explains where weights come from
+    bad = _run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv"))
+    bad["weights"] = {}
+    cpath.write_text(yaml.safe_dump(bad))
+    r = CliRunner().invoke(cli, ["weights", str(cpath)])
+    assert r.exit_code == 1 and "no precomputed weights found" in r.output
+
+
+def test_weights_table_found_in_project_cache(tmp_path):
+    """N3: the reference caches weights as {project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather
+    (`aggfly/cache/project_cache.py:46-47`); the CLI picks that file up when weights.table is unset."""
+    paths, rpath, wpath = _write_run_inputs(tmp_path)
+    cache = tmp_path / "proj" / "tmp" / "GridWeights" / "mod-abc123"
+    cache.mkdir(parents=True)
+    pd.read_parquet(wpath).to_feather(cache / "abc123.feather")
+    raw = _run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv"))
+    raw["weights"] = {"project_dir": str(tmp_path / "proj")}
+    c = cfg.parse_config(raw)
+    assert pipeline.find_weights_table(c).endswith("abc123.feather")
+    w, gr, sample = pipeline.compute_weights(c)
+    assert len(w.weights) == len(pd.read_parquet(wpath)) and w.zero_weight == "nan"
+    assert len(sample.latitude) < 8 and len(sample.longitude) < 8        # clipped to the regions' extent
