@@ -116,7 +116,21 @@ def weights_from_objects(clim: Dataset, georegions: GeoRegions, secondary_weight
 def weights_from_feather(path: str, clim: Dataset, georegions: GeoRegions, zero_weight: str = "nan") -> GridWeights:
     """Read a weights table the reference cached as feather
     (`aggfly/cache/project_cache.py:72-100`, layout ``{project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather``)."""
-    return weights_from_objects(clim, georegions, table=pd.read_feather(path), zero_weight=zero_weight)
+    return weights_from_objects(clim, georegions, table=_read_feather(path), zero_weight=zero_weight)
+
+
+def _read_feather(path: str) -> pd.DataFrame:
+    """Feather V2 is the Arrow IPC file format; V1 files go through pyarrow.feather."""
+    import pyarrow as pa
+    try:
+        with pa.OSFile(path, "rb") as f:
+            return pa.ipc.open_file(f).read_all().to_pandas()
+    except pa.ArrowInvalid:
+        import warnings
+        import pyarrow.feather as feather
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", FutureWarning)
+            return feather.read_feather(path)
 
 
 def _read_table(path: str) -> pd.DataFrame:
@@ -126,7 +140,7 @@ def _read_table(path: str) -> pd.DataFrame:
     if ext in ("parquet", "pq"):
         return pd.read_parquet(path)
     if ext in ("feather", "arrow"):
-        return pd.read_feather(path)
+        return _read_feather(path)
     raise ValueError(f"unsupported table format: {path}")
 
 
