@@ -514,6 +514,9 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     fa.cube = cube; fa.C = pl->desc.n_cells;
     fa.inner_bounds = pl->d_ib.p; fa.emit = pl->d_emit.p; fa.chunks = pl->d_chunks.p;
     fa.partial = partial; fa.K = pl->K; fa.nthr = pl->nthr;
+    fa.n_tiles = (int32_t)pl->tiles;
+    fa.xcd_remap = 1;      // measured +0.2..1 % on configs[1] (profiles/r01_xcd_remap.txt): harmless, kept on
+    if (const char* e = getenv("AFHIP_XCD_REMAP")) fa.xcd_remap = atoi(e) ? 1 : 0;   // experiment knob
     for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];
     for (int i = pl->nthr; i < MAX_THR; ++i) {       // padded slots never fire
         fa.thr[i] = ThrSlot{};

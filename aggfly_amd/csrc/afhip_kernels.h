@@ -73,6 +73,7 @@ struct FusedArgs {
     const ChunkDesc* chunks;       // device [n_chunks]
     double* partial;               // device [n_slots][K][C]
     int32_t K, nthr;
+    int32_t xcd_remap, n_tiles;    // 1: give each XCD a contiguous range of cell tiles (speed only)
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
 };
@@ -220,7 +221,15 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     const int64_t C = a.C;
     const int K = a.K;
     const int lane = threadIdx.x & 63;
-    const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  With xcd_remap the
+    // tiles of one XCD form a contiguous run of cells; it changes which XCD reads what, never
+    // what is computed (bijective for any tile count).
+    int64_t tile = blockIdx.x;
+    if (a.xcd_remap) {
+        const int nt = a.n_tiles, q = nt / 8, r = nt % 8, x = (int)(blockIdx.x % 8), i = (int)(blockIdx.x / 8);
+        tile = (x < r ? (int64_t)x * (q + 1) : (int64_t)r * (q + 1) + (int64_t)(x - r) * q) + i;
+    }
+    const int64_t c0 = (tile * blockDim.x + threadIdx.x) * VEC;
     const bool active = c0 < C;
     const int64_t c_ld = active ? c0 : (C - VEC);   // clamped: inactive lanes re-read valid cells
     int64_t k_lo, k_hi;
