@@ -541,8 +541,14 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
         ca.outer[j] = pl->cols[(size_t)j].outer;
         ca.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
     }
-    dim3 grid((unsigned)P, (unsigned)((C + WG - 1) / WG));
-    hipLaunchKernelGGL(k_combine_slots, grid, dim3(WG), 0, st, ca);
+    if (P >= 4 && panel) {      // many periods: the tiled kernel writes the panel in contiguous runs
+        dim3 grid((unsigned)((P + CT_PER - 1) / CT_PER), (unsigned)((C + CT_CELLS - 1) / CT_CELLS));
+        if (grid.y > 65535) return fail(AFHIP_E_UNSUPPORTED, "too many cells for the tiled combine kernel");
+        hipLaunchKernelGGL(k_combine_slots_tiled, grid, dim3(WG), 0, st, ca);
+    } else {
+        dim3 grid((unsigned)P, (unsigned)((C + WG - 1) / WG));
+        hipLaunchKernelGGL(k_combine_slots, grid, dim3(WG), 0, st, ca);
+    }
     HIP_TRY(hipGetLastError());
     return AFHIP_OK;
 }

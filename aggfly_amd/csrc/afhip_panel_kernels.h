@@ -13,7 +13,8 @@ namespace afhip {
 // (= time) order; OUT_MEAN divides by the period's inner-group count.  A period without
 // slots is an empty resample bin -> NaN (nb_kernels.py:138-141).
 //   cells_out [K][P][C]   (optional) per-cell values, NaN kept       = aggregate_time output
-//   panel     [C][(K+1)*P] where(valid, x, 0) per column and the valid plane in column K
+//   panel     [C][P][K+1]  where(valid, x, 0) per column and the valid flag in slot K: a thread
+//             writes its (K+1) values contiguously, and the CSR kernel reads whole rows
 // ---------------------------------------------------------------------------------------
 struct CombineArgs {
     const double* partial;
@@ -56,12 +57,68 @@ __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
         }
         valid = valid && (v == v);
         if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;
-        if (a.panel) a.panel[c * Q + (int64_t)j * a.P + p] = v;   // zeroed below if invalid
+        if (a.panel) a.panel[c * Q + p * (K + 1) + j] = v;   // zeroed below if invalid
     }
     if (a.panel) {
         if (!valid)
-            for (int j = 0; j < K; ++j) a.panel[c * Q + (int64_t)j * a.P + p] = 0.0;
-        a.panel[c * Q + (int64_t)K * a.P + p] = valid ? 1.0 : 0.0;
+            for (int j = 0; j < K; ++j) a.panel[c * Q + p * (K + 1) + j] = 0.0;
+        a.panel[c * Q + p * (K + 1) + K] = valid ? 1.0 : 0.0;
+    }
+}
+
+// Tiled form for many output periods: a block owns 32 cells x 8 consecutive periods.  Phase 1
+// (thread = one (period, cell)) merges the slots exactly like k_combine_slots and parks the
+// K+1 values in LDS; phase 2 writes each cell's 8*(K+1) contiguous doubles of the panel with
+// consecutive lanes on consecutive addresses.  The one-thread-per-(p,c) kernel scatters 8-byte
+// stores 28 KB apart when P is large (2.7 ms at 251 periods x 13 columns x 51,840 cells).
+constexpr int CT_CELLS = 32, CT_PER = 8;
+
+__global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a) {
+    __shared__ double tile[CT_CELLS][CT_PER][MAX_COLS + 1];
+    const int cl = threadIdx.x % CT_CELLS, pl = threadIdx.x / CT_CELLS;
+    const int64_t c = (int64_t)blockIdx.y * CT_CELLS + cl;
+    const int64_t p0 = (int64_t)blockIdx.x * CT_PER;
+    const int64_t p = p0 + pl;
+    const int K = a.K;
+    const int64_t Q = (int64_t)(K + 1) * a.P;
+    if (c < a.C && p < a.P) {
+        const int s0 = a.slot_ptr[p], s1 = a.slot_ptr[p + 1];
+        const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
+        bool valid = true;
+        for (int j = 0; j < K; ++j) {
+            double v;
+            if (s1 == s0) {
+                v = nan64();
+            } else {
+                v = a.partial[((int64_t)s0 * K + j) * a.C + c];
+                const int o = a.outer[j];
+                for (int s = s0 + 1; s < s1; ++s) {
+                    const double x = a.partial[((int64_t)s * K + j) * a.C + c];
+                    if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                    else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                    else if (o == OUT_FIRST) { }
+                    else v += x;
+                }
+                if (o == OUT_MEAN) v = v / ng;
+                if (a.round_final[j]) v = (double)(float)v;
+            }
+            valid = valid && (v == v);
+            if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;
+            tile[cl][pl][j] = v;
+        }
+        if (!valid)
+            for (int j = 0; j < K; ++j) tile[cl][pl][j] = 0.0;
+        tile[cl][pl][K] = valid ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (!a.panel) return;
+    const int np = (int)((a.P - p0) < CT_PER ? (a.P - p0) : CT_PER);       // periods in this tile
+    const int run = np * (K + 1);                                           // contiguous doubles per cell
+    const int ncell = (int)((a.C - (int64_t)blockIdx.y * CT_CELLS) < CT_CELLS ? (a.C - (int64_t)blockIdx.y * CT_CELLS) : CT_CELLS);
+    for (int e = threadIdx.x; e < ncell * run; e += WG) {
+        const int cc = e / run, off = e - cc * run;
+        const int pp = off / (K + 1), jj = off - pp * (K + 1);
+        a.panel[((int64_t)blockIdx.y * CT_CELLS + cc) * Q + p0 * (K + 1) + off] = tile[cc][pp][jj];
     }
 }
 
@@ -109,7 +166,7 @@ __global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ ind
     out[tid] = accv;
 }
 
-// sums[R][(K+1)*P] -> num[K][R][P], den[R][P], res[K][R][P] (spatial.py:127-133)
+// sums[R][P][K+1] -> num[K][R][P], den[R][P], res[K][R][P] (spatial.py:127-133)
 __global__ __launch_bounds__(WG) void k_panel_divide(const double* __restrict__ sums, double* num,
                                                      double* den, double* res, int64_t R, int64_t P, int K) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
@@ -119,14 +176,14 @@ __global__ __launch_bounds__(WG) void k_panel_divide(const double* __restrict__ 
     const int64_t rp = tid - k * R * P;
     const int64_t r = rp / P, p = rp - r * P;
     const int64_t Q = (int64_t)(K + 1) * P;
-    const double nu = sums[r * Q + k * P + p];
-    const double de = sums[r * Q + (int64_t)K * P + p];
+    const double nu = sums[r * Q + p * (K + 1) + k];
+    const double de = sums[r * Q + p * (K + 1) + K];
     if (num) num[tid] = nu;
     if (den && k == 0) den[rp] = de;
     res[tid] = (de != 0.0) ? nu / de : nan64();
 }
 
-// x[K][C][nt] -> panel[C][(K+1)*nt] with shared validity (spatial.py:114-123); used by
+// x[K][C][nt] -> panel[C][nt][K+1] with shared validity (spatial.py:114-123); used by
 // afhip_spatial_wavg, whose input layout is the reference's (cell, time) block per name.
 __global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict__ x, double* __restrict__ panel,
                                                        int64_t C, int64_t nt, int K) {
@@ -138,9 +195,9 @@ __global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict_
     for (int j = 0; j < K; ++j) { const double v = x[((int64_t)j * C + c) * nt + t]; valid = valid && (v == v); }
     for (int j = 0; j < K; ++j) {
         const double v = x[((int64_t)j * C + c) * nt + t];
-        panel[c * Q + (int64_t)j * nt + t] = valid ? v : 0.0;
+        panel[c * Q + t * (K + 1) + j] = valid ? v : 0.0;
     }
-    panel[c * Q + (int64_t)K * nt + t] = valid ? 1.0 : 0.0;
+    panel[c * Q + t * (K + 1) + K] = valid ? 1.0 : 0.0;
 }
 
 }  // namespace afhip
