@@ -99,6 +99,8 @@ struct afhip_plan {
     const Variant* variant = nullptr;
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
+    int hb_n = 0; double hb_e0 = 0, hb_invw = 0, hb_lo = 0, hb_hi = 0;   // LDS-histogram bins
+    int hb_sorted[MAX_THR] = {0}, hb_bin_of_slot[MAX_THR] = {0};
     // device tables
     DevBuf<int64_t> d_ib, d_ob;
     DevBuf<int32_t> d_emit;
@@ -458,12 +460,34 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     bool single_level = desc->P == desc->G1;
     for (int64_t p = 0; single_level && p <= desc->P; ++p) single_level = pl->ob[(size_t)p] == p;
     for (const ColOp& c : pl->cols) single_level = single_level && c.outer == OUT_FIRST;
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level);
+    // contiguous equal-width partition?  (sorted by t0, t1[b] == t0[b+1], constant width)
+    pl->hb_n = 0;
+    if (all_bins && pl->nthr >= 4) {
+        std::vector<int> order((size_t)pl->nthr);
+        for (int i = 0; i < pl->nthr; ++i) order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return pl->thr[(size_t)x].t0 < pl->thr[(size_t)y].t0; });
+        const double e0 = pl->thr[(size_t)order[0]].t0;
+        const double w = pl->thr[(size_t)order[0]].t1 - e0;
+        bool ok = w > 0 && std::isfinite(e0) && std::isfinite(w);
+        for (int b = 0; ok && b < pl->nthr; ++b) {
+            const ThrSlot& t = pl->thr[(size_t)order[(size_t)b]];
+            ok = std::fabs(t.t0 - (e0 + b * w)) <= 1e-9 * w && std::fabs(t.t1 - (e0 + (b + 1) * w)) <= 1e-9 * w;
+            if (ok && b + 1 < pl->nthr) ok = t.t1 == pl->thr[(size_t)order[(size_t)b + 1]].t0;
+        }
+        if (ok) {
+            pl->hb_n = pl->nthr; pl->hb_e0 = e0; pl->hb_invw = 1.0 / w;
+            pl->hb_lo = e0; pl->hb_hi = pl->thr[(size_t)order[(size_t)pl->nthr - 1]].t1;
+            for (int b = 0; b < pl->nthr; ++b) { pl->hb_sorted[b] = order[(size_t)b]; pl->hb_bin_of_slot[order[(size_t)b]] = b; }
+        }
+    }
+    if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
+    const bool partition = pl->hb_n > 0 && want_pipe == 0;
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition);
     if (!v && tuning > 0) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for tuning arm %d", tuning);
     }
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
@@ -526,7 +550,12 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
-    const size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
+    size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
+    if (pl->variant->hb) {
+        fa.hb_n = pl->hb_n; fa.hb_e0 = pl->hb_e0; fa.hb_invw = pl->hb_invw; fa.hb_lo = pl->hb_lo; fa.hb_hi = pl->hb_hi;
+        for (int i = 0; i < MAX_THR; ++i) { fa.hb_sorted[i] = pl->hb_sorted[i]; fa.hb_bin_of_slot[i] = pl->hb_bin_of_slot[i]; }
+        lds = (size_t)MAX_THR * 16 + (size_t)pl->hb_n * pl->variant->vec * pl->wg * 4;
+    }
     HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;
 }

@@ -74,6 +74,11 @@ struct FusedArgs {
     double* partial;               // device [n_slots][K][C]
     int32_t K, nthr;
     int32_t xcd_remap, n_tiles;    // 1: give each XCD a contiguous range of cell tiles (speed only)
+    // LDS-histogram bins (FEAT bit 5): the threshold slots form a contiguous partition of equal
+    // width; hb_sorted[b] = slot of the b-th bin, hb_bin_of_slot = its inverse
+    double hb_e0, hb_invw, hb_lo, hb_hi;
+    int32_t hb_n, hb_pad;
+    int32_t hb_sorted[MAX_THR], hb_bin_of_slot[MAX_THR];
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
 };
@@ -215,8 +220,15 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //             v_addc per slot and element instead of fma + select + f64 add)
     // FEAT bit 4: single-level plan (every inner group is an output period, every column
     //             passes its inner value through): no outer accumulators at all
+    // FEAT bit 5: the bins are a contiguous equal-width partition -> per-lane histogram in LDS:
+    //             the bin index comes from one subtract/multiply/floor, the (lo, hi) edges of that
+    //             bin are looked up in an LDS table and compared strictly like the reference, and
+    //             one ds_add bumps the lane's private counter.  ~10 VALU + 2 LDS ops per element
+    //             instead of 3 VALU per bin.
     constexpr bool TKI = (FEAT & 8) != 0;
     constexpr bool SL = (FEAT & 16) != 0;
+    constexpr bool HB = (FEAT & 32) != 0;
+    static_assert(!HB || (TKI && PIPE == 0), "the LDS histogram replaces the integer bin counters of the direct-load path");
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
     const int64_t C = a.C;
     const int K = a.K;
@@ -250,14 +262,29 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     int cnt[VEC];
     unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
     double acc[(NTHR > 0 && !TKI) ? NTHR : 1][VEC];
-    int cthr[(NTHR > 0 && TKI) ? NTHR : 1][VEC];
+    int cthr[(NTHR > 0 && TKI && !HB) ? NTHR : 1][VEC];
     double os[SL ? 1 : KMAX][VEC];
 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
-        for (int j = 0; j < NTHR; ++j) { if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
+        for (int j = 0; j < NTHR; ++j) { if (HB) {} else if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
+    }
+    // LDS-histogram state: edge table [hb_n] of (lo, hi) pairs, then counters [hb_n * VEC][blockDim]
+    typedef double edge2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynlds[];
+    edge2* etab = (edge2*)dynlds;
+    int* hcnt = (int*)(dynlds + MAX_THR * sizeof(edge2));
+    const int bd = blockDim.x, tid = threadIdx.x;
+    if constexpr (HB) {
+        if (tid < a.hb_n) {
+            const int sl_ = a.hb_sorted[tid];
+            edge2 e; e.x = a.thr[sl_].t0; e.y = a.thr[sl_].t1;
+            etab[tid] = e;
+        }
+        for (int b = 0; b < a.hb_n * VEC; ++b) hcnt[b * bd + tid] = 0;
+        __syncthreads();
     }
     auto reset_outer = [&]() {
         if (SL) return;
@@ -293,8 +320,26 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 mn[i] = (v < mn[i]) ? v : mn[i];
                 mx[i] = (v > mx[i]) ? v : mx[i];
             }
+            if constexpr (HB) {
+                int idx = (int)floor((v - a.hb_e0) * a.hb_invw);
+                idx = idx < 0 ? 0 : (idx >= a.hb_n ? a.hb_n - 1 : idx);
+                edge2 e = etab[idx];
+                bool m = (v > e.x) && (v < e.y);                          // strict, NaN -> false
+                // a value within a few ulp of an edge can land in the neighbouring slot of the
+                // multiply/floor: repair it against the true edges (wave-uniform, almost never taken)
+                const bool stray = !m && (v > a.hb_lo) && (v < a.hb_hi);
+                if (__builtin_amdgcn_ballot_w64(stray) != 0ull) {
+                    if (stray) {
+                        int i2 = (v >= e.y) ? idx + 1 : idx - 1;
+                        i2 = i2 < 0 ? 0 : (i2 >= a.hb_n ? a.hb_n - 1 : i2);
+                        const edge2 e2 = etab[i2];
+                        if ((v > e2.x) && (v < e2.y)) { idx = i2; m = true; }
+                    }
+                }
+                if (m) hcnt[(idx * VEC + i) * bd + tid] += 1;
+            }
 #pragma unroll
-            for (int j = 0; j < NTHR; ++j) {
+            for (int j = 0; j < (HB ? 0 : NTHR); ++j) {
                 bool m;                                                   // strict, NaN -> false
                 if constexpr (sizeof(TIn) == 4) m = (vr > a.thr[j].t0f) && (vr < a.thr[j].t1f);
                 else m = (v > a.thr[j].t0) && (v < a.thr[j].t1);
@@ -340,7 +385,8 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                         for (int q = 0; q < NTHR; ++q)
                             if (q == co.src_idx) {
-                                t = TKI ? (double)cthr[q][i] : acc[q][i];
+                                if constexpr (HB) t = (double)hcnt[(a.hb_bin_of_slot[q] * VEC + i) * bd + tid];
+                                else t = TKI ? (double)cthr[q][i] : acc[q][i];
                                 poisons = a.thr[q].nan_poisons != 0;
                             }
                         x = (empty || (poisons && hasnan[i])) ? nan64() : t;
@@ -395,7 +441,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         for (int i = 0; i < VEC; ++i) {
             s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
 #pragma unroll
-            for (int j = 0; j < NTHR; ++j) { if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
+            for (int j = 0; j < NTHR; ++j) { if (HB) {} else if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
+        }
+        if constexpr (HB) {
+            for (int b = 0; b < a.hb_n * VEC; ++b) hcnt[b * bd + tid] = 0;
         }
         if constexpr (SL) {
             ++slot;
@@ -442,7 +491,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     } else {
         // ---- LDS-DMA ring, wave-private ----
-        extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // waves * DEPTH KiB
+        unsigned char* ring = dynlds;                                         // waves * DEPTH KiB
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)ring;
         const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)wave * (DEPTH * 1024u));

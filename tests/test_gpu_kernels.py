@@ -258,3 +258,46 @@ def test_edge_shapes(torch_cuda):
         hip.CSR([0], [ny * nx], [1.0], 1, ny * nx)            # column out of range is refused before upload
     with pytest.raises(ValueError):
         hip.FusedPlan(T, ny * nx, hip.F64, np.array([0, 30, 20, T]), np.array([0, 3]), [dict(inner="mean")])   # non-monotone bounds
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dtype):
+    """Contiguous equal-width bins take the per-lane LDS-histogram path.  Strict compares must
+    survive it: values exactly ON an edge fall in no bin, values one ulp to either side fall in
+    the neighbouring bins, NaN/inf fall nowhere — exactly as the reference's compare chain."""
+    from aggfly_amd import hip
+    T, ny, nx = 365 * 2, 6, 10
+    rng = np.random.default_rng(77)
+    cube = rng.normal(14, 12, (T, ny, nx)).astype(dtype)
+    edges = np.arange(-20, 50, 5.0)
+    flat = cube.reshape(-1)
+    pick = rng.choice(flat.size, 600, replace=False)
+    e = rng.choice(edges, 600).astype(dtype)
+    flat[pick[:200]] = e[:200]                                           # exactly on an edge
+    flat[pick[200:400]] = np.nextafter(e[200:400], dtype(np.inf))        # one ulp above
+    flat[pick[400:560]] = np.nextafter(e[400:560], dtype(-np.inf))       # one ulp below
+    flat[pick[560:580]] = np.nan
+    flat[pick[580:590]] = np.inf
+    flat[pick[590:600]] = -np.inf
+    bounds = np.array([0, 365, 365, T], dtype=np.int64)                  # an empty group in the middle
+    dda = [[edges[i], edges[i + 1], 0] for i in range(13)]
+    d = torch_cuda.from_numpy(cube).cuda()
+    want = cport.block_bins(cube, bounds, dda)
+    np.testing.assert_array_equal(hip.group_bins(d, bounds, dda).cpu().numpy(), want)
+    cols = [dict(inner="bins", inner_args=r) for r in dda]
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    plan = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), cols)
+    assert "_hist" in plan.describe(), plan.describe()
+    got = plan.run_temporal(d).cpu().numpy()                             # [D, G, cells]
+    np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want.reshape(3, -1, 13))
+    # shuffled slot order and a two-level use (daily mean + annual bins on raw hourly-like groups)
+    perm = rng.permutation(13)
+    plan2 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [cols[i] for i in perm] + [dict(inner="mean")])
+    got2 = plan2.run_temporal(d).cpu().numpy()
+    np.testing.assert_array_equal(got2[:13], got[perm])
+    # unequal widths are not a histogram: integer-counter path, same numbers
+    odd = [[-20, 0, 0], [0, 7.5, 0], [7.5, 10, 0], [10, 30, 0], [30, 99, 0]]
+    plan3 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [dict(inner="bins", inner_args=r) for r in odd])
+    assert "_hist" not in plan3.describe() and "_ibins" in plan3.describe()
+    np.testing.assert_array_equal(np.transpose(plan3.run_temporal(d).cpu().numpy(), (1, 2, 0)),
+                                  cport.block_bins(cube, bounds, odd).reshape(3, -1, 5))
