@@ -94,6 +94,7 @@ struct afhip_plan {
     std::vector<ColOp> cols;
     std::vector<ChunkDesc> chunks;
     std::vector<int32_t> emit;
+    std::vector<int64_t> gtab;            // [(end step) << 1 | emit] per inner group, padded by one
     std::vector<int32_t> slot_ptr;        // [P+1]
     int64_t n_slots = 0;
     const Variant* variant = nullptr;
@@ -103,7 +104,7 @@ struct afhip_plan {
     int hb_sorted[MAX_THR] = {0}, hb_bin_of_slot[MAX_THR] = {0};
     // device tables
     DevBuf<int64_t> d_ib, d_ob;
-    DevBuf<int32_t> d_emit;
+    DevBuf<int64_t> d_gtab;
     DevBuf<ChunkDesc> d_chunks;
     DevBuf<int32_t> d_slot_ptr;
     // workspace
@@ -495,7 +496,9 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->variant = v;
     if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
 
-    if ((rc = pl->d_ib.upload(pl->ib)) || (rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_emit.upload(pl->emit)) ||
+    pl->gtab.assign((size_t)desc->G1 + 2, 0);
+    for (int64_t g = 0; g < desc->G1; ++g) pl->gtab[(size_t)g] = (pl->ib[(size_t)g + 1] << 1) | (pl->emit[(size_t)g] ? 1 : 0);
+    if ((rc = pl->d_ib.upload(pl->ib)) || (rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_gtab.upload(pl->gtab)) ||
         (rc = pl->d_chunks.upload(pl->chunks)) || (rc = pl->d_slot_ptr.upload(pl->slot_ptr))) {
         delete pl;
         return rc;
@@ -536,7 +539,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     if (pl->chunks.empty()) return AFHIP_OK;
     FusedArgs fa{};
     fa.cube = cube; fa.C = pl->desc.n_cells;
-    fa.inner_bounds = pl->d_ib.p; fa.emit = pl->d_emit.p; fa.chunks = pl->d_chunks.p;
+    fa.gtab = pl->d_gtab.p; fa.chunks = pl->d_chunks.p;
     fa.partial = partial; fa.K = pl->K; fa.nthr = pl->nthr;
     fa.n_tiles = (int32_t)pl->tiles;
     fa.xcd_remap = 1;      // measured +0.2..1 % on configs[1] (profiles/r01_xcd_remap.txt): harmless, kept on

@@ -68,8 +68,7 @@ struct ChunkDesc {
 struct FusedArgs {
     const void* cube;
     int64_t C;                     // cells
-    const int64_t* inner_bounds;   // device [G1+1]
-    const int32_t* emit;           // device [G1]: 1 = write a slot after this inner group
+    const int64_t* gtab;           // device [G1+1]: (end step of inner group g) << 1 | (emit a slot after g)
     const ChunkDesc* chunks;       // device [n_chunks]
     double* partial;               // device [n_slots][K][C]
     int32_t K, nthr;
@@ -110,34 +109,72 @@ __device__ __forceinline__ double powi_dd(double x, int e) {
     return e < 0 ? 1.0 / r : r;
 }
 
+// asin / acos to ~2e-15 relative (checked against numpy on 2e6 points): on
+// |x| <= 1/2, asin(x) = x + x^3 p(x^2) with a degree-10 Chebyshev-fitted p; beyond, the
+// half-angle identity asin(x) = pi/2 - 2 asin(sqrt((1-x)/2)).  One sqrt + 11 FMAs instead of
+// the library's ~70-instruction routines: sine_dd needs one of these per threshold per
+// cell-day and was bound by them.  |x| > 1 yields NaN like the library functions.
+__device__ __forceinline__ double asin_core(double s, double t) {
+    double p = 2.78600666767379636e-02;
+    p = __fma_rn(p, t, -6.80823893868847015e-03);
+    p = __fma_rn(p, t, 1.54379220773654957e-02);
+    p = __fma_rn(p, t, 1.02917232813431302e-02);
+    p = __fma_rn(p, t, 1.41405795351722628e-02);
+    p = __fma_rn(p, t, 1.73372313610090298e-02);
+    p = __fma_rn(p, t, 2.23730075566984689e-02);
+    p = __fma_rn(p, t, 3.03819175771733174e-02);
+    p = __fma_rn(p, t, 4.46428575770584091e-02);
+    p = __fma_rn(p, t, 7.49999999972744968e-02);
+    p = __fma_rn(p, t, 1.66666666666669405e-01);
+    return __fma_rn(s * t, p, s);                    // asin(s) for 0 <= s <= 1/2, t = s^2
+}
+__device__ __forceinline__ double acos_fast(double x) {
+    const double HALF_PI = 1.57079632679489661923, PI = 3.14159265358979323846;
+    const double ax = fabs(x);
+    const bool small = ax <= 0.5;
+    const double t = small ? ax * ax : (1.0 - ax) * 0.5;
+    const double s = small ? ax : sqrt(t);
+    const double r = asin_core(s, t);
+    return small ? HALF_PI - copysign(r, x) : (x > 0.0 ? 2.0 * r : PI - 2.0 * r);
+}
+__device__ __forceinline__ double asin_fast(double x) {
+    const double HALF_PI = 1.57079632679489661923;
+    const double ax = fabs(x);
+    const bool small = ax <= 0.5;
+    const double t = small ? ax * ax : (1.0 - ax) * 0.5;
+    const double s = small ? ax : sqrt(t);
+    const double r = asin_core(s, t);
+    return copysign(small ? r : HALF_PI - 2.0 * r, x);
+}
+
 // Single-sine degree-day "parts" (nb_kernels.py:224-249), with the reference's nested
 // transcendentals folded by identities that hold on the branch's domain:
 //   cooling: a = acos(z), |z| <= 1:  sin(a) = sqrt(1 - z^2)
 //   heating: at = atan(r / sqrt(1 - r^2)) = asin(r),  cos(at) = sqrt(1 - r^2)
-// (|r| > 1 gives NaN in both forms, as in the reference).  One transcendental per part
-// instead of two; results agree with the reference's form to ~1e-15, inside the 1e-10
-// contract for sine_dd.
+// (|r| > 1 gives NaN in both forms, as in the reference), and the divisions by pi written as
+// multiplications by 1/pi.  Results agree with the reference's form to ~1e-15, inside the
+// 1e-10 contract for sine_dd.
 __device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg) {
-    const double PI = 3.14159265358979323846;
+    const double INV_PI = 0.31830988618379067154;
     if (thr <= tmin) return tavg - thr;
     if (thr < tmax && tmin < thr) {
         const double rng = tmax - tmin;
         const double z = (2.0 * thr - tmax - tmin) / rng;
-        const double a = acos(z);
+        const double a = acos_fast(z);
         const double sa = sqrt((1.0 - z) * (1.0 + z));
-        return ((tavg - thr) * a + rng * sa / 2.0) / PI;
+        return ((tavg - thr) * a + rng * sa * 0.5) * INV_PI;
     }
     return 0.0;
 }
 __device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg) {
-    const double PI = 3.14159265358979323846;
+    const double INV_PI = 0.31830988618379067154, HALF_PI = 1.57079632679489661923;
     if (thr >= tmax) return thr - tavg;
     if (thr < tmax && tmin < thr) {
-        const double alpha = (tmax - tmin) / 2.0;
+        const double alpha = (tmax - tmin) * 0.5;
         const double r = (thr - tavg) / alpha;
-        const double at = asin(r);
+        const double at = asin_fast(r);
         const double ca = sqrt((1.0 - r) * (1.0 + r));
-        return (1.0 / PI) * ((thr - tavg) * (at + PI / 2.0) + alpha * ca);
+        return INV_PI * ((thr - tavg) * (at + HALF_PI) + alpha * ca);
     }
     return 0.0;
 }
@@ -354,7 +391,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----
-    auto group_end = [&](int g, int nsteps) {
+    auto group_end = [&](bool emit_slot, int nsteps) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
         bool hasnan[VEC];
@@ -448,7 +485,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
         if constexpr (SL) {
             ++slot;
-        } else if (ld_uniform(&a.emit[g])) {
+        } else if (emit_slot) {
             if (active) {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
@@ -469,8 +506,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 
     if constexpr (PIPE == 0) {
         const TIn* p = cube;
+        // group table word for g is fetched one group ahead: its scalar-load latency hides behind
+        // the previous group's work (matters for 1-2 step groups: daily data, tmin/tmax pairs)
+        int64_t w_next = ld_uniform(&a.gtab[g]);
         while (g < g_hi) {
-            const int gend = (int)(ld_uniform(&a.inner_bounds[g + 1]) - k_lo);
+            const int64_t w = w_next;
+            w_next = ld_uniform(&a.gtab[g + 1]);                 // table is padded by one entry
+            const int gend = (int)((w >> 1) - k_lo);
             const int gbeg = kk;
             // DEPTH rows in flight per lane inside a group
             for (; kk + DEPTH <= gend; kk += DEPTH) {
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 p += C;
                 consume(r0);
             }
-            group_end(g, gend - gbeg);
+            group_end((w & 1) != 0, gend - gbeg);
             ++g;
         }
     } else {
@@ -509,8 +551,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) issue(d, d);
         }
+        int64_t w_next = ld_uniform(&a.gtab[g]);
         while (g < g_hi) {
-            const int gend = (int)(ld_uniform(&a.inner_bounds[g + 1]) - k_lo);
+            const int64_t w = w_next;
+            w_next = ld_uniform(&a.gtab[g + 1]);
+            const int gend = (int)((w >> 1) - k_lo);
             const int gbeg = kk;
             for (; kk < gend; ++kk) {
                 u32x4 raw;
@@ -527,7 +572,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 __builtin_memcpy(&rv, &raw, 16);
                 consume(rv);
             }
-            group_end(g, gend - gbeg);
+            group_end((w & 1) != 0, gend - gbeg);
             ++g;
         }
         // no DMA may still target this workgroup's LDS when the wave retires
