@@ -574,11 +574,11 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
         ca.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
     }
     if (P >= 4 && panel) {      // many periods: the tiled kernel writes the panel in contiguous runs
-        dim3 grid((unsigned)((P + CT_PER - 1) / CT_PER), (unsigned)((C + CT_CELLS - 1) / CT_CELLS));
-        if (grid.y > 65535) return fail(AFHIP_E_UNSUPPORTED, "too many cells for the tiled combine kernel");
+        dim3 grid((unsigned)((C + CT_CELLS - 1) / CT_CELLS), (unsigned)((P + CT_PER - 1) / CT_PER));
+        if (grid.y > 65535) return fail(AFHIP_E_UNSUPPORTED, "more than 524,280 output periods in one call");
         hipLaunchKernelGGL(k_combine_slots_tiled, grid, dim3(WG), 0, st, ca);
     } else {
-        dim3 grid((unsigned)P, (unsigned)((C + WG - 1) / WG));
+        dim3 grid((unsigned)((C + WG - 1) / WG), (unsigned)std::min<int64_t>(P, 65535));   // strides over periods
         hipLaunchKernelGGL(k_combine_slots, grid, dim3(WG), 0, st, ca);
     }
     HIP_TRY(hipGetLastError());
@@ -712,7 +712,7 @@ static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells
     if ((rc = ensure_ws(pl, pl->ws_partial, nullptr, &base))) { delete pl; return rc; }
     double* partial = (double*)base;
     if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
-    dim3 grid((unsigned)G, (unsigned)((n_cells + WG - 1) / WG));
+    dim3 grid((unsigned)((n_cells + WG - 1) / WG), (unsigned)std::min<int64_t>(G, 65535));
     if (dtype == AFHIP_F32)
         hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D);
     else

@@ -29,40 +29,40 @@ struct CombineArgs {
 };
 
 __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
-    const int64_t c = (int64_t)blockIdx.y * WG + threadIdx.x;   // grid = (periods, cell tiles)
-    const int64_t p = blockIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * WG + threadIdx.x;   // grid = (cell tiles, period lanes)
     if (c >= a.C) return;
-    const int s0 = a.slot_ptr[p], s1 = a.slot_ptr[p + 1];
-    const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
     const int K = a.K;
     const int64_t Q = (int64_t)(K + 1) * a.P;
-    bool valid = true;
-    // pass 1: merged values -> cells_out (or recomputed in pass 2 when it is absent)
-    for (int j = 0; j < K; ++j) {
-        double v;
-        if (s1 == s0) {
-            v = nan64();
-        } else {
-            v = a.partial[((int64_t)s0 * K + j) * a.C + c];
-            const int o = a.outer[j];
-            for (int s = s0 + 1; s < s1; ++s) {
-                const double x = a.partial[((int64_t)s * K + j) * a.C + c];
-                if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
-                else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
-                else if (o == OUT_FIRST) { /* a period is never split for OUT_FIRST */ }
-                else v += x;
+    for (int64_t p = blockIdx.y; p < a.P; p += gridDim.y) {
+        const int s0 = a.slot_ptr[p], s1 = a.slot_ptr[p + 1];
+        const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
+        bool valid = true;
+        for (int j = 0; j < K; ++j) {
+            double v;
+            if (s1 == s0) {
+                v = nan64();
+            } else {
+                v = a.partial[((int64_t)s0 * K + j) * a.C + c];
+                const int o = a.outer[j];
+                for (int s = s0 + 1; s < s1; ++s) {
+                    const double x = a.partial[((int64_t)s * K + j) * a.C + c];
+                    if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                    else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
+                    else if (o == OUT_FIRST) { /* a period is never split for OUT_FIRST */ }
+                    else v += x;
+                }
+                if (o == OUT_MEAN) v = v / ng;
+                if (a.round_final[j]) v = (double)(float)v;
             }
-            if (o == OUT_MEAN) v = v / ng;
-            if (a.round_final[j]) v = (double)(float)v;
+            valid = valid && (v == v);
+            if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;
+            if (a.panel) a.panel[c * Q + p * (K + 1) + j] = v;   // zeroed below if invalid
         }
-        valid = valid && (v == v);
-        if (a.cells_out) a.cells_out[((int64_t)j * a.P + p) * a.C + c] = v;
-        if (a.panel) a.panel[c * Q + p * (K + 1) + j] = v;   // zeroed below if invalid
-    }
-    if (a.panel) {
-        if (!valid)
-            for (int j = 0; j < K; ++j) a.panel[c * Q + p * (K + 1) + j] = 0.0;
-        a.panel[c * Q + p * (K + 1) + K] = valid ? 1.0 : 0.0;
+        if (a.panel) {
+            if (!valid)
+                for (int j = 0; j < K; ++j) a.panel[c * Q + p * (K + 1) + j] = 0.0;
+            a.panel[c * Q + p * (K + 1) + K] = valid ? 1.0 : 0.0;
+        }
     }
 }
 
@@ -76,8 +76,9 @@ constexpr int CT_CELLS = 32, CT_PER = 8;
 __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a) {
     __shared__ double tile[CT_CELLS][CT_PER][MAX_COLS + 1];
     const int cl = threadIdx.x % CT_CELLS, pl = threadIdx.x / CT_CELLS;
-    const int64_t c = (int64_t)blockIdx.y * CT_CELLS + cl;
-    const int64_t p0 = (int64_t)blockIdx.x * CT_PER;
+    const int64_t cbase = (int64_t)blockIdx.x * CT_CELLS;     // grid = (cell tiles, period tiles)
+    const int64_t c = cbase + cl;
+    const int64_t p0 = (int64_t)blockIdx.y * CT_PER;
     const int64_t p = p0 + pl;
     const int K = a.K;
     const int64_t Q = (int64_t)(K + 1) * a.P;
@@ -114,11 +115,11 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
     if (!a.panel) return;
     const int np = (int)((a.P - p0) < CT_PER ? (a.P - p0) : CT_PER);       // periods in this tile
     const int run = np * (K + 1);                                           // contiguous doubles per cell
-    const int ncell = (int)((a.C - (int64_t)blockIdx.y * CT_CELLS) < CT_CELLS ? (a.C - (int64_t)blockIdx.y * CT_CELLS) : CT_CELLS);
+    const int ncell = (int)((a.C - cbase) < CT_CELLS ? (a.C - cbase) : CT_CELLS);
     for (int e = threadIdx.x; e < ncell * run; e += WG) {
         const int cc = e / run, off = e - cc * run;
         const int pp = off / (K + 1), jj = off - pp * (K + 1);
-        a.panel[((int64_t)blockIdx.y * CT_CELLS + cc) * Q + p0 * (K + 1) + off] = tile[cc][pp][jj];
+        a.panel[(cbase + cc) * Q + p0 * (K + 1) + off] = tile[cc][pp][jj];
     }
 }
 
@@ -127,13 +128,14 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
 template <typename TOut>
 __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, const int32_t* slot_ptr,
                                                        TOut* out, int64_t C, int64_t G, int D) {
-    const int64_t c = (int64_t)blockIdx.y * WG + threadIdx.x;   // grid = (groups, cell tiles)
-    const int64_t g = blockIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * WG + threadIdx.x;   // grid = (cell tiles, group lanes)
     if (c >= C) return;
-    const int s0 = slot_ptr[g], s1 = slot_ptr[g + 1];
-    for (int d = 0; d < D; ++d) {
-        const double v = (s1 == s0) ? nan64() : partial[((int64_t)s0 * D + d) * C + c];
-        out[(g * C + c) * D + d] = (TOut)v;
+    for (int64_t g = blockIdx.y; g < G; g += gridDim.y) {
+        const int s0 = slot_ptr[g], s1 = slot_ptr[g + 1];
+        for (int d = 0; d < D; ++d) {
+            const double v = (s1 == s0) ? nan64() : partial[((int64_t)s0 * D + d) * C + c];
+            out[(g * C + c) * D + d] = (TOut)v;
+        }
     }
 }
 

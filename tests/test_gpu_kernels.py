@@ -301,3 +301,33 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     assert "_hist" not in plan3.describe() and "_ibins" in plan3.describe()
     np.testing.assert_array_equal(np.transpose(plan3.run_temporal(d).cpu().numpy(), (1, 2, 0)),
                                   cport.block_bins(cube, bounds, odd).reshape(3, -1, 5))
+
+
+def test_many_periods_and_grid_limits(torch_cuda):
+    """More output periods than a grid dimension holds (daily single-level output of a long
+    series: 70,000 periods) through both the cells-only and the panel path."""
+    from aggfly_amd import hip
+    T, ny, nx = 70000, 2, 4
+    rng = np.random.default_rng(5)
+    cube = rng.normal(10, 5, (T, ny, nx)).astype(np.float32)
+    cube[rng.integers(0, T, 50), 0, 0] = np.nan
+    d = torch_cuda.from_numpy(cube).cuda()
+    ib = np.arange(T + 1, dtype=np.int64)
+    want = cport.block_stat(cube, ib, "max")
+    np.testing.assert_array_equal(hip.group_stat(d, ib, "max").cpu().numpy(), want)
+    plan = hip.FusedPlan(T, ny * nx, hip.F32, ib, ib, [dict(inner="max"), dict(inner="dd", inner_args=(5, 15, 0))])
+    cells = plan.run_temporal(d).cpu().numpy()
+    np.testing.assert_array_equal(cells[0].reshape(T, ny, nx), want.astype(np.float64))
+    csr = hip.CSR([0, 0, 1, 1, 1], [0, 1, 2, 5, 7], [0.5, 0.5, 0.2, 0.3, 0.5], 2, ny * nx)
+    out = plan.run(d, csr)
+    flat = want.astype(np.float64).reshape(T, -1)
+    dd = cport.block_dd(cube, ib, [5, 15, 0])[..., 0].astype(np.float64).reshape(T, -1)
+    valid = ~(np.isnan(flat) | np.isnan(dd))
+    for r, (cs, ws) in enumerate((([0, 1], [0.5, 0.5]), ([2, 5, 7], [0.2, 0.3, 0.5]))):
+        den = sum(w * valid[:, c] for c, w in zip(cs, ws))
+        num = np.zeros(T)
+        for c, w in zip(cs, ws):
+            num = num + w * np.where(valid[:, c], flat[:, c], 0.0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want_r = np.where(den != 0, num / den, np.nan)
+        np.testing.assert_array_equal(out["res"][0, r].cpu().numpy(), want_r)
