@@ -320,7 +320,7 @@ static int build_chunks(afhip_plan* pl, int vec) {
     pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count()) ? 64 : WG;
     if (const char* e = getenv("AFHIP_FORCE_WG")) { int w = atoi(e); if (w == 64 || w == 128 || w == 256) pl->wg = w; }   // experiment knob
     pl->tiles = (C + (int64_t)pl->wg * vec - 1) / ((int64_t)pl->wg * vec);
-    // aim for ~16 workgroups per CU over the whole grid, never streaming fewer than 64 steps
+    // aim for ~4 workgroups per CU over the whole grid, never streaming fewer than 64 steps
     int per_cu = 4;      // measured (profiles/r01_sweep_chunks.txt): the fewer time chunks the better once every CU has ~4 workgroups
     if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
     const int64_t want_wgs = (int64_t)cu_count() * per_cu * (WG / pl->wg);
