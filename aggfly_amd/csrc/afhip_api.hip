@@ -103,7 +103,7 @@ struct afhip_plan {
     int hb_n = 0; double hb_e0 = 0, hb_invw = 0, hb_lo = 0, hb_hi = 0;   // LDS-histogram bins
     int hb_sorted[MAX_THR] = {0}, hb_bin_of_slot[MAX_THR] = {0};
     // device tables
-    DevBuf<int64_t> d_ib, d_ob;
+    DevBuf<int64_t> d_ob;
     DevBuf<int64_t> d_gtab;
     DevBuf<ChunkDesc> d_chunks;
     DevBuf<int32_t> d_slot_ptr;
@@ -498,7 +498,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
 
     pl->gtab.assign((size_t)desc->G1 + 2, 0);
     for (int64_t g = 0; g < desc->G1; ++g) pl->gtab[(size_t)g] = (pl->ib[(size_t)g + 1] << 1) | (pl->emit[(size_t)g] ? 1 : 0);
-    if ((rc = pl->d_ib.upload(pl->ib)) || (rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_gtab.upload(pl->gtab)) ||
+    if ((rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_gtab.upload(pl->gtab)) ||
         (rc = pl->d_chunks.upload(pl->chunks)) || (rc = pl->d_slot_ptr.upload(pl->slot_ptr))) {
         delete pl;
         return rc;

@@ -350,8 +350,9 @@ class FusedPlan:
         _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), None, _stream_ptr()))
         return cells
 
-    def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None):
-        """-> dict(num[K,R,P], den[R,P], res[K,R,P], cells?, kernel_ms?)."""
+    def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None, workspace=None):
+        """-> dict(num[K,R,P], den[R,P], res[K,R,P], cells?, kernel_ms?).  ``workspace``: an optional
+        caller-owned uint8 HBM tensor of at least ``workspace_bytes()`` (else the plan owns one)."""
         torch = _torch()
         cube = self._check_cube(cube)
         dev = cube.device
@@ -363,8 +364,13 @@ class FusedPlan:
                 out["cells"] = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=dev)
         ms = (C.c_float * 2)() if timed else None
         cells_ptr = out["cells"].data_ptr() if "cells" in out else None
+        ws_ptr = None
+        if workspace is not None:
+            if workspace.numel() * workspace.element_size() < self.workspace_bytes() or not workspace.is_cuda:
+                raise ValueError(f"workspace must be an HBM tensor of >= {self.workspace_bytes()} bytes")
+            ws_ptr = workspace.data_ptr()
         _check(load().afhip_plan_run(self._h, cube.data_ptr(), csr.handle, out["num"].data_ptr(),
-                                     out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, None,
+                                     out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, ws_ptr,
                                      _stream_ptr(), ms))
         if timed:
             out["kernel_ms"] = (float(ms[0]), float(ms[1]))

@@ -331,3 +331,28 @@ def test_many_periods_and_grid_limits(torch_cuda):
         with np.errstate(invalid="ignore", divide="ignore"):
             want_r = np.where(den != 0, num / den, np.nan)
         np.testing.assert_array_equal(out["res"][0, r].cpu().numpy(), want_r)
+
+
+def test_caller_workspace_and_side_stream(torch_cuda):
+    """The ABI's ownership rules: work is enqueued on the caller's stream and may use a
+    caller-owned workspace; results equal the plan-owned / default-stream run."""
+    from aggfly_amd import hip
+    torch = torch_cuda
+    T, ny, nx = 24 * 50, 10, 16
+    cube = torch.from_numpy(_cube(T, ny, nx, np.float64, seed=17)).cuda()
+    ib = synth.hourly_bounds(T)
+    ob = np.array([0, 20, 50], dtype=np.int64)
+    cols = [dict(inner="mean", outer="sum"), dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+    tab = synth.weights_table(ny, nx, 6, seed=18)
+    csr = hip.CSR(tab.index_right.to_numpy(), tab.cell_id.to_numpy(), tab.weight.to_numpy(), int(tab.index_right.max()) + 1, ny * nx)
+    plan = hip.FusedPlan(T, ny * nx, hip.F64, ib, ob, cols)
+    ref = plan.run(cube, csr)["res"].clone()
+    ws = torch.empty(plan.workspace_bytes(), dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = plan.run(cube, csr, workspace=ws)["res"]
+    side.synchronize()
+    assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+    with pytest.raises(ValueError, match="workspace"):
+        plan.run(cube, csr, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
