@@ -176,16 +176,31 @@ def _staged_name(dataset: Dataset, key: str, steps, engine: str) -> Dict[str, Da
 
 
 def _lower_all(aggregator_dict):
-    """-> (ordered keys, {key: ColumnProg} for fused names, [names that must run staged])."""
-    fused_cols, staged, order = [], [], []
+    """-> (order, fused ColumnProgs, names that must run staged).
+
+    Output keys follow dict semantics like the reference (`aggregate.py:160-161`:
+    ``out_dict = out_dict | dict(zip(keys, data))``): when two columns produce the same key —
+    e.g. two ``ddargs`` rows with equal bounds but different flags — the LATER column wins and
+    keeps the FIRST one's position; the shadowed column is never computed and takes no part in
+    the shared validity mask."""
+    lowered, staged = [], []
     for name, steps in aggregator_dict.items():
         cols, fusable = eng.lower_spec(name, steps)
-        order.append((name, [c.key for c in cols], fusable))
-        if fusable:
-            fused_cols.extend(cols)
-        else:
+        lowered.append((name, cols, fusable))
+        if not fusable:
             staged.append(name)
-    return order, fused_cols, staged
+    winner = {}                                   # key -> (name, index in that name's column list)
+    for name, cols, _ in lowered:
+        for i, c in enumerate(cols):
+            winner[c.key] = (name, i)             # later overrides, first position kept by dict order
+    fused_cols = []
+    for name, cols, fusable in lowered:
+        if fusable:
+            fused_cols.extend(c for i, c in enumerate(cols) if winner[c.key] == (name, i))
+    order = [(name, [k for k, (n, _) in winner.items() if n == name], fusable) for name, _, fusable in lowered]
+    # keys in global first-insertion order
+    order_keys = list(winner)
+    return order, fused_cols, staged, order_keys
 
 
 def aggregate_time(dataset: Dataset, weights=None, aggregator_dict=None, engine: str = "auto", **kwargs) -> Dict[str, Dataset]:
@@ -196,7 +211,7 @@ def aggregate_time(dataset: Dataset, weights=None, aggregator_dict=None, engine:
             raise ValueError("No arguments provided.")
         aggregator_dict = kwargs
     tindex = _labels_of(dataset)
-    order, fused_cols, staged = _lower_all(aggregator_dict)
+    order, fused_cols, staged, order_keys = _lower_all(aggregator_dict)
     _guard_week(fused_cols, tindex)
     results: Dict[str, Dataset] = {}
     if fused_cols:
@@ -205,13 +220,12 @@ def aggregate_time(dataset: Dataset, weights=None, aggregator_dict=None, engine:
             for pr in eng.run_fused_pass(cube, cols, ib, ob):
                 for j, k in enumerate(pr.keys):
                     results[k] = _dataset_from_cells(dataset, pr.cells[j], labels, dataset.history)
+    owner = {k: name for name, keys, _ in order for k in keys}
     for name in staged:
-        results.update(_staged_name(dataset, name, aggregator_dict[name], engine))
-    out = {}
-    for name, keys, _ in order:        # the reference's insertion order (`aggregate.py:160-161`)
-        for k in keys:
-            out[k] = results[k]
-    return out
+        for k, v in _staged_name(dataset, name, aggregator_dict[name], engine).items():
+            if owner.get(k) == name:
+                results[k] = v
+    return {k: results[k] for k in order_keys}
 
 
 def _guard_week(cols, tindex):
@@ -326,9 +340,8 @@ def panel_arrays(weights, dataset: Dataset, aggregator_dict, engine: str = "auto
     import torch
     resolve_engine(engine)
     tindex = _labels_of(dataset)
-    order, fused_cols, staged = _lower_all(aggregator_dict)
+    order, fused_cols, staged, names = _lower_all(aggregator_dict)
     _guard_week(fused_cols, tindex)
-    names = [k for _, keys, _ in order for k in keys]
     csr, region_ids = eng.get_csr(weights, dataset)
     if not staged:
         groups = eng.plan_groups(tindex, fused_cols)

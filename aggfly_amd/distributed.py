@@ -132,8 +132,7 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
         _, labels = resample_groups(tindex, freq)
         local = dataset.deepcopy()
         local.da = dataset.da.isel(time=slice(k_lo, k_hi))
-        order, fused_cols, _ = agg._lower_all(aggregator_dict)
-        names = [k for _, keys, _ in order for k in keys]
+        _, fused_cols, _, names = agg._lower_all(aggregator_dict)
         csr, region_ids = eng.get_csr(weights, dataset)
         if k_hi > k_lo:
             res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
@@ -143,10 +142,9 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
     elif shard == "cells":
         ny, nx = len(dataset.latitude), len(dataset.longitude)
         y0, y1 = split_even(ny, rank, ws)
-        order_, fused_cols, staged = agg._lower_all(aggregator_dict)
+        _, fused_cols, staged, names = agg._lower_all(aggregator_dict)
         if staged:
             raise ValueError("cell sharding supports fused (two-level) specs only")
-        names = [k for _, keys, _ in order_ for k in keys]
         groups = eng.plan_groups(tindex, fused_cols)
         if len(groups) != 1:
             raise ValueError("cell sharding needs all outputs to share their group frequencies")

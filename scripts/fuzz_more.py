@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch
+import test_gpu_fuzz as f
+bad = 0
+for seed in range(6, 60):
+    try:
+        f.test_random_specs_match_oracle(torch, seed)
+    except Exception as e:
+        bad += 1
+        import traceback; print("SEED", seed, "FAILED:", str(e)[:300]); print("".join(traceback.format_exc().splitlines(True)[-14:]))
+print("done, failures:", bad)

@@ -189,3 +189,20 @@ def test_zarr_roundtrip_and_auto_chunks(tmp_path):
             assert back.time.equals(time)
         else:
             assert back.time == time and back.time.calendar == "noleap"
+
+
+def test_duplicate_output_keys_follow_dict_semantics():
+    """Two ddargs rows with equal bounds but different flags produce the same key: like the
+    reference's dict merge (aggregate.py:160-161) the later column wins at the first one's
+    position, and the shadowed column is not computed at all."""
+    from aggfly_amd.aggregate import _lower_all
+    spec = {"a": [("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [[5.0, 95.0, 0], [1.0, 2.0, 0], [5.0, 95.0, 1]]}),
+                  ("aggregate", {"calc": "mean", "groupby": "year"})],
+            "b": [("aggregate", {"calc": "mean", "groupby": "date"}), ("aggregate", {"calc": "sum", "groupby": "year"})],
+            "a_1.0_2.0": [("aggregate", {"calc": "max", "groupby": "year"})]}
+    order, fused, staged, names = _lower_all(spec)
+    assert names == ["a_5.0_95.0", "a_1.0_2.0", "b"] and not staged
+    by_key = {c.key: c for c in fused}
+    assert len(fused) == 3
+    assert by_key["a_5.0_95.0"].inner.ddargs == (5.0, 95.0, 1.0)          # the later row won
+    assert by_key["a_1.0_2.0"].inner.calc == "max"                        # the later NAME won that key
