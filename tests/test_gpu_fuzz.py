@@ -59,13 +59,41 @@ def _random_steps(rng):
     return steps
 
 
-@pytest.mark.parametrize("seed", range(16))
+def _time_axes(rng, T, spd, seed):
+    """(product index, oracle index, kept positions): standard or CF calendar, with a gap of whole
+    days and a few single missing steps so that empty and ragged groups occur."""
+    from oracle.ref_calendar import OracleCFIndex, cf_daily_index
+    keep = np.ones(T, bool)
+    g0 = int(rng.integers(spd * 5, T - spd * 12))
+    keep[g0:g0 + spd * int(rng.integers(1, 5))] = False
+    keep[rng.integers(0, T, 4)] = False
+    keep = np.nonzero(keep)[0]
+    cal = [None, "noleap", "360_day"][seed % 3] if seed >= 16 else None
+    step_h = 24 // spd
+    if cal is None:
+        t = pd.date_range("2001-11-17 00:00", periods=T, freq=f"{step_h}h")
+        return t[keep], t[keep], keep
+    prod = af.cf_range("2001-11-17", T, f"{step_h}h", cal)
+    days = cf_daily_index(cal, (T + spd - 1) // spd, (2001, 11, 17))
+    rep = np.repeat(np.arange(len(days)), spd)[:T]
+    orc = OracleCFIndex(days.year[rep], days.month[rep], days.day[rep], (np.arange(T) % spd) * step_h, cal)
+    return prod[keep], orc[keep], keep
+
+
+@pytest.mark.parametrize("seed", range(28))
 def test_random_specs_match_oracle(torch_cuda, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = np.float64 if seed % 2 == 0 else np.float32
-    T, ny, nx = 24 * int(rng.integers(70, 130)) + int(rng.integers(0, 24)), int(rng.integers(3, 9)), int(rng.integers(3, 12))
-    cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=seed, ocean_frac=0.1, scattered_nan=15)
-    time = pd.date_range("2001-11-17 05:00", periods=T, freq="h")
+    spd = 24 if seed < 16 else int(rng.choice([1, 2, 24]))            # hourly; later seeds also daily / 12-hourly
+    ndays = int(rng.integers(70, 130)) if spd == 24 else int(rng.integers(400, 800))
+    T, ny, nx = spd * ndays + (int(rng.integers(0, 24)) if spd == 24 else 0), int(rng.integers(3, 9)), int(rng.integers(3, 12))
+    cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=seed, steps_per_day=spd, ocean_frac=0.1, scattered_nan=15)
+    if seed < 16:
+        time = otime = pd.date_range("2001-11-17 05:00", periods=T, freq="h")
+    else:
+        time, otime, keep = _time_axes(rng, T, spd, seed)
+        cube = np.ascontiguousarray(cube[keep])
+        T = len(keep)
     lon360 = bool(seed % 3 == 0)
     lat, lon = -10 + 0.5 * np.arange(ny), (170.0 if lon360 else -30.0) + 0.5 * np.arange(nx)
     tab = synth.weights_table(ny, nx, max(2, ny * nx // 9), seed=seed, secondary=bool(seed % 2), zero_frac=0.15)
@@ -73,13 +101,15 @@ def test_random_specs_match_oracle(torch_cuda, seed):
     ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=lon360)
     w = af.weights_from_objects(ds, gr, table=tab)
     ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
-    ods = ra.ODataset(cube.astype(np.float64), time, lat, lon, lon360)
+    ods = ra.ODataset(cube.astype(np.float64), otime, lat, lon, lon360)
     for trial in range(7):
         # all names of one call must share the output frequency (one panel time axis)
         out_freq, spec = None, {}
         for v in range(int(rng.integers(1, 4))):
             for _ in range(20):
                 steps = _random_steps(rng)
+                if not isinstance(time, pd.DatetimeIndex) and any(p.get("groupby") == "week" for k, p in steps if k == "aggregate"):
+                    continue                                   # no calendar week on CF calendars (raises, tested elsewhere)
                 last = [p["groupby"] for k, p in steps if k == "aggregate"][-1]
                 if out_freq in (None, last):
                     out_freq = last
@@ -97,7 +127,11 @@ def test_random_specs_match_oracle(torch_cuda, seed):
         got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
         assert list(got.columns) == list(want.columns), spec
         assert len(got) == len(want), spec
-        assert (got["geoid"].values == want["geoid"].values).all() and (got["time"].values == want["time"].values).all(), spec
+        assert (got["geoid"].values == want["geoid"].values).all(), spec
+        if isinstance(time, pd.DatetimeIndex):
+            assert (got["time"].values == want["time"].values).all(), spec
+        else:
+            assert [(t.year, t.month, t.day) for t in got["time"]] == [(t.year, t.month, t.day) for t in want["time"]], spec
         cols = [c for c in got.columns if c not in ("geoid", "time")]
         assert got[cols].shape == want[cols].shape, (spec, list(got.columns), list(want.columns))
         np.testing.assert_allclose(got[cols].values.astype(float), want[cols].values.astype(float), rtol=1e-10, atol=1e-10,
