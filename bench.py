@@ -114,6 +114,54 @@ def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
                       f"(C/OpenMP port of the reference's numba engine, oracle/c)"}
 
 
+def cpu_baseline_dask_path(T, ny_sample, nx, seed, target_s=8.0):
+    """The reference's dask-path arithmetic (vectorised numpy reducers called once per resample
+    group, `aggfly/aggregate/temporal.py:236-239,266-311`; `np.power`; `np.add.at` scatter) with a
+    thread pool over blocks of days standing in for the dask threaded scheduler."""
+    from concurrent.futures import ThreadPoolExecutor
+    from aggfly_amd import synth
+    from oracle import ref_temporal as rt
+    from oracle.ref_spatial import scatter_block
+    cores = host_cores()
+    ib = synth.hourly_bounds(T)
+    ndays = len(ib) - 1
+    tab = synth.weights_table(ny_sample, nx, max(2, 3100 * ny_sample // 215), seed=7)
+    ridx, cidx, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+    R = int(ridx.max()) + 1
+    cube = synth.temperature_cube(T, ny_sample, nx, dtype=np.float64, seed=seed)
+    blocks = np.linspace(0, ndays, min(ndays, cores * 4) + 1).astype(int)
+
+    def temporal(calc, ddargs=None):
+        def work(i):
+            g0, g1 = blocks[i], blocks[i + 1]
+            return rt.dask_resample(cube[ib[g0]:ib[g1]], ib[g0:g1 + 1] - ib[g0], calc, ddargs)
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            return np.concatenate(list(ex.map(work, range(len(blocks) - 1))))
+
+    def one_pass():
+        outs = [temporal("dd", [10, 30, 0]).sum(axis=0)]
+        for e in (1, 2, 3, 4):
+            outs.append(np.power(temporal("mean"), e).sum(axis=0))      # every output name restarts from the raw data
+        x = np.stack([o.reshape(-1, 1) for o in outs])
+        valid = ~np.isnan(x).any(axis=0)
+        den = scatter_block(valid.astype(float), ridx, cidx, w, R)
+        return [scatter_block(np.where(valid, xk, 0.0), ridx, cidx, w, R) / den for xk in x]
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        one_pass()
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            one_pass()
+            reps += 1
+            if time.perf_counter() - t0 > target_s or reps >= 20:
+                break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": T * ny_sample * nx / dt, "unit": "grid-cell-timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{ny_sample}x{nx} band, T={T}, fp64, {reps} passes of {dt:.2f} s (numpy restatement of the reference's dask path, "
+                      f"thread pool of {cores})"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +275,10 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "grid-cell-timesteps/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e}"}
+            try:   # second reference point: the dask-path arithmetic
+                line["cpu_baseline_dask_path"] = cpu_baseline_dask_path(T, max(8, min(host_cores(), 64)), nx, seed=20260101)
+            except Exception as e:
+                line["cpu_baseline_dask_path"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
