@@ -270,15 +270,16 @@ def main():
                          "algorithmic_bytes_per_launch": T * C * elem},
         }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(T, max(8, min(host_cores(), 64)), nx, seed=20260101)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "grid-cell-timesteps/s", "cores": 0, "kind": "port",
-                                        "sample": f"failed: {e}"}
-            try:   # second reference point: the dask-path arithmetic
-                line["cpu_baseline_dask_path"] = cpu_baseline_dask_path(T, max(8, min(host_cores(), 64)), nx, seed=20260101)
-            except Exception as e:
-                line["cpu_baseline_dask_path"] = {"value": None, "sample": f"failed: {e}"}
+            # both CPU engines of the reference, restated (oracle/): the faster one is THE baseline
+            cands = []
+            for fn in (cpu_baseline, cpu_baseline_dask_path):
+                try:
+                    cands.append(fn(T, max(8, min(host_cores(), 64)), nx, seed=20260101))
+                except Exception as e:  # the baseline must never take the GPU number down with it
+                    cands.append({"value": None, "unit": "grid-cell-timesteps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"})
+            cands.sort(key=lambda c: -(c["value"] or 0.0))
+            line["cpu_baseline"] = cands[0]
+            line["cpu_baseline_other_engine"] = cands[1]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
