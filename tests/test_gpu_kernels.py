@@ -356,3 +356,18 @@ def test_caller_workspace_and_side_stream(torch_cuda):
     assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
     with pytest.raises(ValueError, match="workspace"):
         plan.run(cube, csr, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+
+
+def test_c_abi_from_plain_c(torch_cuda, tmp_path):
+    """The boundary is a C ABI: a C11 program compiled with gcc links libaggfly_hip.so, runs a
+    fused plan + CSR reduce and checks it against its own host loop (examples/c_abi_demo.c)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    lib = os.path.join(root, "aggfly_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_abi_demo.c"),
+                           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-L" + lib, "-laggfly_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C ABI OK" in r.stdout, r.stdout + r.stderr
