@@ -484,10 +484,8 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
     const bool partition = pl->hb_n > 0 && want_pipe == 0;
     const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition);
-    if (!v && tuning > 0) {
-        delete pl;
-        return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for tuning arm %d", tuning);
-    }
+    if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition);
     if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0);
     if (!v) {
         delete pl;

@@ -163,7 +163,8 @@ typedef struct afhip_plan_desc {
     const afhip_column* columns;   /* HOST [K]                                               */
     int32_t exact_order;           /* 1: never split an outer period across workgroups, so
                                       every per-cell sum runs in the reference's order       */
-    int32_t tuning;                /* 0 = default; see DESIGN.md (pipeline variant override) */
+    int32_t tuning;                /* 0 = default; else a load-path arm pipe*1000+vec*100+depth (a hint:
+                                      falls back to the default when that arm is not compiled) */
 } afhip_plan_desc;
 
 typedef struct afhip_plan afhip_plan;
