@@ -373,7 +373,9 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         if ((v > e2.x) && (v < e2.y)) { idx = i2; m = true; }
                     }
                 }
-                if (m) hcnt[(idx * VEC + i) * bd + tid] += 1;
+                // the counter is private to this lane: a relaxed LDS atomic is one ds_add_u32
+                // (no return value) instead of read + add + write
+                if (m) __hip_atomic_fetch_add(&hcnt[(idx * VEC + i) * bd + tid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
 #pragma unroll
             for (int j = 0; j < (HB ? 0 : NTHR); ++j) {
