@@ -94,7 +94,7 @@ struct afhip_plan {
     std::vector<ColOp> cols;
     std::vector<ChunkDesc> chunks;
     std::vector<int32_t> emit;
-    std::vector<int64_t> gtab;            // [(end step) << 1 | emit] per inner group, padded by one
+    std::vector<int64_t> gtab;            // {(end step) << 1 | emit, bits of 1.0/len} per inner group, padded by one
     std::vector<int32_t> slot_ptr;        // [P+1]
     int64_t n_slots = 0;
     const Variant* variant = nullptr;
@@ -494,8 +494,15 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->variant = v;
     if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
 
-    pl->gtab.assign((size_t)desc->G1 + 2, 0);
-    for (int64_t g = 0; g < desc->G1; ++g) pl->gtab[(size_t)g] = (pl->ib[(size_t)g + 1] << 1) | (pl->emit[(size_t)g] ? 1 : 0);
+    pl->gtab.assign(2 * ((size_t)desc->G1 + 2), 0);
+    for (int64_t g = 0; g < desc->G1; ++g) {
+        const int64_t len = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g];
+        const double inv = len > 0 ? 1.0 / (double)len : 0.0;     // correctly rounded: div_by() then equals s / n exactly
+        int64_t bits;
+        memcpy(&bits, &inv, 8);
+        pl->gtab[2 * (size_t)g] = (pl->ib[(size_t)g + 1] << 1) | (pl->emit[(size_t)g] ? 1 : 0);
+        pl->gtab[2 * (size_t)g + 1] = bits;
+    }
     if ((rc = pl->d_ob.upload(pl->ob)) || (rc = pl->d_gtab.upload(pl->gtab)) ||
         (rc = pl->d_chunks.upload(pl->chunks)) || (rc = pl->d_slot_ptr.upload(pl->slot_ptr))) {
         delete pl;

@@ -68,7 +68,8 @@ struct ChunkDesc {
 struct FusedArgs {
     const void* cube;
     int64_t C;                     // cells
-    const int64_t* gtab;           // device [G1+1]: (end step of inner group g) << 1 | (emit a slot after g)
+    const int64_t* gtab;           // device [G1+1][2]: {(end step of inner group g) << 1 | (emit a slot after g),
+                                   //                    bits of the double 1.0 / (steps in g)}
     const ChunkDesc* chunks;       // device [n_chunks]
     double* partial;               // device [n_slots][K][C]
     int32_t K, nthr;
@@ -88,25 +89,86 @@ struct FusedArgs {
 __device__ __forceinline__ double nan64() { return __longlong_as_double(0x7ff8000000000000LL); }
 __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
 
+// A volatile empty asm cannot be speculated, so a block that starts with it stays behind its branch.
+#define KEEP_BRANCH() asm volatile("")
+
 // x**e for a small integer e, evaluated as a double-double product chain so that the
 // result is the correctly rounded power in all but ~1e-16 of cases — what libm's pow()
 // behind np.power (dataset.py:543) returns.  Plain repeated multiplication differs from
 // np.power in the last bit for 26-35 % of inputs at e = 3, 4.
-__device__ __forceinline__ double powi_dd(double x, int e) {
-    if (e == 0) return 1.0;
-    int n = e < 0 ? -e : e;
-    double hi = x, lo = 0.0;
-    for (int i = 1; i < n; ++i) {
-        // (hi + lo) * x  ->  (p + q)
-        double p = hi * x;
-        double err = __fma_rn(hi, x, -p);
-        double q = __fma_rn(lo, x, err);
-        double s = p + q;
-        lo = q - (s - p);
-        hi = s;
+// The exponent is wave-uniform: one scalar loop drives the N independent chains of a lane.
+template <int N>
+__device__ __forceinline__ void powi_dd_vec(double (&x)[N], int e) {
+    if (e == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = 1.0;
+        return;
     }
-    double r = hi + lo;
-    return e < 0 ? 1.0 / r : r;
+    const int n = e < 0 ? -e : e;
+    double hi[N], lo[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { hi[i] = x[i]; lo[i] = 0.0; }
+    for (int it = 1; it < n; ++it) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            // (hi + lo) * x  ->  (p + q)
+            const double p = hi[i] * x[i];
+            const double err = __fma_rn(hi[i], x[i], -p);
+            const double q = __fma_rn(lo[i], x[i], err);
+            const double sm = p + q;
+            lo[i] = q - (sm - p);
+            hi[i] = sm;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = hi[i] + lo[i];
+    if (e < 0) {
+        KEEP_BRANCH();
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = 1.0 / x[i];
+    }
+}
+__device__ __forceinline__ double powi_dd(double x, int e) {
+    double v[1] = {x};
+    powi_dd_vec<1>(v, e);
+    return v[0];
+}
+
+// ---- f64 division / square root without the library's scaling and special-case code ----
+// 1/x for normal x: v_rcp_f64 (~2^-23) + two Newton steps -> faithful (<= 1 ulp).
+__device__ __forceinline__ double rcp_fast(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __fma_rn(-x, y, 1.0);
+    y = __fma_rn(y, e, y);
+    e = __fma_rn(-x, y, 1.0);
+    return __fma_rn(y, e, y);
+}
+// a / b given y ~ 1/b (Markstein): q0 = a*y, r = a - b*q0 exactly (fma), q = q0 + r*y.  With y the
+// CORRECTLY rounded reciprocal (the host's 1.0/n for a group length n) q is the correctly rounded
+// quotient — bit-identical to a true division (checked against exact rational arithmetic,
+// DESIGN.md §5); with a faithful y it is within 1 ulp.  v_div_fixup restores the IEEE results for
+// inf / NaN / zero operands.
+__device__ __forceinline__ double div_by_finite(double a, double b, double y) {   // finite a, normal b
+    const double q0 = a * y;
+    const double r = __fma_rn(-q0, b, a);
+    return __fma_rn(r, y, q0);
+}
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+    return __builtin_amdgcn_div_fixup(div_by_finite(a, b, y), b, a);
+}
+// sqrt(x) for normal x >= 0: v_rsq_f64 seed, Goldschmidt step, two residual corrections (the
+// library's core sequence); x == 0 -> 0, x < 0 or NaN -> NaN.
+__device__ __forceinline__ double sqrt_fast(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __fma_rn(-h, g, 0.5);
+    g = __fma_rn(g, r, g);
+    h = __fma_rn(h, r, h);
+    double d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    return (x == 0.0) ? 0.0 : g;
 }
 
 // asin / acos to ~2e-15 relative (checked against numpy on 2e6 points): on
@@ -114,18 +176,30 @@ __device__ __forceinline__ double powi_dd(double x, int e) {
 // half-angle identity asin(x) = pi/2 - 2 asin(sqrt((1-x)/2)).  One sqrt + 11 FMAs instead of
 // the library's ~70-instruction routines: sine_dd needs one of these per threshold per
 // cell-day and was bound by them.  |x| > 1 yields NaN like the library functions.
+// d = a * b + c as ONE three-address v_fma_f64.  For a Horner chain whose coefficients live in
+// registers hipcc otherwise emits v_mov_b64 + v_fmac_f64 per term (the two-address form clobbers
+// the coefficient), doubling the polynomial's VALU cost.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
 __device__ __forceinline__ double asin_core(double s, double t) {
     double p = 2.78600666767379636e-02;
-    p = __fma_rn(p, t, -6.80823893868847015e-03);
-    p = __fma_rn(p, t, 1.54379220773654957e-02);
-    p = __fma_rn(p, t, 1.02917232813431302e-02);
-    p = __fma_rn(p, t, 1.41405795351722628e-02);
-    p = __fma_rn(p, t, 1.73372313610090298e-02);
-    p = __fma_rn(p, t, 2.23730075566984689e-02);
-    p = __fma_rn(p, t, 3.03819175771733174e-02);
-    p = __fma_rn(p, t, 4.46428575770584091e-02);
-    p = __fma_rn(p, t, 7.49999999972744968e-02);
-    p = __fma_rn(p, t, 1.66666666666669405e-01);
+    p = fma3(p, t, -6.80823893868847015e-03);
+    p = fma3(p, t, 1.54379220773654957e-02);
+    p = fma3(p, t, 1.02917232813431302e-02);
+    p = fma3(p, t, 1.41405795351722628e-02);
+    p = fma3(p, t, 1.73372313610090298e-02);
+    p = fma3(p, t, 2.23730075566984689e-02);
+    p = fma3(p, t, 3.03819175771733174e-02);
+    p = fma3(p, t, 4.46428575770584091e-02);
+    p = fma3(p, t, 7.49999999972744968e-02);
+    p = fma3(p, t, 1.66666666666669405e-01);
     return __fma_rn(s * t, p, s);                    // asin(s) for 0 <= s <= 1/2, t = s^2
 }
 __device__ __forceinline__ double acos_fast(double x) {
@@ -133,7 +207,7 @@ __device__ __forceinline__ double acos_fast(double x) {
     const double ax = fabs(x);
     const bool small = ax <= 0.5;
     const double t = small ? ax * ax : (1.0 - ax) * 0.5;
-    const double s = small ? ax : sqrt(t);
+    const double s = small ? ax : sqrt_fast(t);
     const double r = asin_core(s, t);
     return small ? HALF_PI - copysign(r, x) : (x > 0.0 ? 2.0 * r : PI - 2.0 * r);
 }
@@ -142,7 +216,7 @@ __device__ __forceinline__ double asin_fast(double x) {
     const double ax = fabs(x);
     const bool small = ax <= 0.5;
     const double t = small ? ax * ax : (1.0 - ax) * 0.5;
-    const double s = small ? ax : sqrt(t);
+    const double s = small ? ax : sqrt_fast(t);
     const double r = asin_core(s, t);
     return copysign(small ? r : HALF_PI - 2.0 * r, x);
 }
@@ -152,31 +226,63 @@ __device__ __forceinline__ double asin_fast(double x) {
 //   cooling: a = acos(z), |z| <= 1:  sin(a) = sqrt(1 - z^2)
 //   heating: at = atan(r / sqrt(1 - r^2)) = asin(r),  cos(at) = sqrt(1 - r^2)
 // (|r| > 1 gives NaN in both forms, as in the reference), and the divisions by pi written as
-// multiplications by 1/pi.  Results agree with the reference's form to ~1e-15, inside the
-// 1e-10 contract for sine_dd.
-__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg) {
+// multiplications by 1/pi; the quotient uses one shared reciprocal of (tmax - tmin) per window
+// (rcp_fast + div_by_finite) and the square roots skip the library's range scaling.  Results
+// agree with the reference's form to ~1e-15, inside the 1e-10 contract for sine_dd.
+__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg, double inv_rng) {
     const double INV_PI = 0.31830988618379067154;
     if (thr <= tmin) return tavg - thr;
     if (thr < tmax && tmin < thr) {
         const double rng = tmax - tmin;
-        const double z = (2.0 * thr - tmax - tmin) / rng;
+        const double z = div_by_finite(2.0 * thr - tmax - tmin, rng, inv_rng);   // inf / NaN operands give NaN here too
         const double a = acos_fast(z);
-        const double sa = sqrt((1.0 - z) * (1.0 + z));
-        return ((tavg - thr) * a + rng * sa * 0.5) * INV_PI;
+        const double sa = sqrt_fast((1.0 - z) * (1.0 + z));
+        return ((tavg - thr) * a + (rng * 0.5) * sa) * INV_PI;       // (rng * sa) * 0.5 exactly: halving is exact
     }
     return 0.0;
 }
-__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg) {
+__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg, double inv_rng) {
     const double INV_PI = 0.31830988618379067154, HALF_PI = 1.57079632679489661923;
     if (thr >= tmax) return thr - tavg;
     if (thr < tmax && tmin < thr) {
         const double alpha = (tmax - tmin) * 0.5;
-        const double r = (thr - tavg) / alpha;
+        const double r = div_by_finite(thr - tavg, alpha, 2.0 * inv_rng);
         const double at = asin_fast(r);
-        const double ca = sqrt((1.0 - r) * (1.0 + r));
+        const double ca = sqrt_fast((1.0 - r) * (1.0 + r));
         return INV_PI * ((thr - tavg) * (at + HALF_PI) + alpha * ca);
     }
     return 0.0;
+}
+
+// acc += w on the lanes where t0 < v < t1 (strict; a NaN v fails both compares): the two
+// compares narrow EXEC directly (v_cmpx), the add runs under that mask and EXEC is put back —
+// 3 VALU ops, where compare + compare + a 64-bit select (2 x v_cndmask) + add takes 5.
+template <typename T>
+__device__ __forceinline__ void add_if_between(double& acc, double w, T v, T t0, T t1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    if constexpr (sizeof(T) == 4) {
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "v_cmpx_lt_f32_e32 %[t0], %[v]\n\t"
+            "v_cmpx_gt_f32_e32 %[t1], %[v]\n\t"
+            "v_add_f64 %[acc], %[acc], %[w]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [acc] "+v"(acc), [sv] "=&s"(saved)
+            : [w] "v"(w), [v] "v"(v), [t0] "s"(t0), [t1] "s"(t1)
+            : "vcc");
+    } else {
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "v_cmpx_lt_f64_e32 %[t0], %[v]\n\t"
+            "v_cmpx_gt_f64_e32 %[t1], %[v]\n\t"
+            "v_add_f64 %[acc], %[acc], %[w]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [acc] "+v"(acc), [sv] "=&s"(saved)
+            : [w] "v"(w), [v] "v"(v), [t0] "s"(t0), [t1] "s"(t1)
+            : "vcc");
+    }
+#else
+    acc += (v > t0 && v < t1) ? w : 0.0;
+#endif
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -349,13 +455,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 s[i] += v;                          // a NaN poisons s; the group is NaN anyway
             } else if (STAT == 2) {
                 s[i] += v;
-                mn[i] = (v < mn[i]) ? v : mn[i];    // NaN compares false: skipped like the reference
-                mx[i] = (v > mx[i]) ? v : mx[i];
+                mn[i] = __builtin_fmin(mn[i], v);   // minNum/maxNum skip a NaN like the reference's
+                mx[i] = __builtin_fmax(mx[i], v);   // "v < mn" / "v > mx" updates: one VALU op each
             } else if (STAT == 3) {
                 s[i] += isn ? 0.0 : v;
                 cnt[i] += isn ? 0 : 1;
-                mn[i] = (v < mn[i]) ? v : mn[i];
-                mx[i] = (v > mx[i]) ? v : mx[i];
+                mn[i] = __builtin_fmin(mn[i], v);
+                mx[i] = __builtin_fmax(mx[i], v);
             }
             if constexpr (HB) {
                 int idx = (int)floor((v - a.hb_e0) * a.hb_invw);
@@ -379,45 +485,55 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < (HB ? 0 : NTHR); ++j) {
-                bool m;                                                   // strict, NaN -> false
-                if constexpr (sizeof(TIn) == 4) m = (vr > a.thr[j].t0f) && (vr < a.thr[j].t1f);
-                else m = (v > a.thr[j].t0) && (v < a.thr[j].t1);
                 if constexpr (TKI) {
+                    bool m;                                               // strict, NaN -> false
+                    if constexpr (sizeof(TIn) == 4) m = (vr > a.thr[j].t0f) && (vr < a.thr[j].t1f);
+                    else m = (v > a.thr[j].t0) && (v < a.thr[j].t1);
                     cthr[j][i] += m ? 1 : 0;
                 } else {
                     const double w = __fma_rn(a.thr[j].A, v, a.thr[j].B);
-                    acc[j][i] += m ? w : 0.0;
+                    if constexpr (sizeof(TIn) == 4) add_if_between<float>(acc[j][i], w, vr, a.thr[j].t0f, a.thr[j].t1f);
+                    else add_if_between<double>(acc[j][i], w, v, a.thr[j].t0, a.thr[j].t1);
                 }
             }
         }
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----
-    auto group_end = [&](bool emit_slot, int nsteps) {
+    auto group_end = [&](bool emit_slot, int nsteps, double inv_n, int zoff) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
         bool hasnan[VEC];
-        double mean[VEC];
+        double mean[VEC], inv_rng[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
-            mean[i] = (STAT >= 1) ? s[i] / dn : 0.0;
+            mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
+            inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_fast(mx[i] - mn[i]) : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
-                const ColOp co = a.cols[j];
+                // zoff is 0, but only known at run time (it comes from the group table word): the column
+                // record is then read from the kernel-argument segment HERE, by scalar loads, instead of
+                // being hoisted out of the time loop into ~18 SGPRs per column — which overflowed the
+                // SGPR file and came back as v_readlane (VALU) traffic in every group end.
+                const ColOp co = a.cols[j + zoff];
+                // Every test on a column field below is wave-uniform.  KEEP_BRANCH() pins those tests
+                // as real scalar branches: left alone, hipcc if-converts the cheap-looking arms (a
+                // float round trip, 1/x for negative exponents) and runs them on every group end.
+                double x[VEC];
+                const int src = co.src;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const bool bad = hasnan[i] || empty;
-                    double x = nan64();
-                    const int src = co.src;
-                    if (STAT >= 1 && src == SRC_MEAN) x = bad ? nan64() : mean[i];
-                    else if (STAT >= 1 && src == SRC_SUM) x = bad ? nan64() : s[i];
-                    else if (STAT >= 2 && src == SRC_MIN) x = bad ? nan64() : mn[i];
-                    else if (STAT >= 2 && src == SRC_MAX) x = bad ? nan64() : mx[i];
+                    x[i] = nan64();
+                    if (STAT >= 1 && src == SRC_MEAN) x[i] = bad ? nan64() : mean[i];
+                    else if (STAT >= 1 && src == SRC_SUM) x[i] = bad ? nan64() : s[i];
+                    else if (STAT >= 2 && src == SRC_MIN) x[i] = bad ? nan64() : mn[i];
+                    else if (STAT >= 2 && src == SRC_MAX) x[i] = bad ? nan64() : mx[i];
                     else if (STAT == 3 && src == SRC_NANMEAN)
-                        x = (empty || cnt[i] == 0) ? nan64() : s[i] / (double)cnt[i];
+                        x[i] = (empty || cnt[i] == 0) ? nan64() : s[i] / (double)cnt[i];
                     else if (NTHR > 0 && src == SRC_THR) {
                         double t = 0.0;
                         bool poisons = false;
@@ -428,46 +544,66 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                                 else t = TKI ? (double)cthr[q][i] : acc[q][i];
                                 poisons = a.thr[q].nan_poisons != 0;
                             }
-                        x = (empty || (poisons && hasnan[i])) ? nan64() : t;
+                        x[i] = (empty || (poisons && hasnan[i])) ? nan64() : t;
                     } else if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {   // nb_kernels.py:218-251
                         if (!bad) {
                             const double tavg = mean[i];
                             if (co.skind == 0)
-                                x = sine_cool(co.s0, mn[i], mx[i], tavg) - sine_cool(co.s1, mn[i], mx[i], tavg);
+                                x[i] = sine_cool(co.s0, mn[i], mx[i], tavg, inv_rng[i]) - sine_cool(co.s1, mn[i], mx[i], tavg, inv_rng[i]);
                             else
-                                x = -sine_heat(co.s0, mn[i], mx[i], tavg) + sine_heat(co.s1, mn[i], mx[i], tavg);
+                                x[i] = -sine_heat(co.s0, mn[i], mx[i], tavg, inv_rng[i]) + sine_heat(co.s1, mn[i], mx[i], tavg, inv_rng[i]);
                         }
                     }
-                    if (co.rounding & 1) x = (double)(float)x;        // the reference stored this step in float32
-                    const int tf = co.tf;
-                    if (tf == TF_POWI) x = powi_dd(x, co.tf_iarg);
-                    else if (tf == TF_HINGE) {
-                        if (co.rounding & 2) {
-                            const float xf = (float)x, kf = (float)co.tf_arg;
-                            x = (double)(((xf > kf) ? 1.0f : 0.0f) * (xf - kf));
-                        } else {
-                            x = ((x > co.tf_arg) ? 1.0 : 0.0) * (x - co.tf_arg);
+                }
+                if (co.rounding & 1) {                                // the reference stored this step in float32
+                    KEEP_BRANCH();
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) x[i] = (double)(float)x[i];
+                }
+                const int tf = co.tf;
+                if (tf == TF_POWI) {
+                    powi_dd_vec<VEC>(x, co.tf_iarg);
+                } else if (tf == TF_HINGE) {
+                    KEEP_BRANCH();
+                    if (co.rounding & 2) {
+                        const float kf = (float)co.tf_arg;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const float xf = (float)x[i];
+                            x[i] = (double)(((xf > kf) ? 1.0f : 0.0f) * (xf - kf));
                         }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) x[i] = ((x[i] > co.tf_arg) ? 1.0 : 0.0) * (x[i] - co.tf_arg);
                     }
-                    else if ((FEAT & 2) && tf == TF_POW) x = pow(x, co.tf_arg);
-                    if constexpr (SL) {
-                        if (active) a.partial[((int64_t)slot * K + j) * C + c0 + i] = x;
-                        continue;
+                } else if ((FEAT & 2) && tf == TF_POW) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) x[i] = pow(x[i], co.tf_arg);
+                }
+                if constexpr (SL) {
+                    if (active) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) a.partial[((int64_t)slot * K + j) * C + c0 + i] = x[i];
                     }
+                    continue;
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const double xi = x[i];
                     double o = os[j][i];
                     switch (co.outer) {
-                        case OUT_FIRST: o = x; break;
+                        case OUT_FIRST: o = xi; break;
                         case OUT_SUM:
-                        case OUT_MEAN: o += x; break;               // NaN is sticky
-                        case OUT_MIN: { double t = (x < o) ? x : o; o = (x != x) ? x : t; break; }
-                        case OUT_MAX: { double t = (x > o) ? x : o; o = (x != x) ? x : t; break; }
+                        case OUT_MEAN: o += xi; break;              // NaN is sticky
+                        case OUT_MIN: { double t = (xi < o) ? xi : o; o = (xi != xi) ? xi : t; break; }
+                        case OUT_MAX: { double t = (xi > o) ? xi : o; o = (xi != xi) ? xi : t; break; }
                         case OUT_DD: {
-                            const bool m = (x > co.o0) && (x < co.o1);
-                            o += (x != x) ? x : (m ? fabs(x - co.obase) : 0.0);
+                            const bool m = (xi > co.o0) && (xi < co.o1);
+                            o += (xi != xi) ? xi : (m ? fabs(xi - co.obase) : 0.0);
                             break;
                         }
                         default: {  // OUT_BINS: a NaN value is simply out of range
-                            const bool m = (x > co.o0) && (x < co.o1);
+                            const bool m = (xi > co.o0) && (xi < co.o1);
                             o += m ? 1.0 : 0.0;
                             break;
                         }
@@ -510,10 +646,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         const TIn* p = cube;
         // group table word for g is fetched one group ahead: its scalar-load latency hides behind
         // the previous group's work (matters for 1-2 step groups: daily data, tmin/tmax pairs)
-        int64_t w_next = ld_uniform(&a.gtab[g]);
+        int64_t w_next = ld_uniform(&a.gtab[2 * g]), iv_next = ld_uniform(&a.gtab[2 * g + 1]);
         while (g < g_hi) {
-            const int64_t w = w_next;
-            w_next = ld_uniform(&a.gtab[g + 1]);                 // table is padded by one entry
+            const int64_t w = w_next, iv = iv_next;
+            w_next = ld_uniform(&a.gtab[2 * g + 2]);             // table is padded by one entry
+            iv_next = ld_uniform(&a.gtab[2 * g + 3]);
             const int gend = (int)((w >> 1) - k_lo);
             const int gbeg = kk;
             // DEPTH rows in flight per lane inside a group
@@ -530,7 +667,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 p += C;
                 consume(r0);
             }
-            group_end((w & 1) != 0, gend - gbeg);
+            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63));
             ++g;
         }
     } else {
@@ -553,10 +690,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) issue(d, d);
         }
-        int64_t w_next = ld_uniform(&a.gtab[g]);
+        int64_t w_next = ld_uniform(&a.gtab[2 * g]), iv_next = ld_uniform(&a.gtab[2 * g + 1]);
         while (g < g_hi) {
-            const int64_t w = w_next;
-            w_next = ld_uniform(&a.gtab[g + 1]);
+            const int64_t w = w_next, iv = iv_next;
+            w_next = ld_uniform(&a.gtab[2 * g + 2]);
+            iv_next = ld_uniform(&a.gtab[2 * g + 3]);
             const int gend = (int)((w >> 1) - k_lo);
             const int gbeg = kk;
             for (; kk < gend; ++kk) {
@@ -574,7 +712,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 __builtin_memcpy(&rv, &raw, 16);
                 consume(rv);
             }
-            group_end((w & 1) != 0, gend - gbeg);
+            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63));
             ++g;
         }
         // no DMA may still target this workgroup's LDS when the wave retires
