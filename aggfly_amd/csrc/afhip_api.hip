@@ -100,8 +100,9 @@ struct afhip_plan {
     const Variant* variant = nullptr;
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
-    int hb_n = 0; double hb_e0 = 0, hb_invw = 0, hb_lo = 0, hb_hi = 0;   // LDS-histogram bins
-    int hb_sorted[MAX_THR] = {0}, hb_bin_of_slot[MAX_THR] = {0};
+    int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
+    int hb_bin_of_slot[MAX_THR] = {0};
+    double hb_edge[MAX_THR + 1] = {0};
     // device tables
     DevBuf<int64_t> d_ob;
     DevBuf<int64_t> d_gtab;
@@ -475,10 +476,18 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
             ok = std::fabs(t.t0 - (e0 + b * w)) <= 1e-9 * w && std::fabs(t.t1 - (e0 + (b + 1) * w)) <= 1e-9 * w;
             if (ok && b + 1 < pl->nthr) ok = t.t1 == pl->thr[(size_t)order[(size_t)b + 1]].t0;
         }
+        // the in-kernel guess floor(v / w - e0 / w) is computed in the INPUT precision and may be off by
+        // one bin at most: the bins must not be narrower than ~2^20 (f32) / 2^48 (f64) ulps of the edges
+        const double emax = std::max(std::fabs(e0), std::fabs(e0 + pl->nthr * w));
+        const double eps = desc->dtype == AFHIP_F32 ? 1.2e-7 : 2.3e-16;
+        ok = ok && emax * eps * 16.0 < w;
         if (ok) {
-            pl->hb_n = pl->nthr; pl->hb_e0 = e0; pl->hb_invw = 1.0 / w;
-            pl->hb_lo = e0; pl->hb_hi = pl->thr[(size_t)order[(size_t)pl->nthr - 1]].t1;
-            for (int b = 0; b < pl->nthr; ++b) { pl->hb_sorted[b] = order[(size_t)b]; pl->hb_bin_of_slot[order[(size_t)b]] = b; }
+            pl->hb_n = pl->nthr; pl->hb_c1 = 1.0 / w; pl->hb_c0 = 1.0 - e0 / w;      // + 1: bin 0 is the lower guard bin
+            for (int b = 0; b < pl->nthr; ++b) {
+                pl->hb_bin_of_slot[order[(size_t)b]] = b;
+                pl->hb_edge[b] = pl->thr[(size_t)order[(size_t)b]].t0;
+            }
+            pl->hb_edge[pl->nthr] = pl->thr[(size_t)order[(size_t)pl->nthr - 1]].t1;
         }
     }
     if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
@@ -560,9 +569,18 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     void* args[] = {&fa};
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
     if (pl->variant->hb) {
-        fa.hb_n = pl->hb_n; fa.hb_e0 = pl->hb_e0; fa.hb_invw = pl->hb_invw; fa.hb_lo = pl->hb_lo; fa.hb_hi = pl->hb_hi;
-        for (int i = 0; i < MAX_THR; ++i) { fa.hb_sorted[i] = pl->hb_sorted[i]; fa.hb_bin_of_slot[i] = pl->hb_bin_of_slot[i]; }
-        lds = (size_t)MAX_THR * 16 + (size_t)pl->hb_n * pl->variant->vec * pl->wg * 4;
+        fa.hb_n = pl->hb_n; fa.hb_c1 = pl->hb_c1; fa.hb_c0 = pl->hb_c0;
+        fa.hb_c1f = (float)pl->hb_c1; fa.hb_c0f = (float)pl->hb_c0;
+        fa.hb_shift = pl->wg == 64 ? 6 : (pl->wg == 128 ? 7 : 8);
+        for (int i = 0; i < MAX_THR; ++i) fa.hb_bin_of_slot[i] = pl->hb_bin_of_slot[i];
+        for (int k = 0; k <= pl->hb_n; ++k) {
+            const double t = pl->hb_edge[k];
+            const float f = (float)t;
+            fa.hb_edge[k] = t;
+            fa.hb_dn[k] = (double)f > t ? std::nextafterf(f, -INFINITY) : f;     // largest float <= t
+            fa.hb_up[k] = (double)f < t ? std::nextafterf(f, INFINITY) : f;      // smallest float >= t
+        }
+        lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
     }
     HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;

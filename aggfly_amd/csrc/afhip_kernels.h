@@ -28,6 +28,7 @@ namespace afhip {
 constexpr int WG = 256;          // 4 wavefronts of 64
 constexpr int MAX_THR = 16;      // threshold slots evaluated on raw data per pass
 constexpr int MAX_COLS = 16;     // output columns per pass
+constexpr int HB_TABLE_BYTES = 2 * (MAX_THR + 2) * 16;    // LDS edge tables of the histogram path (576 B)
 
 // inner-source kinds (what a column reads at the end of an inner group)
 enum : int { SRC_MEAN = 0, SRC_SUM = 1, SRC_MIN = 2, SRC_MAX = 3, SRC_NANMEAN = 4, SRC_THR = 5, SRC_SINE = 6 };
@@ -75,10 +76,15 @@ struct FusedArgs {
     int32_t K, nthr;
     int32_t xcd_remap, n_tiles;    // 1: give each XCD a contiguous range of cell tiles (speed only)
     // LDS-histogram bins (FEAT bit 5): the threshold slots form a contiguous partition of equal
-    // width; hb_sorted[b] = slot of the b-th bin, hb_bin_of_slot = its inverse
-    double hb_e0, hb_invw, hb_lo, hb_hi;
-    int32_t hb_n, hb_pad;
-    int32_t hb_sorted[MAX_THR], hb_bin_of_slot[MAX_THR];
+    // width with edges hb_edge[0..hb_n]; hb_bin_of_slot[slot] = position of that slot's bin.
+    // guess bin (shifted by one guard bin) = floor(v * hb_c1 + hb_c0); hb_dn / hb_up are the edges
+    // rounded down / up to float, so a float v compares exactly:  v > t <=> v > dn,  v < t <=> v < up.
+    double hb_c1, hb_c0;
+    float hb_c1f, hb_c0f;
+    int32_t hb_n, hb_shift;        // hb_shift = log2(blockDim): counters are laid out [bin * VEC + i][blockDim]
+    int32_t hb_bin_of_slot[MAX_THR];
+    double hb_edge[MAX_THR + 1];
+    float hb_dn[MAX_THR + 1], hb_up[MAX_THR + 1];
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
 };
@@ -363,10 +369,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //             v_addc per slot and element instead of fma + select + f64 add)
     // FEAT bit 4: single-level plan (every inner group is an output period, every column
     //             passes its inner value through): no outer accumulators at all
-    // FEAT bit 5: the bins are a contiguous equal-width partition -> per-lane histogram in LDS:
-    //             the bin index comes from one subtract/multiply/floor, the (lo, hi) edges of that
-    //             bin are looked up in an LDS table and compared strictly like the reference, and
-    //             one ds_add bumps the lane's private counter.  ~10 VALU + 2 LDS ops per element
+    // FEAT bit 5: the bins are a contiguous equal-width partition -> per-lane histogram in LDS.
+    //             One fma + floor in the INPUT precision guesses the bin (off by one at most, host-
+    //             checked); the two edges around the guess come from an LDS table and four exact
+    //             compares move the guess up / down or reject a value that sits on an edge (strict
+    //             inequalities, like the reference); one ds_add_u32 bumps the lane's private
+    //             counter.  A guard bin on either side absorbs out-of-range values, so there is no
+    //             range test and no data-dependent branch.  ~13 VALU + 2 LDS ops per element
     //             instead of 3 VALU per bin.
     constexpr bool TKI = (FEAT & 8) != 0;
     constexpr bool SL = (FEAT & 16) != 0;
@@ -414,20 +423,42 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
         for (int j = 0; j < NTHR; ++j) { if (HB) {} else if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
     }
-    // LDS-histogram state: edge table [hb_n] of (lo, hi) pairs, then counters [hb_n * VEC][blockDim]
-    typedef double edge2 __attribute__((ext_vector_type(2)));
+    // LDS-histogram state.  With E[0] = E[hb_n + 2] = NaN (sentinels: every compare fails) and
+    // E[k + 1] = edge k, bin g of the guarded partition (g = 0 and g = hb_n + 1 are the guard bins) lies
+    // between E[g] and E[g + 1]:
+    //   etab_a[g] = {E[g].dn, E[g+1].up}   what the common path needs: v <= dn -> below, v >= up -> above
+    //   etab_b[g] = {E[g].up, E[g+1].dn}   only for lanes that leave the guessed bin: is v ON the edge?
+    // then the counters [(hb_n + 2) * VEC][blockDim].
+    struct EdgeT { TIn lo, hi; };
     extern __shared__ __attribute__((aligned(16))) unsigned char dynlds[];
-    edge2* etab = (edge2*)dynlds;
-    int* hcnt = (int*)(dynlds + MAX_THR * sizeof(edge2));
+    EdgeT* etab_a = (EdgeT*)dynlds;
+    EdgeT* etab_b = (EdgeT*)(dynlds + HB_TABLE_BYTES / 2);
+    int* hcnt = (int*)(dynlds + HB_TABLE_BYTES);
     const int bd = blockDim.x, tid = threadIdx.x;
+    const int hb_bins = a.hb_n + 2;
+    TIn hb_c1 = 0, hb_c0 = 0, hb_top = 0;
+    int hb_sh = 0, hb_lane[VEC] = {0};
     if constexpr (HB) {
-        if (tid < a.hb_n) {
-            const int sl_ = a.hb_sorted[tid];
-            edge2 e; e.x = a.thr[sl_].t0; e.y = a.thr[sl_].t1;
-            etab[tid] = e;
+        if (tid < hb_bins) {
+            auto edge = [&](int k, bool want_up) -> TIn {        // E[k].up or E[k].dn
+                if (k == 0 || k == a.hb_n + 2) return (TIn)nan64();
+                if constexpr (sizeof(TIn) == 4) return want_up ? a.hb_up[k - 1] : a.hb_dn[k - 1];
+                else return a.hb_edge[k - 1];
+            };
+            EdgeT ea, eb;
+            ea.lo = edge(tid, false); ea.hi = edge(tid + 1, true);
+            eb.lo = edge(tid, true);  eb.hi = edge(tid + 1, false);
+            etab_a[tid] = ea; etab_b[tid] = eb;
         }
-        for (int b = 0; b < a.hb_n * VEC; ++b) hcnt[b * bd + tid] = 0;
+        for (int b = 0; b < hb_bins * VEC; ++b) hcnt[b * bd + tid] = 0;
         __syncthreads();
+        if constexpr (sizeof(TIn) == 4) { hb_c1 = a.hb_c1f; hb_c0 = a.hb_c0f; }
+        else { hb_c1 = a.hb_c1; hb_c0 = a.hb_c0; }
+        hb_top = (TIn)(a.hb_n + 1);
+        asm volatile("" : "+v"(hb_c0));      // keep the addend in a VGPR: v_fma takes one scalar operand only
+        hb_sh = a.hb_shift + 2 + (VEC == 4 ? 2 : (VEC == 2 ? 1 : 0));     // byte stride between bins = VEC * blockDim * 4
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) hb_lane[i] = ((i << a.hb_shift) + tid) * 4;
     }
     auto reset_outer = [&]() {
         if (SL) return;
@@ -444,7 +475,31 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     reset_outer();
 
     // ---- the hot per-element update ----
-    auto consume = [&](const RawVec<TIn, VEC>& rv) {
+    // LDS-histogram update of one value, in two halves so that a batch of rows can issue all its
+    // table reads before the first compare needs one (see the PIPE 0 loop).
+    auto hb_guess = [&](TIn vr, int& b, EdgeT& ea) {
+        // guess in the input precision, clamped into the guarded range while still a float:
+        // fmax(NaN, 0) = 0, so a NaN drops into the lower guard bin without a test of its own;
+        // the clamped value is >= 0, so the truncating conversion is the floor
+        TIn t;
+        if constexpr (sizeof(TIn) == 4) t = __builtin_amdgcn_fmed3f(__fmaf_rn(vr, hb_c1, hb_c0), 0.0f, hb_top);
+        else t = fmin(fmax(__fma_rn((double)vr, hb_c1, hb_c0), 0.0), hb_top);
+        b = (int)t;
+        ea = etab_a[b];
+    };
+    auto hb_count = [&](TIn vr, int i, int b, const EdgeT& ea) {
+        const bool up = vr >= ea.hi, dn = vr <= ea.lo;               // the value belongs above / below the guess
+        bool count = true;
+        if (up || dn) {                                               // rare: guess off by one, or v on an edge
+            const EdgeT eb = etab_b[b];
+            count = up ? !(vr <= eb.hi) : !(vr >= eb.lo);             // strict bins: an edge value is in none
+            b += up ? 1 : -1;
+        }
+        // the counter is private to this lane: a relaxed LDS atomic is one ds_add_u32 (no return value)
+        if (count)
+            __hip_atomic_fetch_add((int*)((char*)hcnt + (b << hb_sh) + hb_lane[i]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    auto consume = [&](const RawVec<TIn, VEC>& rv, bool hb_inline = true) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const TIn vr = rv.v[i];
@@ -464,24 +519,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 mx[i] = __builtin_fmax(mx[i], v);
             }
             if constexpr (HB) {
-                int idx = (int)floor((v - a.hb_e0) * a.hb_invw);
-                idx = idx < 0 ? 0 : (idx >= a.hb_n ? a.hb_n - 1 : idx);
-                edge2 e = etab[idx];
-                bool m = (v > e.x) && (v < e.y);                          // strict, NaN -> false
-                // a value within a few ulp of an edge can land in the neighbouring slot of the
-                // multiply/floor: repair it against the true edges (wave-uniform, almost never taken)
-                const bool stray = !m && (v > a.hb_lo) && (v < a.hb_hi);
-                if (__builtin_amdgcn_ballot_w64(stray) != 0ull) {
-                    if (stray) {
-                        int i2 = (v >= e.y) ? idx + 1 : idx - 1;
-                        i2 = i2 < 0 ? 0 : (i2 >= a.hb_n ? a.hb_n - 1 : i2);
-                        const edge2 e2 = etab[i2];
-                        if ((v > e2.x) && (v < e2.y)) { idx = i2; m = true; }
-                    }
-                }
-                // the counter is private to this lane: a relaxed LDS atomic is one ds_add_u32
-                // (no return value) instead of read + add + write
-                if (m) __hip_atomic_fetch_add(&hcnt[(idx * VEC + i) * bd + tid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (hb_inline) { int b; EdgeT ea; hb_guess(vr, b, ea); hb_count(vr, i, b, ea); }
             }
 #pragma unroll
             for (int j = 0; j < (HB ? 0 : NTHR); ++j) {
@@ -540,7 +578,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                         for (int q = 0; q < NTHR; ++q)
                             if (q == co.src_idx) {
-                                if constexpr (HB) t = (double)hcnt[(a.hb_bin_of_slot[q] * VEC + i) * bd + tid];
+                                if constexpr (HB) t = (double)hcnt[((a.hb_bin_of_slot[q] + 1) * VEC + i) * bd + tid];
                                 else t = TKI ? (double)cthr[q][i] : acc[q][i];
                                 poisons = a.thr[q].nan_poisons != 0;
                             }
@@ -619,7 +657,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             for (int j = 0; j < NTHR; ++j) { if (HB) {} else if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
         }
         if constexpr (HB) {
-            for (int b = 0; b < a.hb_n * VEC; ++b) hcnt[b * bd + tid] = 0;
+            for (int b = 0; b < hb_bins * VEC; ++b) hcnt[b * bd + tid] = 0;
         }
         if constexpr (SL) {
             ++slot;
@@ -659,8 +697,23 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; ++d) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
                 p += (int64_t)DEPTH * C;
+                if constexpr (HB) {
+                    int hb_b[DEPTH][VEC];
+                    EdgeT hb_e[DEPTH][VEC];
 #pragma unroll
-                for (int d = 0; d < DEPTH; ++d) consume(r[d]);
+                    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) hb_guess(r[d].v[i], hb_b[d][i], hb_e[d][i]);
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        consume(r[d], false);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) hb_count(r[d].v[i], i, hb_b[d][i], hb_e[d][i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) consume(r[d]);
+                }
             }
             for (; kk < gend; ++kk) {
                 RawVec<TIn, VEC> r0 = ld_stream<TIn, VEC, AUX>(p);
