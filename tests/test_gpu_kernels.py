@@ -303,6 +303,68 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
                                   cport.block_bins(cube, bounds, odd).reshape(3, -1, 5))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("edges", ["tenths", "kelvin"])
+def test_lds_histogram_with_edges_that_float32_cannot_represent(torch_cuda, dtype, edges):
+    """The histogram path guesses the bin in the input precision and repairs the guess against the
+    exact edges.  Edges like 0.1*k or 250.15 + 0.7*k have no float32 representation: the value
+    next to such an edge on either side, quantised data sitting on every edge, and the guard bins
+    below / above the partition must all count exactly as the reference's double compares do."""
+    from aggfly_amd import hip
+    T, ny, nx = 400, 4, 32
+    rng = np.random.default_rng(5)
+    if edges == "tenths":
+        e = 0.1 * np.arange(-3, 11)                                      # 13 bins of width 0.1 (0.1*k is inexact)
+        cube = np.round(rng.normal(0.4, 0.5, (T, ny, nx)), 1)            # data quantised to the edge lattice
+    else:
+        e = 250.15 + 0.7 * np.arange(0, 17)                              # 16 bins in kelvin
+        cube = rng.normal(256, 5, (T, ny, nx))
+    cube = cube.astype(dtype)
+    flat = cube.reshape(-1)
+    pick = rng.choice(flat.size, 900, replace=False)
+    ee = rng.choice(e, 900)
+    flat[pick[:300]] = ee[:300].astype(dtype)                            # the nearest representable value of an edge
+    flat[pick[300:600]] = np.nextafter(ee[300:600].astype(dtype), dtype(np.inf))
+    flat[pick[600:880]] = np.nextafter(ee[600:880].astype(dtype), dtype(-np.inf))
+    flat[pick[880:890]] = np.nan
+    flat[pick[890:895]] = np.inf
+    flat[pick[895:900]] = -np.inf
+    bounds = np.array([0, 150, T], dtype=np.int64)
+    dda = [[e[i], e[i + 1], 0] for i in range(len(e) - 1)]
+    want = cport.block_bins(cube, bounds, dda).reshape(2, -1, len(dda))
+    d = torch_cuda.from_numpy(cube).cuda()
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    cols = [dict(inner="bins", inner_args=r) for r in dda]
+    for tuning in (0, 208, 104):                                         # default, two cells per lane, shallow prefetch
+        plan = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(3), cols, tuning=tuning)
+        if tuning == 0 or (tuning == 208 and dtype == np.float32):      # other arms are hints and may pick plain counters
+            assert "_hist" in plan.describe(), plan.describe()
+        got = plan.run_temporal(d).cpu().numpy()
+        np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want, err_msg=f"tuning {tuning}")
+    assert want.sum() > 0.5 * T * ny * nx * (0.3 if edges == "tenths" else 0.5)      # the bins really are populated
+
+
+def test_lds_histogram_is_refused_for_bins_narrower_than_the_data_resolution(torch_cuda):
+    """Bins much narrower than a float32 ulp of the edges cannot be guessed to within one bin in
+    float32: the plan falls back to the per-bin counters and stays exact."""
+    from aggfly_amd import hip
+    T, ny, nx = 64, 2, 32
+    rng = np.random.default_rng(6)
+    e = 300.0 + 1e-5 * np.arange(0, 9)
+    cube = (300.0 + rng.uniform(-2e-5, 1e-4, (T, ny, nx))).astype(np.float32)
+    bounds = np.array([0, T], dtype=np.int64)
+    dda = [[e[i], e[i + 1], 0] for i in range(8)]
+    plan = hip.FusedPlan(T, ny * nx, hip.F32, bounds, np.arange(2), [dict(inner="bins", inner_args=r) for r in dda])
+    assert "_hist" not in plan.describe()
+    got = plan.run_temporal(torch_cuda.from_numpy(cube).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), cport.block_bins(cube, bounds, dda).reshape(1, -1, 8))
+    plan64 = hip.FusedPlan(T, ny * nx, hip.F64, bounds, np.arange(2), [dict(inner="bins", inner_args=r) for r in dda])
+    # (at float64 the edges 300 + 1e-5*k are not equally spaced to 1e-9 of a width either: plain counters again)
+    c64 = cube.astype(np.float64)
+    got = plan64.run_temporal(torch_cuda.from_numpy(c64).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), cport.block_bins(c64, bounds, dda).reshape(1, -1, 8))
+
+
 def test_many_periods_and_grid_limits(torch_cuda):
     """More output periods than a grid dimension holds (daily single-level output of a long
     series: 70,000 periods) through both the cells-only and the panel path."""
