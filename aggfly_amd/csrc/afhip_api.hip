@@ -216,7 +216,7 @@ extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int
     int rc = launch_spmm(csr, panel, sums, Q, st);
     if (rc) return rc;
     {
-        const int64_t n = K * csr->R * nt;
+        const int64_t n = K > 0 ? csr->R * nt : 0;            // one thread per (region, time step)
         if (n) {
             hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, sums, num_dev, den_dev, res_dev, csr->R, nt, (int)K);
             HIP_TRY(hipGetLastError());
@@ -664,7 +664,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
     if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
     if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
-    const int64_t n = K * csr->R * P;
+    const int64_t n = K > 0 ? csr->R * P : 0;                 // one thread per (region, period)
     if (n) {
         hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, plan->sums, num_dev,
                            den_dev, res_dev, csr->R, P, (int)K);

@@ -200,6 +200,45 @@ def test_fused_plan_bins_of_daily_means_and_single_level(torch_cuda):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_single_level_plan_panel_matches_the_definition(torch_cuda, dtype):
+    """Single-level plan (every inner group is an output period) through combine + CSR + divide: same
+    num / den / res with and without the per-cell output, and equal to the definition — NaN cells void
+    a whole (cell, period) for every column, an empty period has no weight, float32 final rounding."""
+    from aggfly_amd import hip
+    T, ny, nx, R = 24 * 40, 5, 24, 7
+    rng = np.random.default_rng(21)
+    cube = _cube(T, ny, nx, dtype, seed=13)
+    cube[rng.integers(0, T, 40), rng.integers(0, ny, 40), rng.integers(0, nx, 40)] = np.nan     # sparse NaN steps
+    cube[:, 1, 3] = np.nan                                                                       # an "ocean" cell
+    ib = np.array([0, 24 * 10, 24 * 10, 24 * 25, T], dtype=np.int64)                             # 4 periods, one empty
+    cols = [dict(inner="mean", rounding=hip.ROUND_FINAL if dtype == np.float32 else 0), dict(inner="dd", inner_args=(10, 30, 0)),
+            dict(inner="bins", inner_args=(0, 15, 0)), dict(inner="nanmean"), dict(inner="max")]
+    C_ = ny * nx
+    rows = rng.integers(0, R, 3 * C_ // 2); ccols = rng.integers(0, C_, 3 * C_ // 2); w = rng.uniform(0.1, 1.0, 3 * C_ // 2)
+    order = np.argsort(rows, kind="stable")
+    csr = hip.CSR(rows[order], ccols[order], w[order], R, C_)
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    d = torch_cuda.from_numpy(cube).cuda()
+    plan = hip.FusedPlan(T, C_, code, ib, np.arange(5), cols)
+    assert "_sl" in plan.describe(), plan.describe()
+    direct = plan.run(d, csr)
+    twopass = plan.run(d, csr, want_cells=True)
+    for k in ("num", "den", "res"):
+        np.testing.assert_array_equal(direct[k].cpu().numpy(), twopass[k].cpu().numpy(), err_msg=k)
+    # and against the definition: shared validity, weighted sums in table order
+    cells = twopass["cells"].cpu().numpy()                        # [K, P, C]
+    valid = ~np.isnan(cells).any(axis=0)                          # [P, C]
+    den = np.zeros((R, 4)); num = np.zeros((len(cols), R, 4))
+    for r_, c_, w_ in zip(rows[order], ccols[order], w[order]):
+        den[r_] += w_ * valid[:, c_]
+        for k in range(len(cols)):
+            num[k, r_] += w_ * np.where(valid[:, c_], cells[k, :, c_], 0.0)
+    np.testing.assert_allclose(direct["den"].cpu().numpy(), den, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(direct["num"].cpu().numpy(), num, rtol=1e-12, atol=1e-12)
+    assert (den[:, 1] == 0).all() and np.isnan(direct["res"].cpu().numpy()[:, :, 1]).all()      # the empty period
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_every_load_path_arm_gives_identical_cells(torch_cuda, dtype):
     """Direct loads (1/2/4 cells per lane, 4/8 rows in flight) and the LDS-DMA ring (depth 4/8/16,
     nt and default cache policy) are the same arithmetic: cells must match bit for bit."""
