@@ -1,0 +1,151 @@
+"""ctypes binding of ``libaggfly_codec.so`` (aggfly_amd/csrc/blosc1.c): the host-side chunk codecs
+of the ingestion path — Blosc-1 containers (blosclz / lz4 / lz4hc / zlib / zstd, byte- and
+bit-shuffle), plain Zstandard frames, and a Blosc-LZ4 encoder for the writer side.
+
+The reference decodes chunks through numcodecs inside its dask graph
+(`aggfly/dataset/dataset.py:697-728`); here every chunk is decoded by native code on a host thread
+(ctypes drops the GIL), or a whole slab of chunks at once on an OpenMP team.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaggfly_codec.so")
+_lib = None
+
+CODEC_NAMES = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}
+
+
+class CodecError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CodecError(f"{LIB_PATH} is missing: build it with `make -C aggfly_amd/csrc codec` "
+                             "or `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_PATH)
+        lib.afcodec_last_error.restype = C.c_char_p
+        lib.afcodec_have.argtypes = [C.c_int]
+        lib.afcodec_blosc_info.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.afcodec_blosc_decode.restype = C.c_int64
+        lib.afcodec_blosc_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.afcodec_blosc_decode_many.argtypes = [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64)]
+        lib.afcodec_blosc_decode_files.argtypes = [C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                                   C.c_int, C.POINTER(C.c_int64)]
+        lib.afcodec_blosc_bound.restype = C.c_int64
+        lib.afcodec_blosc_bound.argtypes = [C.c_int64, C.c_int64]
+        lib.afcodec_blosc_encode_lz4.restype = C.c_int64
+        lib.afcodec_blosc_encode_lz4.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+        lib.afcodec_zstd_decode.restype = C.c_int64
+        lib.afcodec_zstd_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        _lib = lib
+    return _lib
+
+
+EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
+           "afcodec_blosc_decode_files",
+           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode")
+
+
+def _err(lib, what):
+    return CodecError(f"{what}: {lib.afcodec_last_error().decode()}")
+
+
+def _addr(buf):
+    """Address of a bytes-like object without copying it."""
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data, buf.nbytes
+    mv = memoryview(buf)
+    if mv.readonly:
+        return C.cast(C.c_char_p(bytes(buf) if not isinstance(buf, bytes) else buf), C.c_void_p).value, mv.nbytes
+    return C.addressof(C.c_char.from_buffer(mv)), mv.nbytes
+
+
+def blosc_info(buf) -> dict:
+    lib = load()
+    p, n = _addr(buf)
+    nb, bs, ts, fl = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+    if lib.afcodec_blosc_info(p, n, C.byref(nb), C.byref(bs), C.byref(ts), C.byref(fl)):
+        raise _err(lib, "blosc_info")
+    f = fl.value
+    return {"nbytes": nb.value, "blocksize": bs.value, "typesize": ts.value, "flags": f, "codec": CODEC_NAMES.get((f >> 5) & 7, "?"),
+            "shuffle": 1 if f & 1 else (2 if f & 4 else 0), "stored": bool(f & 2), "split": not (f & 0x10)}
+
+
+def blosc_decode(buf, out: np.ndarray | None = None) -> np.ndarray:
+    """Decode one Blosc-1 chunk; ``out`` (C-contiguous, >= nbytes) is filled in place when given."""
+    lib = load()
+    p, n = _addr(buf)
+    if out is None:
+        out = np.empty(blosc_info(buf)["nbytes"], dtype=np.uint8)
+    if not out.flags.c_contiguous:
+        raise ValueError("blosc_decode: out must be C-contiguous")
+    r = lib.afcodec_blosc_decode(p, n, out.ctypes.data, out.nbytes)
+    if r < 0:
+        raise _err(lib, "blosc_decode")
+    return out
+
+
+def blosc_decode_many(bufs, outs, threads: int = 8):
+    """Decode chunks ``bufs[i]`` into the C-contiguous arrays ``outs[i]`` on an OpenMP team."""
+    lib = load()
+    n = len(bufs)
+    keep = [b if isinstance(b, (bytes, np.ndarray)) else bytes(b) for b in bufs]
+    addrs = [_addr(b) for b in keep]
+    cp = (C.c_void_p * n)(*[a for a, _ in addrs])
+    cs = (C.c_int64 * n)(*[s for _, s in addrs])
+    dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ds = (C.c_int64 * n)(*[o.nbytes for o in outs])
+    res = (C.c_int64 * n)()
+    if lib.afcodec_blosc_decode_many(n, cp, cs, dp, ds, int(threads), res):
+        bad = [i for i in range(n) if res[i] < 0]
+        raise CodecError(f"blosc_decode_many: chunks {bad[:8]} failed: {lib.afcodec_last_error().decode()}")
+    return [int(res[i]) for i in range(n)]
+
+
+def blosc_decode_files(paths, outs, threads: int = 8):
+    """Read and decode the chunk files ``paths[i]`` into ``outs[i]`` on an OpenMP team.
+    -> list of decoded sizes; -100 marks a missing file (the caller applies the fill value)."""
+    lib = load()
+    n = len(paths)
+    pp = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ds = (C.c_int64 * n)(*[o.nbytes for o in outs])
+    res = (C.c_int64 * n)()
+    if lib.afcodec_blosc_decode_files(n, pp, dp, ds, int(threads), res):
+        bad = [paths[i] for i in range(n) if res[i] < 0 and res[i] != -100]
+        raise CodecError(f"blosc_decode_files: {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+    return [int(res[i]) for i in range(n)]
+
+
+def blosc_encode(data, typesize: int, shuffle: bool = True, blocksize: int = 0) -> bytes:
+    """Blosc-1 / LZ4 chunk of ``data`` (bytes-like or array): what numcodecs' ``Blosc(cname="lz4")`` reads."""
+    lib = load()
+    arr = np.ascontiguousarray(data) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    cap = lib.afcodec_blosc_bound(arr.nbytes, blocksize)
+    dst = np.empty(cap, dtype=np.uint8)
+    r = lib.afcodec_blosc_encode_lz4(arr.ctypes.data, arr.nbytes, int(typesize), 1 if shuffle else 0, int(blocksize), dst.ctypes.data, cap)
+    if r < 0:
+        raise _err(lib, "blosc_encode")
+    return dst[:r].tobytes()
+
+
+def zstd_decode(buf, nbytes: int, out: np.ndarray | None = None) -> np.ndarray:
+    """Decode one Zstandard frame of at most ``nbytes`` decoded bytes."""
+    lib = load()
+    p, n = _addr(buf)
+    if out is None:
+        out = np.empty(nbytes, dtype=np.uint8)
+    r = lib.afcodec_zstd_decode(p, n, out.ctypes.data, out.nbytes)
+    if r < 0:
+        raise _err(lib, "zstd_decode")
+    return out[:r] if r != out.nbytes and out.ndim == 1 else out

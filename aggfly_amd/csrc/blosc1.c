@@ -1,0 +1,382 @@
+/* blosc1.c — host-side chunk codec of the ingestion path.
+ *
+ * Zarr stores in the wild are compressed with Blosc-1 (numcodecs' default compressor is
+ * Blosc(cname="lz4", shuffle=SHUFFLE)); the reference decodes them through numcodecs inside its
+ * dask graph (aggfly/dataset/dataset.py:697-728), GIL-limited to ~2 cores
+ * (benchmarks/bench_read_scheduler.py:4-8).  This file decodes Blosc-1 chunks natively, one
+ * chunk per host thread, straight into the time-major staging buffer that is then copied to HBM.
+ *
+ * Blosc-1 container (c-blosc 1.x, format version 2), restated from the published format:
+ *   header  [0] version  [1] versionlz  [2] flags  [3] typesize  [4:8] nbytes  [8:12] blocksize
+ *           [12:16] cbytes (all little-endian)
+ *   flags   0x01 byte shuffle | 0x02 stored uncompressed ("memcpyed") | 0x04 bit shuffle |
+ *           0x10 blocks are not split into per-byte streams | bits 5-7: codec (0 blosclz, 1 lz4 /
+ *           lz4hc, 2 snappy, 3 zlib, 4 zstd)
+ *   then    int32 bstarts[nblocks]: offset of every block's data from the start of the chunk
+ *   block   nsplits streams (typesize streams when split, else 1), each: int32 csize, data;
+ *           csize == stream length means the stream is stored raw
+ *   the (un)shuffle acts per block; the last, shorter block is never split.
+ * Pinned against chunks produced by the real c-blosc 1.21 (tests/golden/blosc_fixtures.json).
+ *
+ * LZ4 / Zstandard come from the system's liblz4.so.1 / libzstd.so.1 (dlopen, stable C ABIs:
+ * LZ4_decompress_safe, LZ4_compress_default, ZSTD_decompress, ZSTD_isError), zlib is linked.
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#define AFCODEC_OK 0
+#define AFCODEC_E_FORMAT (-1)
+#define AFCODEC_E_UNSUPPORTED (-2)
+#define AFCODEC_E_SIZE (-3)
+#define AFCODEC_E_CODEC (-4)
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+const char* afcodec_last_error(void) { return g_err; }
+
+/* ---- lazily bound system codecs ---- */
+typedef int (*lz4_dec_fn)(const char*, char*, int, int);
+typedef int (*lz4_enc_fn)(const char*, char*, int, int);
+typedef int (*lz4_bound_fn)(int);
+typedef size_t (*zstd_dec_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserr_fn)(size_t);
+static lz4_dec_fn p_lz4_dec;
+static lz4_enc_fn p_lz4_enc;
+static lz4_bound_fn p_lz4_bound;
+static zstd_dec_fn p_zstd_dec;
+static zstd_iserr_fn p_zstd_iserr;
+static int g_lz4_tried, g_zstd_tried;
+
+static int need_lz4(void) {
+    if (!g_lz4_tried) {
+        void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            p_lz4_dec = (lz4_dec_fn)dlsym(h, "LZ4_decompress_safe");
+            p_lz4_enc = (lz4_enc_fn)dlsym(h, "LZ4_compress_default");
+            p_lz4_bound = (lz4_bound_fn)dlsym(h, "LZ4_compressBound");
+        }
+        g_lz4_tried = 1;
+    }
+    return (p_lz4_dec && p_lz4_enc && p_lz4_bound) ? 0 : fail(AFCODEC_E_UNSUPPORTED, "liblz4.so.1 not available");
+}
+static int need_zstd(void) {
+    if (!g_zstd_tried) {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            p_zstd_dec = (zstd_dec_fn)dlsym(h, "ZSTD_decompress");
+            p_zstd_iserr = (zstd_iserr_fn)dlsym(h, "ZSTD_isError");
+        }
+        g_zstd_tried = 1;
+    }
+    return (p_zstd_dec && p_zstd_iserr) ? 0 : fail(AFCODEC_E_UNSUPPORTED, "libzstd.so.1 not available");
+}
+int afcodec_have(int codec) { /* 1 lz4, 3 zlib, 4 zstd, 0 blosclz */
+    if (codec == 1) return need_lz4() == 0;
+    if (codec == 4) return need_zstd() == 0;
+    return codec == 0 || codec == 3;
+}
+
+static uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static void put32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+/* ---- BloscLZ (the FastLZ-derived codec shipped inside c-blosc 1.x) ---- */
+static int blosclz_decode(const uint8_t* ip, int length, uint8_t* out, int maxout) {
+    const uint8_t* ip_limit = ip + length;
+    uint8_t* op = out;
+    uint8_t* op_limit = out + maxout;
+    if (length == 0) return 0;
+    uint32_t ctrl = (*ip++) & 31u;
+    for (;;) {
+        if (ctrl >= 32) {                                   /* match: length in the top 3 bits, distance below */
+            int32_t len = (int32_t)(ctrl >> 5) - 1;
+            int32_t ofs = (int32_t)((ctrl & 31u) << 8);
+            const uint8_t* ref = op - ofs;
+            uint8_t code;
+            if (len == 7 - 1) {
+                do {
+                    if (ip + 1 >= ip_limit) return -1;
+                    code = *ip++;
+                    len += code;
+                } while (code == 255);
+            } else if (ip + 1 >= ip_limit) {
+                return -1;
+            }
+            code = *ip++;
+            len += 3;
+            ref -= code;
+            if (code == 255 && ofs == (31 << 8)) {          /* far match: 16-bit distance beyond 8191 */
+                if (ip + 1 >= ip_limit) return -1;
+                ofs = (*ip++) << 8;
+                ofs += *ip++;
+                ref = op - ofs - 8191;
+            }
+            if (op + len > op_limit) return -1;
+            if (ref - 1 < out) return -1;
+            const int last = ip >= ip_limit;
+            if (!last) ctrl = *ip++;
+            ref--;
+            for (int32_t i = 0; i < len; ++i) op[i] = ref[i];      /* byte-wise: overlapping runs repeat */
+            op += len;
+            if (last) break;
+        } else {                                            /* literal run of ctrl + 1 bytes */
+            ctrl++;
+            if (op + ctrl > op_limit || ip + ctrl > ip_limit) return -1;
+            memcpy(op, ip, ctrl);
+            op += ctrl;
+            ip += ctrl;
+            if (ip >= ip_limit) break;
+            ctrl = *ip++;
+        }
+    }
+    return (int)(op - out);
+}
+
+/* ---- shuffle filters, per block ---- */
+static void unshuffle_bytes(int ts, int64_t bsize, const uint8_t* src, uint8_t* dst) {
+    const int64_t n = bsize / ts, rem = bsize % ts;
+    if (ts == 4) {
+        const uint8_t *s0 = src, *s1 = src + n, *s2 = src + 2 * n, *s3 = src + 3 * n;
+        for (int64_t i = 0; i < n; ++i) { dst[4 * i] = s0[i]; dst[4 * i + 1] = s1[i]; dst[4 * i + 2] = s2[i]; dst[4 * i + 3] = s3[i]; }
+    } else if (ts == 8) {
+        for (int64_t i = 0; i < n; ++i)
+            for (int j = 0; j < 8; ++j) dst[8 * i + j] = src[(int64_t)j * n + i];
+    } else {
+        for (int64_t i = 0; i < n; ++i)
+            for (int j = 0; j < ts; ++j) dst[i * ts + j] = src[(int64_t)j * n + i];
+    }
+    if (rem) memcpy(dst + bsize - rem, src + bsize - rem, (size_t)rem);
+}
+static void shuffle_bytes(int ts, int64_t bsize, const uint8_t* src, uint8_t* dst) {
+    const int64_t n = bsize / ts, rem = bsize % ts;
+    for (int j = 0; j < ts; ++j)
+        for (int64_t i = 0; i < n; ++i) dst[(int64_t)j * n + i] = src[i * ts + j];
+    if (rem) memcpy(dst + bsize - rem, src + bsize - rem, (size_t)rem);
+}
+/* Bit shuffle: bit b (byte j = b / 8, LSB-first) of element e is stored in bit row b at bit e.
+ * c-blosc 1.x bit-shuffles a block only when it holds a multiple of 8 elements; any other block
+ * (typically the short last one) is stored unshuffled (pinned by the 1.21 fixtures). */
+static void unshuffle_bits(int ts, int64_t bsize, const uint8_t* src, uint8_t* dst) {
+    const int64_t n = bsize / ts;
+    if (n % 8 != 0) { memcpy(dst, src, (size_t)bsize); return; }
+    const int64_t nrow = n / 8;
+    for (int64_t g = 0; g < nrow; ++g) {                    /* 8 elements at a time */
+        for (int j = 0; j < ts; ++j) {
+            uint64_t x = 0;                                 /* byte k of x = bit row (8j + k), byte g */
+            for (int k = 0; k < 8; ++k) x |= (uint64_t)src[((int64_t)j * 8 + k) * nrow + g] << (8 * k);
+            /* 8x8 bit-matrix transpose (Hacker's Delight 7-3) */
+            uint64_t t;
+            t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAULL;  x = x ^ t ^ (t << 7);
+            t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCULL; x = x ^ t ^ (t << 14);
+            t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ULL; x = x ^ t ^ (t << 28);
+            for (int m = 0; m < 8; ++m) dst[(g * 8 + m) * ts + j] = (uint8_t)(x >> (8 * m));
+        }
+    }
+    const int64_t off = n * ts;
+    if (bsize > off) memcpy(dst + off, src + off, (size_t)(bsize - off));
+}
+
+/* ---- chunk header ---- */
+int afcodec_blosc_info(const void* chunk, int64_t size, int64_t* nbytes, int64_t* blocksize, int32_t* typesize, int32_t* flags) {
+    const uint8_t* c = (const uint8_t*)chunk;
+    if (!c || size < 16) return fail(AFCODEC_E_FORMAT, "blosc chunk shorter than its 16-byte header");
+    if (c[0] != 2) return fail(AFCODEC_E_UNSUPPORTED, "blosc format version is not 2 (Blosc-1)");
+    if (nbytes) *nbytes = le32(c + 4);
+    if (blocksize) *blocksize = le32(c + 8);
+    if (typesize) *typesize = c[3];
+    if (flags) *flags = c[2];
+    if ((int64_t)le32(c + 12) > size) return fail(AFCODEC_E_SIZE, "blosc chunk is truncated (cbytes > size)");
+    return AFCODEC_OK;
+}
+
+static int decode_stream(int codec, const uint8_t* src, int32_t csize, uint8_t* dst, int32_t want) {
+    int got = -1;
+    switch (codec) {
+        case 0: got = blosclz_decode(src, csize, dst, want); break;
+        case 1: got = p_lz4_dec((const char*)src, (char*)dst, csize, want); break;
+        case 3: { uLongf n = (uLongf)want; got = uncompress(dst, &n, src, (uLong)csize) == Z_OK ? (int)n : -1; break; }
+        case 4: { size_t n = p_zstd_dec(dst, (size_t)want, src, (size_t)csize); got = p_zstd_iserr(n) ? -1 : (int)n; break; }
+        default: break;
+    }
+    return got == want ? 0 : -1;
+}
+
+static __thread uint8_t* t_scratch;
+static __thread int64_t t_scratch_cap;
+
+/* Decodes one chunk into dst (capacity dstsize); returns the number of bytes written or < 0. */
+int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64_t dstsize) {
+    const uint8_t* c = (const uint8_t*)chunk;
+    uint8_t* dst = (uint8_t*)dstv;
+    int64_t nbytes, blocksize;
+    int32_t ts, flags;
+    int rc = afcodec_blosc_info(chunk, csize, &nbytes, &blocksize, &ts, &flags);
+    if (rc) return rc;
+    if (nbytes > dstsize) return fail(AFCODEC_E_SIZE, "destination smaller than the chunk's nbytes");
+    if (nbytes == 0) return 0;
+    const int64_t cbytes = le32(c + 12);
+    if (flags & 0x02) {
+        if (cbytes < 16 + nbytes) return fail(AFCODEC_E_FORMAT, "stored chunk shorter than nbytes");
+        memcpy(dst, c + 16, (size_t)nbytes);
+        return nbytes;
+    }
+    const int codec = (flags >> 5) & 7;
+    if (codec == 1) { if ((rc = need_lz4())) return rc; }
+    else if (codec == 4) { if ((rc = need_zstd())) return rc; }
+    else if (codec != 0 && codec != 3) return fail(AFCODEC_E_UNSUPPORTED, "blosc codec not supported (snappy)");
+    if (blocksize <= 0 || ts <= 0) return fail(AFCODEC_E_FORMAT, "bad blocksize / typesize");
+    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const int64_t leftover = nbytes % blocksize;
+    if (16 + 4 * nblocks > cbytes) return fail(AFCODEC_E_FORMAT, "block table beyond the chunk");
+    const int dont_split = (flags >> 4) & 1;
+    const int want_shuffle = (flags & 0x01) && ts > 1;
+    uint8_t* tmp = NULL;
+    if (want_shuffle || (flags & 0x04)) {
+        /* per-thread scratch, kept between calls: a fresh malloc of a block (>= 128 KiB -> mmap/munmap)
+         * per chunk page-faults every time and serialises the threads on the process's mmap lock */
+        if (t_scratch_cap < blocksize) {
+            free(t_scratch);
+            t_scratch = (uint8_t*)malloc((size_t)blocksize);
+            t_scratch_cap = t_scratch ? blocksize : 0;
+        }
+        tmp = t_scratch;
+        if (!tmp) return fail(AFCODEC_E_SIZE, "out of memory");
+    }
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int last_short = (b == nblocks - 1) && leftover > 0;
+        const int64_t bsize = last_short ? leftover : blocksize;
+        const int do_shuf = want_shuffle;
+        const int do_bits = !do_shuf && (flags & 0x04) && bsize >= ts;
+        uint8_t* out = dst + b * blocksize;
+        uint8_t* into = (do_shuf || do_bits) ? tmp : out;
+        int nsplits = 1;
+        if (!dont_split && ts <= 16 && blocksize / ts >= 128 && !last_short) nsplits = ts;
+        const int64_t neblock = bsize / nsplits;
+        const int64_t start = (int64_t)(int32_t)le32(c + 16 + 4 * b);
+        if (start < 16 + 4 * nblocks || start >= cbytes) { return fail(AFCODEC_E_FORMAT, "block offset out of range"); }
+        const uint8_t* src = c + start;
+        for (int j = 0; j < nsplits; ++j) {
+            if (src + 4 > c + cbytes) { return fail(AFCODEC_E_FORMAT, "stream header beyond the chunk"); }
+            const int32_t sz = (int32_t)le32(src);
+            src += 4;
+            if (sz < 0 || src + sz > c + cbytes) { return fail(AFCODEC_E_FORMAT, "stream beyond the chunk"); }
+            if (sz == neblock) memcpy(into + j * neblock, src, (size_t)neblock);
+            else if (decode_stream(codec, src, sz, into + j * neblock, (int32_t)neblock)) {
+                return fail(AFCODEC_E_CODEC, "block failed to decompress to its recorded size");
+            }
+            src += sz;
+        }
+        if (do_shuf) unshuffle_bytes(ts, bsize, tmp, out);
+        else if (do_bits) unshuffle_bits(ts, bsize, tmp, out);
+    }
+    return nbytes;
+}
+
+/* Many chunks at once, one per OpenMP thread (ctypes releases the GIL around this call). */
+int afcodec_blosc_decode_many(int64_t n, const void* const* chunks, const int64_t* csizes, void* const* dsts,
+                              const int64_t* dstsizes, int nthreads, int64_t* results) {
+    int bad = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : bad)
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = afcodec_blosc_decode(chunks[i], csizes[i], dsts[i], dstsizes[i]);
+        results[i] = r;
+        if (r < 0) bad += 1;
+    }
+    return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
+}
+
+/* The same, reading each chunk file inside the worker (no Python between chunks): paths[i] -> dsts[i].
+ * A missing file leaves results[i] = -100 (the caller fills the Zarr fill value). */
+int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                               int nthreads, int64_t* results) {
+    int bad = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : bad)
+    {
+        uint8_t* buf = NULL;
+        int64_t cap = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t i = 0; i < n; ++i) {
+            FILE* f = fopen(paths[i], "rb");
+            if (!f) { results[i] = -100; continue; }
+            fseek(f, 0, SEEK_END);
+            const int64_t sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz > cap) { free(buf); buf = (uint8_t*)malloc((size_t)sz + 64); cap = buf ? sz : 0; }
+            int64_t r;
+            if (!buf || (int64_t)fread(buf, 1, (size_t)sz, f) != sz) r = fail(AFCODEC_E_FORMAT, "chunk file could not be read");
+            else r = afcodec_blosc_decode(buf, sz, dsts[i], dstsizes[i]);
+            fclose(f);
+            results[i] = r;
+            if (r < 0) bad += 1;
+        }
+        free(buf);
+    }
+    return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files failed to decode (see results[])") : AFCODEC_OK;
+}
+
+/* Encoder for the writer side (dataset_to_zarr, synthetic stores of the ingestion benchmark):
+ * LZ4, byte shuffle on request, blocks never split.  Readable by any Blosc-1 decoder. */
+int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize) {
+    if (blocksize <= 0) blocksize = 1 << 18;
+    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    return 16 + nblocks * 8 + nbytes + nbytes / 255 + 64;
+}
+int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
+                                 void* dstv, int64_t cap) {
+    const uint8_t* src = (const uint8_t*)srcv;
+    uint8_t* dst = (uint8_t*)dstv;
+    int rc = need_lz4();
+    if (rc) return rc;
+    if (nbytes < 0 || nbytes > 0x7fffffffLL - 64 || typesize < 1 || typesize > 255) return fail(AFCODEC_E_SIZE, "bad nbytes / typesize");
+    if (blocksize <= 0) blocksize = 1 << 18;
+    blocksize -= blocksize % typesize;
+    if (blocksize < typesize) blocksize = typesize;
+    if (blocksize > nbytes && nbytes > 0) blocksize = nbytes;
+    if (cap < afcodec_blosc_bound(nbytes, blocksize)) return fail(AFCODEC_E_SIZE, "destination smaller than afcodec_blosc_bound()");
+    const int do_shuf = shuffle && typesize > 1;
+    dst[0] = 2; dst[1] = 1; dst[3] = (uint8_t)typesize;
+    put32(dst + 4, (uint32_t)nbytes);
+    if (nbytes < 128) {                                      /* tiny buffers are stored */
+        dst[2] = 0x02 | (do_shuf ? 0x01 : 0) | (1 << 5) | 0x10;
+        put32(dst + 8, (uint32_t)(nbytes ? nbytes : typesize));
+        memcpy(dst + 16, src, (size_t)nbytes);
+        put32(dst + 12, (uint32_t)(16 + nbytes));
+        return 16 + nbytes;
+    }
+    dst[2] = (uint8_t)((do_shuf ? 0x01 : 0) | 0x10 | (1 << 5));
+    put32(dst + 8, (uint32_t)blocksize);
+    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    uint8_t* tmp = do_shuf ? (uint8_t*)malloc((size_t)blocksize) : NULL;
+    if (do_shuf && !tmp) return fail(AFCODEC_E_SIZE, "out of memory");
+    int64_t pos = 16 + 4 * nblocks;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int64_t bsize = (b == nblocks - 1) ? nbytes - b * blocksize : blocksize;
+        const uint8_t* in = src + b * blocksize;
+        if (do_shuf) { shuffle_bytes(typesize, bsize, in, tmp); in = tmp; }
+        put32(dst + 16 + 4 * b, (uint32_t)pos);
+        int csz = p_lz4_enc((const char*)in, (char*)dst + pos + 4, (int)bsize, (int)(bsize - 1));   /* 0 if it does not shrink */
+        if (csz <= 0) { memcpy(dst + pos + 4, in, (size_t)bsize); csz = (int)bsize; }
+        put32(dst + pos, (uint32_t)csz);
+        pos += 4 + csz;
+    }
+    free(tmp);
+    put32(dst + 12, (uint32_t)pos);
+    return pos;
+}
+
+/* Plain Zstandard frames (Zarr compressor id "zstd"). */
+int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap) {
+    int rc = need_zstd();
+    if (rc) return rc;
+    const size_t got = p_zstd_dec(dst, (size_t)cap, src, (size_t)n);
+    if (p_zstd_iserr(got)) return fail(AFCODEC_E_CODEC, "zstd frame failed to decode");
+    return (int64_t)got;
+}

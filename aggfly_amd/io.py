@@ -6,8 +6,8 @@ to time-contiguous Zarr with `dataset_to_zarr` / `zarr_from_path`
 or on the GPU box, so this module reads what can be read with numpy + the standard
 library:
 
-* Zarr v2 directory stores: C-order chunks, ``compressor`` null / zlib / gzip (and blosc or
-  zstd when the ``blosc`` / ``zstandard`` module happens to be importable), ``_ARRAY_DIMENSIONS``
+* Zarr v2 directory stores: C-order chunks, ``compressor`` null / zlib / gzip / blosc (every
+  Blosc-1 codec and shuffle, decoded natively by ``csrc/blosc1.c``) / zstd, ``_ARRAY_DIMENSIONS``
   attributes, CF time decoding (``units`` + ``calendar``; non-standard calendars go to
   ``cfcalendar``), ``scale_factor`` / ``add_offset`` / ``_FillValue``;
 * ``.npz`` bundles with ``data``, ``time``, ``latitude``, ``longitude``;
@@ -51,7 +51,8 @@ def _looks_like_zarr(path, storage_options=None) -> bool:
 # --------------------------------------------------------------------------------------
 # Zarr v2
 # --------------------------------------------------------------------------------------
-def _decompress(buf: bytes, comp) -> bytes:
+def _decompress(buf: bytes, comp, nbytes: Optional[int] = None):
+    """Decoded bytes of one chunk.  ``nbytes`` = decoded size when known (needed for zstd frames)."""
     if comp is None:
         return buf
     cid = comp.get("id")
@@ -60,18 +61,13 @@ def _decompress(buf: bytes, comp) -> bytes:
     if cid == "gzip":
         return gzip.decompress(buf)
     if cid == "blosc":
-        try:
-            import blosc
-        except ImportError as e:
-            raise ImportError("this Zarr store is blosc-compressed and the 'blosc' module is not installed; "
-                              "re-encode it with zlib or no compressor (dataset_to_zarr does)") from e
-        return blosc.decompress(buf)
+        from . import codec
+        return codec.blosc_decode(buf)               # native Blosc-1 decoder (csrc/blosc1.c), GIL released
     if cid == "zstd":
-        try:
-            import zstandard
-        except ImportError as e:
-            raise ImportError("this Zarr store is zstd-compressed and 'zstandard' is not installed") from e
-        return zstandard.ZstdDecompressor().decompress(buf)
+        from . import codec
+        if nbytes is None:
+            raise ValueError("zstd chunks need the decoded size")
+        return codec.zstd_decode(buf, nbytes)
     raise ValueError(f"unsupported Zarr compressor {cid!r}")
 
 
@@ -109,7 +105,7 @@ class ZarrArray:
             fv = np.nan if fill in (None, "NaN") and self.dtype.kind == "f" else (0 if fill is None else fill)
             return np.full(self.chunks, fv, dtype=self.dtype)
         with open(fn, "rb") as f:
-            raw = _decompress(f.read(), self.meta.get("compressor"))
+            raw = _decompress(f.read(), self.meta.get("compressor"), int(np.prod(self.chunks)) * self.dtype.itemsize)
         return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
 
     def read(self, out: Optional[np.ndarray] = None, threads: int = 8) -> np.ndarray:
@@ -142,33 +138,52 @@ class ZarrArray:
 # --------------------------------------------------------------------------------------
 # host -> HBM streaming
 # --------------------------------------------------------------------------------------
+_PINNED_STAGE = {}      # (nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
+
+
+def _pinned_stage(nbytes: int, count: int):
+    """``count`` page-locked host buffers of >= nbytes, cached for the life of the process (the CLI's
+    year loop and every later dataset reuse them).  Pinning costs ~0.1 s per GB, which is why a
+    per-call pinned buffer measured slower than a pageable one; a cached one makes the H2D copy
+    truly asynchronous, so slab i uploads at PCIe rate while slab i+1 decodes."""
+    import torch
+    size = 1 << max(20, (int(nbytes) - 1).bit_length())
+    bufs = _PINNED_STAGE.setdefault(size, [])
+    while len(bufs) < count:
+        bufs.append(torch.empty(size, dtype=torch.uint8, pin_memory=True))
+    return bufs[:count]
+
+
 def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: int, device="cuda", post=None):
-    """Fill a (T, *spatial) HBM tensor slab by slab through two host staging buffers.
+    """Fill a (T, *spatial) HBM tensor slab by slab through two cached page-locked staging buffers.
 
     ``read_slab(k0, k1, out)`` fills ``out[:k1-k0]`` with time steps [k0, k1) (a Zarr chunk
     decode on host threads).  The upload of slab i is queued on its own HIP stream while slab
-    i+1 is decoded, and the host never holds a second full copy of the cube.  Staging buffers are
-    ordinary pageable arrays: on this platform a pageable H2D copy already runs at ~56 GB/s
-    (measured, profiles/r01_ingest_bench.json) while pinning fresh buffers per call costs more
-    than it saves, and decode (1-8 GB/s) is the bound either way."""
+    i+1 is decoded, and the host never holds a second full copy of the cube.  Measured on the
+    MI355X box (16 host cores, `profiles/r01_ingest_bench.json`): native Blosc decode 66 GB/s,
+    pageable H2D 56 GB/s."""
     import torch
-    tdt = {np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64}[np.dtype(np_dtype)]
+    np_dtype = np.dtype(np_dtype)
+    tdt = {np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64}[np_dtype]
     cube = torch.empty((T,) + tuple(spatial), dtype=tdt, device=device)
     if T == 0:
         return cube
     slab_steps = max(1, min(slab_steps, T))
-    stage = [np.empty((slab_steps,) + tuple(spatial), dtype=np_dtype) for _ in range(2 if T > slab_steps else 1)]
+    row = int(np.prod(spatial)) * np_dtype.itemsize
+    nstage = 2 if T > slab_steps else 1
+    stage_t = [b[:slab_steps * row].view(tdt).reshape((slab_steps,) + tuple(spatial)) for b in _pinned_stage(slab_steps * row, nstage)]
+    stage = [t.numpy() for t in stage_t]
     copy_stream = torch.cuda.Stream(device=device)
     done = [None, None]
     for i, k0 in enumerate(range(0, T, slab_steps)):
         k1 = min(T, k0 + slab_steps)
-        b = i % len(stage)
+        b = i % nstage
         if done[b] is not None:
             done[b].synchronize()                       # staging buffer b is free again
         read_slab(k0, k1, stage[b])
         with torch.cuda.stream(copy_stream):
             dst = cube[k0:k1]
-            dst.copy_(torch.from_numpy(stage[b][:k1 - k0]), non_blocking=True)
+            dst.copy_(stage_t[b][:k1 - k0], non_blocking=True)
             if post is not None:
                 post(dst)                                # e.g. fill-value masking, applied in HBM
             ev = torch.cuda.Event()
@@ -179,7 +194,7 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     return cube
 
 
-def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 512 << 20):
+def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20):
     """Decode a time-major Zarr v2 array straight into HBM: each slab is a whole number of
     time chunks, decoded chunk-parallel on host threads into pinned memory and uploaded while
     the next slab decodes.  Returns (tensor, ZarrArray)."""
@@ -190,12 +205,43 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
         raise ValueError("packed integer stores go through dataset_from_path (host decode), not the streaming path")
     T, ny, nx = za.shape
     tc = za.chunks[0]
-    slab = max(tc, (slab_bytes // max(ny * nx * za.dtype.itemsize, 1)) // tc * tc)
     grid_yx = [(iy, ix) for iy in range((ny + za.chunks[1] - 1) // za.chunks[1]) for ix in range((nx + za.chunks[2] - 1) // za.chunks[2])]
+    # a slab is a whole number of time chunks: ~slab_bytes, but never fewer chunks than decode threads
+    slab = max(tc * -(-threads // len(grid_yx)), (slab_bytes // max(ny * nx * za.dtype.itemsize, 1)) // tc * tc)
 
     pool = ThreadPoolExecutor(max_workers=threads) if threads > 1 else None
 
+    comp = za.meta.get("compressor")
+    whole_rows = za.chunks[1] >= ny and za.chunks[2] >= nx and za.chunks[1] == ny and za.chunks[2] == nx
+
+    def read_blosc_slab(k0, k1, out):
+        """Time-contiguous store (every chunk spans the whole grid): each Blosc chunk decodes straight
+        into its rows of the staging slab, all chunks of the slab on one OpenMP team — no per-chunk
+        temporary, no Python between chunks."""
+        from . import codec
+        its = list(range(k0 // tc, (k1 + tc - 1) // tc))
+        paths, outs, spans, tails = [], [], [], []
+        for it in its:
+            t0, t1 = it * tc, min((it + 1) * tc, T)
+            paths.append(os.path.join(za.path, za.sep.join((str(it), "0", "0"))))
+            spans.append((t0, t1))
+            if t1 - t0 == tc:
+                outs.append(out[t0 - k0:t1 - k0])
+                tails.append(None)
+            else:                                   # the last, padded chunk: decode beside, copy the real steps
+                tmp = np.empty((tc, ny, nx), dtype=za.dtype)
+                outs.append(tmp)
+                tails.append(tmp)
+        res = codec.blosc_decode_files(paths, outs, threads=threads)
+        for (t0, t1), r, tmp in zip(spans, res, tails):
+            if r == -100:                           # absent chunk = fill value
+                out[t0 - k0:t1 - k0] = np.nan
+            elif tmp is not None:
+                out[t0 - k0:t1 - k0] = tmp[:t1 - t0]
+
     def read(k0, k1, out):
+        if whole_rows and comp is not None and comp.get("id") == "blosc" and out.flags.c_contiguous:
+            return read_blosc_slab(k0, k1, out)
         jobs = [(it, iy, ix) for it in range(k0 // tc, (k1 + tc - 1) // tc) for (iy, ix) in grid_yx]
 
         def work(j):
@@ -287,6 +333,12 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor):
         raw = blk.tobytes()
         if compressor and compressor["id"] == "zlib":
             raw = zlib.compress(raw, compressor.get("level", 1))
+        elif compressor and compressor["id"] == "blosc":
+            from . import codec
+            raw = codec.blosc_encode(blk, data.dtype.itemsize, shuffle=compressor.get("shuffle", 1) == 1,
+                                     blocksize=compressor.get("blocksize", 0))
+        elif compressor:
+            raise ValueError(f"cannot write Zarr compressor {compressor['id']!r}")
         with open(os.path.join(d, ".".join(str(i) for i in idx)), "wb") as f:
             f.write(raw)
 
@@ -313,8 +365,10 @@ def _auto_chunks(sizes: dict, itemsize: int, target_mb: float = 256) -> dict:
     return {"time": int(min(max(1, budget // (side * side)), nt)), "latitude": side, "longitude": side}
 
 
-def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress: bool = True, mode: str = "w"):
-    """`dataset_to_zarr` (`zarr_convert.py:50-121`): write a time-major, time-contiguous store."""
+def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress=True, mode: str = "w"):
+    """`dataset_to_zarr` (`zarr_convert.py:50-121`): write a time-major, time-contiguous store.
+    ``compress``: True / "blosc" -> Blosc-1 LZ4 + byte shuffle (what zarr-python 2 / numcodecs write by
+    default and read back), "zlib" -> zlib level 1, False -> raw chunks."""
     cube = dataset.cube()
     if not isinstance(cube, np.ndarray):
         cube = cube.cpu().numpy()
@@ -324,7 +378,14 @@ def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, 
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, ".zgroup"), "w") as f:
         json.dump({"zarr_format": 2}, f)
-    comp = {"id": "zlib", "level": 1} if compress else None
+    if compress in (True, "blosc"):
+        comp = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+    elif compress == "zlib":
+        comp = {"id": "zlib", "level": 1}
+    elif not compress:
+        comp = None
+    else:
+        raise ValueError(f"compress must be True, False, 'blosc' or 'zlib', got {compress!r}")
     _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp)
     tv, tattrs = _encode_time(dataset.time)
     _write_array(path, "time", np.asarray(tv, dtype=np.float64), ("time",), (len(tv),), tattrs, None)

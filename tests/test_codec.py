@@ -1,0 +1,132 @@
+"""Host-side chunk codecs of the ingestion path (aggfly_amd/csrc/blosc1.c) against chunks written by
+the REAL c-blosc 1.21 (tests/golden/blosc_fixtures.json, made by tests/golden/make_blosc_fixtures.py),
+and the Zarr reader on stores built from those chunks.  CPU only."""
+import base64
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_blosc_fixtures import recipe          # noqa: E402  (seeded numpy recipes of the raw arrays)
+
+from aggfly_amd import codec, io as afio        # noqa: E402
+
+FIX = json.load(open(os.path.join(HERE, "golden", "blosc_fixtures.json")))
+CASES = FIX["cases"]
+
+
+def _id(c):
+    return f"{c['cname']}-s{c['shuffle']}-{c['dtype'][1:]}-{c['recipe']}-{c['n']}-b{c['blocksize']}-l{c['clevel']}"
+
+
+def test_library_exports_every_symbol():
+    lib = codec.load()
+    assert all(hasattr(lib, s) for s in codec.EXPORTS)
+    assert lib.afcodec_have(1) and lib.afcodec_have(4) and lib.afcodec_have(3) and lib.afcodec_have(0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=_id)
+def test_decodes_real_cblosc_chunks_bit_exact(case):
+    chunk = base64.b64decode(case["chunk_b64"])
+    raw = recipe(case["recipe"], case["n"], case["dtype"], case["seed"])
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == case["sha256"]          # the recipe still yields the fixture's input
+    info = codec.blosc_info(chunk)
+    assert info["nbytes"] == raw.nbytes and info["typesize"] == raw.dtype.itemsize
+    assert info["codec"] == {"lz4hc": "lz4"}.get(case["cname"], case["cname"]) or info["stored"]
+    out = codec.blosc_decode(chunk)
+    assert out.tobytes() == raw.tobytes()
+    into = np.empty(raw.shape, dtype=raw.dtype)                                 # straight into a typed destination
+    codec.blosc_decode(chunk, into)
+    assert into.tobytes() == raw.tobytes()
+
+
+def test_decode_many_on_threads():
+    chunks = [base64.b64decode(c["chunk_b64"]) for c in CASES]
+    outs = [np.empty(c["nbytes"], dtype=np.uint8) for c in CASES]
+    res = codec.blosc_decode_many(chunks, outs, threads=4)
+    assert res == [c["nbytes"] for c in CASES]
+    assert all(hashlib.sha256(o.tobytes()).hexdigest() == c["sha256"] for o, c in zip(outs, CASES))
+
+
+def test_damaged_chunks_are_refused_not_crashed_on():
+    chunk = base64.b64decode(next(c for c in CASES if c["cname"] == "lz4" and c["n"] == 40000)["chunk_b64"])
+    with pytest.raises(codec.CodecError):
+        codec.blosc_decode(chunk[:10])                                          # shorter than the header
+    with pytest.raises(codec.CodecError):
+        codec.blosc_decode(chunk[:len(chunk) // 2])                             # truncated
+    bad = bytearray(chunk); bad[0] = 9
+    with pytest.raises(codec.CodecError):
+        codec.blosc_decode(bytes(bad))                                          # unknown format version
+    bad = bytearray(chunk); bad[16:20] = (2 ** 31 - 1).to_bytes(4, "little")
+    with pytest.raises(codec.CodecError):
+        codec.blosc_decode(bytes(bad))                                          # block offset out of range
+    bad = bytearray(chunk); bad[len(bad) // 2:len(bad) // 2 + 64] = os.urandom(64)
+    try:
+        out = codec.blosc_decode(bytes(bad))                                    # garbage payload: error or wrong bytes, never a fault
+        assert out.nbytes == 160000
+    except codec.CodecError:
+        pass
+    with pytest.raises(codec.CodecError):
+        codec.blosc_decode(chunk, np.empty(100, dtype=np.uint8))                # destination too small
+
+
+@pytest.mark.parametrize("dtype,n,shuffle,blocksize", [("<f4", 100000, True, 0), ("<f8", 33333, True, 65536), ("<f4", 17, True, 0),
+                                                        ("<i2", 5000, False, 4096), ("<f4", 70001, True, 10000), ("<f4", 0, True, 0)])
+def test_encoder_round_trip_and_real_cblosc_reads_it(dtype, n, shuffle, blocksize):
+    rng = np.random.default_rng(n)
+    x = (280 + 10 * np.sin(np.arange(n) / 50) + rng.normal(0, 0.3, n)).astype(dtype)
+    enc = codec.blosc_encode(x, x.dtype.itemsize, shuffle, blocksize)
+    assert codec.blosc_decode(enc).tobytes() == x.tobytes()
+    if n > 1000:
+        assert len(enc) < x.nbytes                                              # it does compress
+    real = "/opt/conda/lib/libblosc.so.1"                                       # present in the build container only
+    if os.path.exists(real) and n:
+        lib = C.CDLL(real)
+        back = C.create_string_buffer(x.nbytes)
+        assert lib.blosc_decompress_ctx(enc, back, x.nbytes, 1) == x.nbytes and back.raw == x.tobytes()
+
+
+def _zarr_v2_from_chunks(path, name, shape, chunks, dtype, compressor, files, dims):
+    d = os.path.join(path, name)
+    os.makedirs(d, exist_ok=True)
+    json.dump({"zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": dtype, "compressor": compressor,
+               "fill_value": "NaN", "order": "C", "filters": None}, open(os.path.join(d, ".zarray"), "w"))
+    json.dump({"_ARRAY_DIMENSIONS": list(dims)}, open(os.path.join(d, ".zattrs"), "w"))
+    for key, blob in files.items():
+        open(os.path.join(d, key), "wb").write(blob)
+
+
+@pytest.mark.parametrize("cname,shuffle", [("lz4", 1), ("zstd", 1), ("blosclz", 1), ("zlib", 2), ("lz4hc", 0)])
+def test_zarr_store_made_of_real_cblosc_chunks(tmp_path, cname, shuffle):
+    """A Zarr v2 array whose chunk files are byte-for-byte what numcodecs' Blosc would have written."""
+    case = next(c for c in CASES if c["cname"] == cname and c["shuffle"] == shuffle and c["dtype"] == "<f4" and c["n"] == 6000)
+    raw = recipe(case["recipe"], case["n"], case["dtype"], case["seed"]).reshape(60, 10, 10)
+    comp = {"id": "blosc", "cname": cname, "clevel": 5, "shuffle": shuffle, "blocksize": 0}
+    _zarr_v2_from_chunks(str(tmp_path), "t2m", (60, 10, 10), (60, 10, 10), "<f4", comp,
+                         {"0.0.0": base64.b64decode(case["chunk_b64"])}, ("time", "latitude", "longitude"))
+    got = afio.ZarrArray(os.path.join(str(tmp_path), "t2m")).read()
+    np.testing.assert_array_equal(got, raw)
+
+
+def test_zarr_zstd_compressor_and_blosc_writer(tmp_path):
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(2)
+    data = rng.normal(10, 5, (48, 6, 8)).astype("<f8")
+    files = {}
+    for it in range(2):
+        files[f"{it}.0.0"] = pa.Codec("zstd").compress(data[it * 24:(it + 1) * 24].tobytes(), asbytes=True)
+    _zarr_v2_from_chunks(str(tmp_path), "v", data.shape, (24, 6, 8), "<f8", {"id": "zstd", "level": 3}, files,
+                         ("time", "latitude", "longitude"))
+    np.testing.assert_array_equal(afio.ZarrArray(os.path.join(str(tmp_path), "v")).read(threads=2), data)
+    # the writer's default is Blosc-LZ4 + shuffle, ragged edge chunks included
+    afio._write_array(str(tmp_path), "w", data, ("time", "latitude", "longitude"), (20, 4, 8), {},
+                      {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0})
+    za = afio.ZarrArray(os.path.join(str(tmp_path), "w"))
+    assert codec.blosc_info(open(os.path.join(za.path, "2.1.0"), "rb").read())["codec"] == "lz4"
+    np.testing.assert_array_equal(za.read(), data)

@@ -360,6 +360,14 @@ def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
     a = af.aggregate_dataset(dataset=dev, weights=af.weights_from_objects(dev, gr, table=tab), **spec)
     b = af.aggregate_dataset(dataset=host, weights=af.weights_from_objects(host, gr, table=tab), **spec)
     pd.testing.assert_frame_equal(a, b)
+    # time-contiguous layout (each chunk = a run of whole time steps): the slab's Blosc chunks are read and
+    # decoded by the native codec on an OpenMP team straight into the staging rows; 960 = 13 x 70 + 50, so
+    # the last chunk is padded; zlib and raw stores take the generic per-chunk route
+    for comp in ("blosc", "zlib", False):
+        store2 = str(tmp_path / f"rows_{comp}.zarr")
+        af.dataset_to_zarr(ds, store2, var="t2m", chunks={"time": 70, "latitude": ny, "longitude": nx}, compress=comp)
+        dev2 = af.dataset_from_path(store2, "t2m", preprocess=lambda x: x - 273.15, device="cuda")
+        np.testing.assert_array_equal(dev2.cube().cpu().numpy(), host.cube())
 
 
 def test_float32_reference_rounding_mode(torch_cuda):
