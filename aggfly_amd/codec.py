@@ -47,13 +47,17 @@ def load():
         lib.afcodec_blosc_encode_lz4.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
         lib.afcodec_zstd_decode.restype = C.c_int64
         lib.afcodec_zstd_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.afcodec_zstd_bound.restype = C.c_int64
+        lib.afcodec_zstd_bound.argtypes = [C.c_int64]
+        lib.afcodec_zstd_encode.restype = C.c_int64
+        lib.afcodec_zstd_encode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         _lib = lib
     return _lib
 
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
            "afcodec_blosc_decode_files",
-           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode")
+           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode")
 
 
 def _err(lib, what):
@@ -149,3 +153,14 @@ def zstd_decode(buf, nbytes: int, out: np.ndarray | None = None) -> np.ndarray:
     if r < 0:
         raise _err(lib, "zstd_decode")
     return out[:r] if r != out.nbytes and out.ndim == 1 else out
+
+
+def zstd_encode(data, level: int = 3) -> bytes:
+    lib = load()
+    arr = np.ascontiguousarray(data) if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    cap = lib.afcodec_zstd_bound(arr.nbytes)
+    dst = np.empty(cap, dtype=np.uint8)
+    r = lib.afcodec_zstd_encode(arr.ctypes.data, arr.nbytes, int(level), dst.ctypes.data, cap)
+    if r < 0:
+        raise _err(lib, "zstd_encode")
+    return dst[:r].tobytes()

@@ -47,11 +47,15 @@ typedef int (*lz4_enc_fn)(const char*, char*, int, int);
 typedef int (*lz4_bound_fn)(int);
 typedef size_t (*zstd_dec_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_iserr_fn)(size_t);
+typedef size_t (*zstd_enc_fn)(void*, size_t, const void*, size_t, int);
+typedef size_t (*zstd_bound_fn)(size_t);
 static lz4_dec_fn p_lz4_dec;
 static lz4_enc_fn p_lz4_enc;
 static lz4_bound_fn p_lz4_bound;
 static zstd_dec_fn p_zstd_dec;
 static zstd_iserr_fn p_zstd_iserr;
+static zstd_enc_fn p_zstd_enc;
+static zstd_bound_fn p_zstd_bound;
 static int g_lz4_tried, g_zstd_tried;
 
 static int need_lz4(void) {
@@ -72,6 +76,8 @@ static int need_zstd(void) {
         if (h) {
             p_zstd_dec = (zstd_dec_fn)dlsym(h, "ZSTD_decompress");
             p_zstd_iserr = (zstd_iserr_fn)dlsym(h, "ZSTD_isError");
+            p_zstd_enc = (zstd_enc_fn)dlsym(h, "ZSTD_compress");
+            p_zstd_bound = (zstd_bound_fn)dlsym(h, "ZSTD_compressBound");
         }
         g_zstd_tried = 1;
     }
@@ -378,5 +384,19 @@ int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap) 
     if (rc) return rc;
     const size_t got = p_zstd_dec(dst, (size_t)cap, src, (size_t)n);
     if (p_zstd_iserr(got)) return fail(AFCODEC_E_CODEC, "zstd frame failed to decode");
+    return (int64_t)got;
+}
+
+/* Zstandard frame of src (writer side of Zarr v3 stores); cap >= afcodec_zstd_bound(n). */
+int64_t afcodec_zstd_bound(int64_t n) {
+    if (need_zstd() || !p_zstd_bound) return n + n / 128 + 512;
+    return (int64_t)p_zstd_bound((size_t)n);
+}
+int64_t afcodec_zstd_encode(const void* src, int64_t n, int level, void* dst, int64_t cap) {
+    int rc = need_zstd();
+    if (rc) return rc;
+    if (!p_zstd_enc) return fail(AFCODEC_E_UNSUPPORTED, "libzstd has no ZSTD_compress");
+    const size_t got = p_zstd_enc(dst, (size_t)cap, src, (size_t)n, level);
+    if (p_zstd_iserr(got)) return fail(AFCODEC_E_CODEC, "zstd compression failed");
     return (int64_t)got;
 }

@@ -6,7 +6,7 @@ to time-contiguous Zarr with `dataset_to_zarr` / `zarr_from_path`
 or on the GPU box, so this module reads what can be read with numpy + the standard
 library:
 
-* Zarr v2 directory stores: C-order chunks, ``compressor`` null / zlib / gzip / blosc (every
+* Zarr directory stores, format 2 and format 3 (``zarr.json``): C-order chunks, ``compressor`` null / zlib / gzip / blosc (every
   Blosc-1 codec and shuffle, decoded natively by ``csrc/blosc1.c``) / zstd, ``_ARRAY_DIMENSIONS``
   attributes, CF time decoding (``units`` + ``calendar``; non-standard calendars go to
   ``cfcalendar``), ``scale_factor`` / ``add_offset`` / ``_FillValue``;
@@ -71,42 +71,157 @@ def _decompress(buf: bytes, comp, nbytes: Optional[int] = None):
     raise ValueError(f"unsupported Zarr compressor {cid!r}")
 
 
+_V3_DTYPES = {"bool": "|b1", "int8": "|i1", "int16": "<i2", "int32": "<i4", "int64": "<i8", "uint8": "|u1", "uint16": "<u2",
+              "uint32": "<u4", "uint64": "<u8", "float16": "<f2", "float32": "<f4", "float64": "<f8"}
+
+
+def is_zarr_array(path: str) -> bool:
+    if os.path.exists(os.path.join(path, ".zarray")):
+        return True
+    zj = os.path.join(path, "zarr.json")
+    if os.path.exists(zj):
+        with open(zj) as f:
+            return json.load(f).get("node_type") == "array"
+    return False
+
+
 class ZarrArray:
-    """One array of a Zarr v2 directory store."""
+    """One array of a Zarr directory store, format 2 (``.zarray`` / ``.zattrs``, chunk files ``i.j.k``)
+    or format 3 (``zarr.json``, chunk files ``c/i/j/k``, codec pipeline) — what zarr-python 2 and 3
+    write by default.  Both reduce to: a chunk file name, a chain of bytes -> bytes decoders, a dtype.
+
+    Format 3 is implemented from the specification (bytes / gzip / zstd / blosc / crc32c codecs, default
+    and v2 chunk-key encodings, ``dimension_names``); no zarr-python 3 is available in this image to
+    cross-check against, sharded arrays are refused."""
 
     def __init__(self, path: str):
         self.path = path
-        with open(os.path.join(path, ".zarray")) as f:
+        if os.path.exists(os.path.join(path, ".zarray")):
+            self._init_v2()
+        elif os.path.exists(os.path.join(path, "zarr.json")):
+            self._init_v3()
+        else:
+            raise FileNotFoundError(f"{path} is not a Zarr array (no .zarray / zarr.json)")
+        self.disk_dtype = self.dtype                                    # as stored (may be big-endian)
+        self.dtype = self.dtype.newbyteorder("=") if not self.dtype.isnative else self.dtype
+        self.chunk_nbytes = int(np.prod(self.chunks)) * self.dtype.itemsize if self.shape else self.dtype.itemsize
+
+    # ---- format 2 ----
+    def _init_v2(self):
+        with open(os.path.join(self.path, ".zarray")) as f:
             self.meta = json.load(f)
         if self.meta.get("zarr_format") != 2:
-            raise ValueError("only Zarr format 2 is supported")
+            raise ValueError("a .zarray file must declare zarr_format 2")
         if self.meta.get("order", "C") != "C":
             raise ValueError("only C-order Zarr chunks are supported")
         if self.meta.get("filters"):
             raise ValueError("Zarr filters are not supported")
+        self.format = 2
         self.shape = tuple(self.meta["shape"])
         self.chunks = tuple(self.meta["chunks"])
         self.dtype = np.dtype(self.meta["dtype"])
         self.sep = self.meta.get("dimension_separator", ".")
+        self.key_prefix = ""
+        comp = self.meta.get("compressor")
+        self.codecs = [] if comp is None else [dict(comp)]             # bytes -> bytes decoders, in decode order
+        self.fill_value = self.meta.get("fill_value")
         self.attrs = {}
-        ap = os.path.join(path, ".zattrs")
+        ap = os.path.join(self.path, ".zattrs")
         if os.path.exists(ap):
             with open(ap) as f:
                 self.attrs = json.load(f)
+        self._dims = self.attrs.get("_ARRAY_DIMENSIONS")
+
+    # ---- format 3 ----
+    def _init_v3(self):
+        with open(os.path.join(self.path, "zarr.json")) as f:
+            self.meta = m = json.load(f)
+        if m.get("zarr_format") != 3 or m.get("node_type") != "array":
+            raise ValueError(f"{self.path}/zarr.json is not a format-3 array node")
+        self.format = 3
+        self.shape = tuple(m["shape"])
+        grid = m.get("chunk_grid", {})
+        if grid.get("name") != "regular":
+            raise ValueError(f"unsupported chunk grid {grid.get('name')!r}")
+        self.chunks = tuple(grid["configuration"]["chunk_shape"])
+        dt = m["data_type"]
+        if not isinstance(dt, str) or dt not in _V3_DTYPES:
+            raise ValueError(f"unsupported Zarr v3 data_type {dt!r}")
+        self.dtype = np.dtype(_V3_DTYPES[dt])
+        enc = m.get("chunk_key_encoding", {"name": "default"})
+        conf = enc.get("configuration", {})
+        if enc.get("name") == "default":
+            self.sep, self.key_prefix = conf.get("separator", "/"), "c"
+        elif enc.get("name") == "v2":
+            self.sep, self.key_prefix = conf.get("separator", "."), ""
+        else:
+            raise ValueError(f"unsupported chunk key encoding {enc.get('name')!r}")
+        self.codecs = []
+        seen_bytes = False
+        for c in m.get("codecs", []):
+            name, cf = c.get("name"), c.get("configuration", {}) or {}
+            if name == "bytes":
+                if cf.get("endian", "little") != "little" and self.dtype.itemsize > 1:
+                    self.dtype = self.dtype.newbyteorder(">")
+                seen_bytes = True
+            elif name == "transpose":
+                if list(cf.get("order", [])) != list(range(len(self.shape))):
+                    raise ValueError("Zarr v3 transpose codecs other than the identity are not supported")
+            elif name in ("gzip", "zstd", "blosc", "crc32c"):
+                self.codecs.insert(0, dict(cf, id=name))                # decode order is the reverse of encode order
+            elif name == "sharding_indexed":
+                raise ValueError("sharded Zarr v3 arrays are not supported")
+            else:
+                raise ValueError(f"unsupported Zarr v3 codec {name!r}")
+        if not seen_bytes:
+            raise ValueError("Zarr v3 codec chain has no array -> bytes codec")
+        self.fill_value = m.get("fill_value")
+        self.attrs = dict(m.get("attributes", {}))
+        self._dims = m.get("dimension_names")
 
     @property
     def dims(self):
-        return tuple(self.attrs.get("_ARRAY_DIMENSIONS", [f"dim_{i}" for i in range(len(self.shape))]))
+        d = self._dims
+        return tuple(d) if d and all(x is not None for x in d) else tuple(f"dim_{i}" for i in range(len(self.shape)))
+
+    @property
+    def blosc_only(self) -> bool:
+        """True when a chunk file is exactly one Blosc-1 container (the common case)."""
+        return len(self.codecs) == 1 and self.codecs[0].get("id") == "blosc" and self.disk_dtype.isnative
+
+    def chunk_path(self, idx) -> str:
+        if self.format == 2:
+            key = self.sep.join(str(i) for i in idx) if idx else "0"
+        else:
+            key = self.sep.join([self.key_prefix] + [str(i) for i in idx]) if self.key_prefix else self.sep.join(str(i) for i in idx)
+        return os.path.join(self.path, *key.split("/"))
+
+    def _fill(self):
+        fv = self.fill_value
+        if self.dtype.kind == "f":
+            if fv in (None, "NaN"):
+                return np.nan
+            if fv in ("Infinity", "-Infinity"):
+                return np.inf if fv == "Infinity" else -np.inf
+        return 0 if fv is None else fv
+
+    def decode(self, buf):
+        """Chunk file bytes -> decoded bytes (ndarray or bytes) through the codec chain."""
+        for c in self.codecs:
+            if c["id"] == "crc32c":
+                buf = bytes(buf)[:-4]                                   # 4-byte checksum trailer (not verified)
+            else:
+                buf = _decompress(buf, c, self.chunk_nbytes)
+        return buf
 
     def _chunk(self, idx):
-        fn = os.path.join(self.path, self.sep.join(str(i) for i in idx) if idx else "0")
+        fn = self.chunk_path(idx)
         if not os.path.exists(fn):
-            fill = self.meta.get("fill_value")
-            fv = np.nan if fill in (None, "NaN") and self.dtype.kind == "f" else (0 if fill is None else fill)
-            return np.full(self.chunks, fv, dtype=self.dtype)
+            return np.full(self.chunks, self._fill(), dtype=self.dtype)
         with open(fn, "rb") as f:
-            raw = _decompress(f.read(), self.meta.get("compressor"), int(np.prod(self.chunks)) * self.dtype.itemsize)
-        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+            raw = self.decode(f.read())
+        arr = np.frombuffer(raw, dtype=self.disk_dtype, count=int(np.prod(self.chunks)) if self.shape else 1).reshape(self.chunks)
+        return arr if self.disk_dtype.isnative else arr.astype(self.dtype)
 
     def read(self, out: Optional[np.ndarray] = None, threads: int = 8) -> np.ndarray:
         if out is None:
@@ -211,8 +326,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
 
     pool = ThreadPoolExecutor(max_workers=threads) if threads > 1 else None
 
-    comp = za.meta.get("compressor")
-    whole_rows = za.chunks[1] >= ny and za.chunks[2] >= nx and za.chunks[1] == ny and za.chunks[2] == nx
+    whole_rows = za.chunks[1] == ny and za.chunks[2] == nx
 
     def read_blosc_slab(k0, k1, out):
         """Time-contiguous store (every chunk spans the whole grid): each Blosc chunk decodes straight
@@ -223,7 +337,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
         paths, outs, spans, tails = [], [], [], []
         for it in its:
             t0, t1 = it * tc, min((it + 1) * tc, T)
-            paths.append(os.path.join(za.path, za.sep.join((str(it), "0", "0"))))
+            paths.append(za.chunk_path((it, 0, 0)))
             spans.append((t0, t1))
             if t1 - t0 == tc:
                 outs.append(out[t0 - k0:t1 - k0])
@@ -240,7 +354,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
                 out[t0 - k0:t1 - k0] = tmp[:t1 - t0]
 
     def read(k0, k1, out):
-        if whole_rows and comp is not None and comp.get("id") == "blosc" and out.flags.c_contiguous:
+        if whole_rows and za.blosc_only and out.flags.c_contiguous:
             return read_blosc_slab(k0, k1, out)
         jobs = [(it, iy, ix) for it in range(k0 // tc, (k1 + tc - 1) // tc) for (iy, ix) in grid_yx]
 
@@ -258,7 +372,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             for j in jobs:
                 work(j)
 
-    fv = za.attrs.get("_FillValue", za.attrs.get("missing_value"))
+    fv = _attr_fill(za.attrs)
 
     def post(dst):
         if fv is not None and not (isinstance(fv, float) and np.isnan(fv)):
@@ -284,8 +398,24 @@ def _decode_time(values, attrs):
     return decode_cf_time(values, units, cal)
 
 
-def _cf_mask_scale(arr, attrs):
+def _attr_fill(attrs):
+    """``_FillValue`` / ``missing_value`` attribute; xarray writes it base64-packed into format-3 stores."""
     fv = attrs.get("_FillValue", attrs.get("missing_value"))
+    if isinstance(fv, str):
+        if fv in ("NaN", "nan"):
+            return float("nan")
+        try:
+            import base64
+            import struct
+            raw = base64.standard_b64decode(fv)
+            fv = struct.unpack("<d", raw)[0] if len(raw) == 8 else (struct.unpack("<f", raw)[0] if len(raw) == 4 else None)
+        except Exception:
+            fv = None
+    return fv
+
+
+def _cf_mask_scale(arr, attrs):
+    fv = _attr_fill(attrs)
     sf, ao = attrs.get("scale_factor"), attrs.get("add_offset")
     if fv is None and sf is None and ao is None:
         return arr
@@ -306,24 +436,46 @@ def open_zarr(path: str, var: str, threads: int = 8) -> DataArray:
     coords = {}
     for d in dims:
         cp = os.path.join(path, d)
-        if os.path.exists(os.path.join(cp, ".zarray")):
+        if is_zarr_array(cp):
             c = ZarrArray(cp)
             v = c.read(threads=1)
             coords[d] = _decode_time(v, c.attrs) if ("units" in c.attrs and " since " in str(c.attrs["units"])) else v
     return DataArray(data, dims, coords, name=var, attrs=arr.attrs)
 
 
-def _write_array(path, name, data, dims, chunks, attrs, compressor):
+def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format: int = 2):
     d = os.path.join(path, name)
     os.makedirs(d, exist_ok=True)
     data = np.ascontiguousarray(data)
     chunks = tuple(int(min(c, s)) if s else 1 for c, s in zip(chunks, data.shape))
-    meta = {"zarr_format": 2, "shape": list(data.shape), "chunks": list(chunks), "dtype": data.dtype.str,
-            "compressor": compressor, "fill_value": "NaN" if data.dtype.kind == "f" else 0, "order": "C", "filters": None}
-    with open(os.path.join(d, ".zarray"), "w") as f:
-        json.dump(meta, f)
-    with open(os.path.join(d, ".zattrs"), "w") as f:
-        json.dump(dict(attrs, _ARRAY_DIMENSIONS=list(dims)), f)
+    cid = compressor["id"] if compressor else None
+    if zarr_format == 2:
+        meta = {"zarr_format": 2, "shape": list(data.shape), "chunks": list(chunks), "dtype": data.dtype.str,
+                "compressor": compressor, "fill_value": "NaN" if data.dtype.kind == "f" else 0, "order": "C", "filters": None}
+        with open(os.path.join(d, ".zarray"), "w") as f:
+            json.dump(meta, f)
+        with open(os.path.join(d, ".zattrs"), "w") as f:
+            json.dump(dict(attrs, _ARRAY_DIMENSIONS=list(dims)), f)
+    elif zarr_format == 3:
+        v3name = {v: k for k, v in _V3_DTYPES.items()}[data.dtype.newbyteorder("<").str if data.dtype.itemsize > 1 else data.dtype.str]
+        codecs = [{"name": "bytes", "configuration": {"endian": "little"}}]
+        if cid == "blosc":
+            codecs.append({"name": "blosc", "configuration": {"cname": "lz4", "clevel": 5, "shuffle": "shuffle" if compressor.get("shuffle", 1) == 1 else "noshuffle",
+                                                               "typesize": data.dtype.itemsize, "blocksize": compressor.get("blocksize", 0)}})
+        elif cid == "zstd":
+            codecs.append({"name": "zstd", "configuration": {"level": compressor.get("level", 0), "checksum": False}})
+        elif cid in ("zlib", "gzip"):
+            cid = "gzip"
+            codecs.append({"name": "gzip", "configuration": {"level": compressor.get("level", 1)}})
+        meta = {"zarr_format": 3, "node_type": "array", "shape": list(data.shape), "data_type": v3name,
+                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(chunks)}},
+                "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
+                "fill_value": "NaN" if data.dtype.kind == "f" else 0, "codecs": codecs, "attributes": dict(attrs),
+                "dimension_names": list(dims), "storage_transformers": []}
+        with open(os.path.join(d, "zarr.json"), "w") as f:
+            json.dump(meta, f)
+    else:
+        raise ValueError("zarr_format must be 2 or 3")
     grid = [range((s + c - 1) // c) for s, c in zip(data.shape, chunks)]
     for idx in np.ndindex(*[len(g) for g in grid]):
         blk = np.full(chunks, np.nan if data.dtype.kind == "f" else 0, dtype=data.dtype)
@@ -331,15 +483,22 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor):
         part = data[sl]
         blk[tuple(slice(0, n) for n in part.shape)] = part
         raw = blk.tobytes()
-        if compressor and compressor["id"] == "zlib":
+        if cid == "zlib":
             raw = zlib.compress(raw, compressor.get("level", 1))
-        elif compressor and compressor["id"] == "blosc":
+        elif cid == "gzip":
+            raw = gzip.compress(raw, compressor.get("level", 1))
+        elif cid == "blosc":
             from . import codec
             raw = codec.blosc_encode(blk, data.dtype.itemsize, shuffle=compressor.get("shuffle", 1) == 1,
                                      blocksize=compressor.get("blocksize", 0))
-        elif compressor:
-            raise ValueError(f"cannot write Zarr compressor {compressor['id']!r}")
-        with open(os.path.join(d, ".".join(str(i) for i in idx)), "wb") as f:
+        elif cid == "zstd":
+            from . import codec
+            raw = codec.zstd_encode(blk, compressor.get("level", 3) or 3)
+        elif cid is not None:
+            raise ValueError(f"cannot write Zarr compressor {cid!r}")
+        fn = os.path.join(d, ".".join(str(i) for i in idx)) if zarr_format == 2 else os.path.join(d, "c", *[str(i) for i in idx])
+        os.makedirs(os.path.dirname(fn), exist_ok=True)
+        with open(fn, "wb") as f:
             f.write(raw)
 
 
@@ -365,10 +524,11 @@ def _auto_chunks(sizes: dict, itemsize: int, target_mb: float = 256) -> dict:
     return {"time": int(min(max(1, budget // (side * side)), nt)), "latitude": side, "longitude": side}
 
 
-def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress=True, mode: str = "w"):
+def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress=True, mode: str = "w", zarr_format: int = 2):
     """`dataset_to_zarr` (`zarr_convert.py:50-121`): write a time-major, time-contiguous store.
     ``compress``: True / "blosc" -> Blosc-1 LZ4 + byte shuffle (what zarr-python 2 / numcodecs write by
-    default and read back), "zlib" -> zlib level 1, False -> raw chunks."""
+    default and read back), "zstd" (zarr-python 3's default codec), "zlib" -> zlib level 1, False -> raw.
+    ``zarr_format``: 2 (``.zarray``) or 3 (``zarr.json``, ``c/`` chunk keys)."""
     cube = dataset.cube()
     if not isinstance(cube, np.ndarray):
         cube = cube.cpu().numpy()
@@ -376,21 +536,27 @@ def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, 
     ch = dict(_auto_chunks(sizes, cube.dtype.itemsize)) if chunks is None else dict(chunks)
     ctuple = tuple(sizes[d] if ch.get(d, -1) in (-1, None) else ch[d] for d in ("time", "latitude", "longitude"))
     os.makedirs(path, exist_ok=True)
-    with open(os.path.join(path, ".zgroup"), "w") as f:
-        json.dump({"zarr_format": 2}, f)
+    if zarr_format == 2:
+        with open(os.path.join(path, ".zgroup"), "w") as f:
+            json.dump({"zarr_format": 2}, f)
+    else:
+        with open(os.path.join(path, "zarr.json"), "w") as f:
+            json.dump({"zarr_format": 3, "node_type": "group", "attributes": {}}, f)
     if compress in (True, "blosc"):
         comp = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+    elif compress == "zstd":
+        comp = {"id": "zstd", "level": 3}
     elif compress == "zlib":
         comp = {"id": "zlib", "level": 1}
     elif not compress:
         comp = None
     else:
-        raise ValueError(f"compress must be True, False, 'blosc' or 'zlib', got {compress!r}")
-    _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp)
+        raise ValueError(f"compress must be True, False, 'blosc', 'zstd' or 'zlib', got {compress!r}")
+    _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp, zarr_format)
     tv, tattrs = _encode_time(dataset.time)
-    _write_array(path, "time", np.asarray(tv, dtype=np.float64), ("time",), (len(tv),), tattrs, None)
-    _write_array(path, "latitude", dataset.latitude, ("latitude",), (len(dataset.latitude),), {}, None)
-    _write_array(path, "longitude", dataset.longitude, ("longitude",), (len(dataset.longitude),), {}, None)
+    _write_array(path, "time", np.asarray(tv, dtype=np.float64), ("time",), (len(tv),), tattrs, None, zarr_format)
+    _write_array(path, "latitude", dataset.latitude, ("latitude",), (len(dataset.latitude),), {}, None, zarr_format)
+    _write_array(path, "longitude", dataset.longitude, ("longitude",), (len(dataset.longitude),), {}, None, zarr_format)
     return path
 
 
@@ -453,7 +619,7 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             coords = {}
             for d in za.dims:
                 cp = os.path.join(paths[0], d)
-                if os.path.exists(os.path.join(cp, ".zarray")):
+                if is_zarr_array(cp):
                     c = ZarrArray(cp)
                     v = c.read(threads=1)
                     coords[d] = _decode_time(v, c.attrs) if " since " in str(c.attrs.get("units", "")) else v

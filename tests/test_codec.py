@@ -130,3 +130,54 @@ def test_zarr_zstd_compressor_and_blosc_writer(tmp_path):
     za = afio.ZarrArray(os.path.join(str(tmp_path), "w"))
     assert codec.blosc_info(open(os.path.join(za.path, "2.1.0"), "rb").read())["codec"] == "lz4"
     np.testing.assert_array_equal(za.read(), data)
+
+
+@pytest.mark.parametrize("compress", ["zstd", "blosc", "zlib", False])
+def test_zarr_format_3_store_round_trip(tmp_path, compress):
+    """Format 3 (zarr.json, c/ chunk keys, codec pipeline) as zarr-python 3 lays it out; written by this
+    package's own writer (no zarr-python 3 exists in the image to produce an independent fixture)."""
+    import pandas as pd
+    import aggfly_amd as af
+    rng = np.random.default_rng(4)
+    T, ny, nx = 50, 7, 9
+    cube = rng.normal(280, 8, (T, ny, nx)).astype(np.float32)
+    cube[3, 2, 1] = np.nan
+    time = pd.date_range("2003-02-01", periods=T, freq="h")
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": time, "latitude": 10 + np.arange(ny) * 0.5, "longitude": 100 + np.arange(nx) * 0.5}), lon_is_360=True)
+    store = str(tmp_path / "v3.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 16, "latitude": 4, "longitude": 9}, compress=compress, zarr_format=3)
+    assert os.path.exists(os.path.join(store, "zarr.json")) and os.path.exists(os.path.join(store, "t2m", "c", "3", "1", "0"))
+    meta = json.load(open(os.path.join(store, "t2m", "zarr.json")))
+    assert meta["zarr_format"] == 3 and meta["node_type"] == "array" and meta["dimension_names"] == ["time", "latitude", "longitude"]
+    assert [c["name"] for c in meta["codecs"]] == ["bytes"] + ({"zstd": ["zstd"], "blosc": ["blosc"], "zlib": ["gzip"], False: []}[compress])
+    back = af.dataset_from_path(store, "t2m")
+    np.testing.assert_array_equal(back.cube(), cube)
+    assert back.time.equals(time) and np.array_equal(back.latitude, ds.latitude)
+
+
+def test_zarr_format_3_details(tmp_path):
+    """v2-style chunk keys inside a format-3 array, a crc32c trailer, big-endian bytes, a missing chunk
+    (fill value), and the refusals."""
+    import zlib as _z
+    d = str(tmp_path / "a")
+    os.makedirs(d)
+    data = np.arange(24, dtype=">i4").reshape(4, 6)
+    meta = {"zarr_format": 3, "node_type": "array", "shape": [4, 6], "data_type": "int32",
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": [2, 6]}},
+            "chunk_key_encoding": {"name": "v2", "configuration": {"separator": "."}}, "fill_value": -1,
+            "codecs": [{"name": "bytes", "configuration": {"endian": "big"}}, {"name": "gzip", "configuration": {"level": 1}}, {"name": "crc32c"}],
+            "attributes": {"units": "1"}, "dimension_names": ["y", "x"]}
+    json.dump(meta, open(os.path.join(d, "zarr.json"), "w"))
+    import gzip as _g
+    open(os.path.join(d, "0.0"), "wb").write(_g.compress(data[:2].tobytes()) + bytes(4))
+    za = afio.ZarrArray(d)
+    got = za.read()
+    assert za.dims == ("y", "x") and got.dtype == np.dtype("int32")
+    np.testing.assert_array_equal(got[:2], np.arange(12).reshape(2, 6))
+    assert (got[2:] == -1).all()                                          # chunk 1.0 is absent
+    for bad in ({"codecs": [{"name": "sharding_indexed", "configuration": {}}]}, {"data_type": "complex64"},
+                {"chunk_grid": {"name": "rectilinear", "configuration": {}}}):
+        json.dump(dict(meta, **bad), open(os.path.join(d, "zarr.json"), "w"))
+        with pytest.raises(ValueError):
+            afio.ZarrArray(d)

@@ -363,9 +363,9 @@ def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
     # time-contiguous layout (each chunk = a run of whole time steps): the slab's Blosc chunks are read and
     # decoded by the native codec on an OpenMP team straight into the staging rows; 960 = 13 x 70 + 50, so
     # the last chunk is padded; zlib and raw stores take the generic per-chunk route
-    for comp in ("blosc", "zlib", False):
-        store2 = str(tmp_path / f"rows_{comp}.zarr")
-        af.dataset_to_zarr(ds, store2, var="t2m", chunks={"time": 70, "latitude": ny, "longitude": nx}, compress=comp)
+    for comp, fmt in (("blosc", 2), ("zlib", 2), (False, 2), ("blosc", 3), ("zstd", 3)):
+        store2 = str(tmp_path / f"rows_{comp}_{fmt}.zarr")
+        af.dataset_to_zarr(ds, store2, var="t2m", chunks={"time": 70, "latitude": ny, "longitude": nx}, compress=comp, zarr_format=fmt)
         dev2 = af.dataset_from_path(store2, "t2m", preprocess=lambda x: x - 273.15, device="cuda")
         np.testing.assert_array_equal(dev2.cube().cpu().numpy(), host.cube())
 
