@@ -379,10 +379,63 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             dst[dst == fv] = float("nan")
 
     try:
+        if not whole_rows and za.blosc_only:
+            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if fv is not None else None), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if fv is not None else None), za
     finally:
         if pool is not None:
             pool.shutdown()
+
+
+def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None):
+    """Any chunk grid (e.g. the whole-time-series-per-spatial-tile layout `_auto_chunks` writes): the host
+    only ever decodes chunks CONTIGUOUSLY — a batch of Blosc chunk files is read and decoded by one OpenMP
+    team back to back into a cached page-locked buffer — the batch goes to HBM in one asynchronous copy,
+    and the GPU scatters every chunk into its (time, y, x) box of the cube (a strided device-to-device
+    copy at HBM speed).  The strided placement is the part a CPU is bad at (472-byte row pieces)."""
+    import torch
+    from . import codec
+    T, ny, nx = za.shape
+    tc, yc, xc = za.chunks
+    tdt = {np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64}[za.dtype]
+    cube = torch.empty((T, ny, nx), dtype=tdt, device=device)
+    cb = za.chunk_nbytes
+    per = max(1, min(max(threads, slab_bytes // cb), 4096))
+    idxs = [(it, iy, ix) for it in range(-(-T // tc)) for iy in range(-(-ny // yc)) for ix in range(-(-nx // xc))]
+    nstage = 2 if len(idxs) > per else 1
+    host = _pinned_stage(per * cb, nstage)
+    dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
+    copy_stream = torch.cuda.Stream(device=device)
+    done = [None, None]
+    for b, lo in enumerate(range(0, len(idxs), per)):
+        batch = idxs[lo:lo + per]
+        k = b % nstage
+        if done[k] is not None:
+            done[k].synchronize()                       # both staging buffers of slot k are free again
+        hbuf = host[k][:len(batch) * cb].numpy()
+        outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
+        res = codec.blosc_decode_files([za.chunk_path(i) for i in batch], outs, threads=threads)
+        with torch.cuda.stream(copy_stream):
+            dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
+            for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
+                t0, t1 = it * tc, min((it + 1) * tc, T)
+                y0, y1 = iy * yc, min((iy + 1) * yc, ny)
+                x0, x1 = ix * xc, min((ix + 1) * xc, nx)
+                dst = cube[t0:t1, y0:y1, x0:x1]
+                if r == -100:                           # absent chunk = fill value
+                    dst.fill_(float("nan"))
+                else:
+                    blk = dev[k][i * cb:(i + 1) * cb].view(tdt).view(tc, yc, xc)
+                    dst.copy_(blk[:t1 - t0, :y1 - y0, :x1 - x0])
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+            done[k] = ev
+    with torch.cuda.stream(copy_stream):
+        if post is not None:
+            post(cube)
+    copy_stream.synchronize()
+    torch.cuda.current_stream(device).wait_stream(copy_stream)
+    return cube
 
 
 def _decode_time(values, attrs):
