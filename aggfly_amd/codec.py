@@ -41,6 +41,8 @@ def load():
                                                   C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64)]
         lib.afcodec_blosc_decode_files.argtypes = [C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                                    C.c_int, C.POINTER(C.c_int64)]
+        lib.afcodec_decode_files.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                             C.c_int, C.POINTER(C.c_int64)]
         lib.afcodec_blosc_bound.restype = C.c_int64
         lib.afcodec_blosc_bound.argtypes = [C.c_int64, C.c_int64]
         lib.afcodec_blosc_encode_lz4.restype = C.c_int64
@@ -56,7 +58,7 @@ def load():
 
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
-           "afcodec_blosc_decode_files",
+           "afcodec_blosc_decode_files", "afcodec_decode_files",
            "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode")
 
 
@@ -116,19 +118,27 @@ def blosc_decode_many(bufs, outs, threads: int = 8):
     return [int(res[i]) for i in range(n)]
 
 
-def blosc_decode_files(paths, outs, threads: int = 8):
-    """Read and decode the chunk files ``paths[i]`` into ``outs[i]`` on an OpenMP team.
-    -> list of decoded sizes; -100 marks a missing file (the caller applies the fill value)."""
+KIND = {"raw": 0, "blosc": 1, "zstd": 2, "zlib": 3, "gzip": 3}
+
+
+def decode_files(kind: str, paths, outs, threads: int = 8):
+    """Read and decode the chunk files ``paths[i]`` (all of codec ``kind``: raw / blosc / zstd / zlib /
+    gzip) into ``outs[i]`` on an OpenMP team.  -> list of decoded sizes; -100 marks a missing file (the
+    caller applies the fill value)."""
     lib = load()
     n = len(paths)
     pp = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
     ds = (C.c_int64 * n)(*[o.nbytes for o in outs])
     res = (C.c_int64 * n)()
-    if lib.afcodec_blosc_decode_files(n, pp, dp, ds, int(threads), res):
+    if lib.afcodec_decode_files(KIND[kind], n, pp, dp, ds, int(threads), res):
         bad = [paths[i] for i in range(n) if res[i] < 0 and res[i] != -100]
-        raise CodecError(f"blosc_decode_files: {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+        raise CodecError(f"decode_files({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
     return [int(res[i]) for i in range(n)]
+
+
+def blosc_decode_files(paths, outs, threads: int = 8):
+    return decode_files("blosc", paths, outs, threads)
 
 
 def blosc_encode(data, typesize: int, shuffle: bool = True, blocksize: int = 0) -> bytes:

@@ -188,6 +188,9 @@ static void unshuffle_bits(int ts, int64_t bsize, const uint8_t* src, uint8_t* d
     if (bsize > off) memcpy(dst + off, src + off, (size_t)(bsize - off));
 }
 
+int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap);
+int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64_t dstsize);
+
 /* ---- chunk header ---- */
 int afcodec_blosc_info(const void* chunk, int64_t size, int64_t* nbytes, int64_t* blocksize, int32_t* typesize, int32_t* flags) {
     const uint8_t* c = (const uint8_t*)chunk;
@@ -298,12 +301,41 @@ int afcodec_blosc_decode_many(int64_t n, const void* const* chunks, const int64_
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
 }
 
-/* The same, reading each chunk file inside the worker (no Python between chunks): paths[i] -> dsts[i].
+/* zlib / gzip streams through zlib's inflate (wbits 15 + 32: header auto-detected). */
+static int64_t inflate_any(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) return fail(AFCODEC_E_CODEC, "inflateInit2 failed");
+    zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n;
+    zs.next_out = dst; zs.avail_out = (uInt)cap;
+    const int rc = inflate(&zs, Z_FINISH);
+    const int64_t got = (int64_t)zs.total_out;
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return fail(AFCODEC_E_CODEC, "zlib / gzip stream failed to inflate into the chunk size");
+    return got;
+}
+
+/* One chunk file -> dst, by codec kind: 0 raw bytes, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip. */
+static int64_t decode_kind(int kind, const uint8_t* buf, int64_t sz, void* dst, int64_t cap) {
+    switch (kind) {
+        case 0:
+            if (sz > cap) return fail(AFCODEC_E_SIZE, "raw chunk larger than its destination");
+            memcpy(dst, buf, (size_t)sz);
+            return sz;
+        case 1: return afcodec_blosc_decode(buf, sz, dst, cap);
+        case 2: return afcodec_zstd_decode(buf, sz, dst, cap);
+        case 3: return inflate_any(buf, sz, (uint8_t*)dst, cap);
+        default: return fail(AFCODEC_E_UNSUPPORTED, "unknown codec kind");
+    }
+}
+
+/* Reads and decodes the chunk files paths[i] -> dsts[i] on an OpenMP team (no Python between chunks).
  * A missing file leaves results[i] = -100 (the caller fills the Zarr fill value). */
-int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
-                               int nthreads, int64_t* results) {
+int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                         int nthreads, int64_t* results) {
     int bad = 0;
     if (nthreads < 1) nthreads = 1;
+    if (kind == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
 #pragma omp parallel num_threads(nthreads) reduction(+ : bad)
     {
         uint8_t* buf = NULL;
@@ -315,10 +347,14 @@ int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const*
             fseek(f, 0, SEEK_END);
             const int64_t sz = ftell(f);
             fseek(f, 0, SEEK_SET);
-            if (sz > cap) { free(buf); buf = (uint8_t*)malloc((size_t)sz + 64); cap = buf ? sz : 0; }
             int64_t r;
-            if (!buf || (int64_t)fread(buf, 1, (size_t)sz, f) != sz) r = fail(AFCODEC_E_FORMAT, "chunk file could not be read");
-            else r = afcodec_blosc_decode(buf, sz, dsts[i], dstsizes[i]);
+            if (kind == 0 && sz <= dstsizes[i]) {            /* raw: straight into the destination */
+                r = (int64_t)fread(dsts[i], 1, (size_t)sz, f) == sz ? sz : fail(AFCODEC_E_FORMAT, "chunk file could not be read");
+            } else {
+                if (sz > cap) { free(buf); buf = (uint8_t*)malloc((size_t)sz + 64); cap = buf ? sz : 0; }
+                if (!buf || (int64_t)fread(buf, 1, (size_t)sz, f) != sz) r = fail(AFCODEC_E_FORMAT, "chunk file could not be read");
+                else r = decode_kind(kind, buf, sz, dsts[i], dstsizes[i]);
+            }
             fclose(f);
             results[i] = r;
             if (r < 0) bad += 1;
@@ -326,6 +362,10 @@ int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const*
         free(buf);
     }
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files failed to decode (see results[])") : AFCODEC_OK;
+}
+int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                               int nthreads, int64_t* results) {
+    return afcodec_decode_files(1, n, paths, dsts, dstsizes, nthreads, results);
 }
 
 /* Encoder for the writer side (dataset_to_zarr, synthetic stores of the ingestion benchmark):

@@ -185,9 +185,19 @@ class ZarrArray:
         return tuple(d) if d and all(x is not None for x in d) else tuple(f"dim_{i}" for i in range(len(self.shape)))
 
     @property
+    def native_kind(self):
+        """'raw' / 'blosc' / 'zstd' / 'zlib' / 'gzip' when a chunk file is at most ONE codec the native
+        batch decoder handles (the common case), else None."""
+        if not self.disk_dtype.isnative or len(self.codecs) > 1:
+            return None
+        if not self.codecs:
+            return "raw"
+        cid = self.codecs[0].get("id")
+        return cid if cid in ("blosc", "zstd", "zlib", "gzip") else None
+
+    @property
     def blosc_only(self) -> bool:
-        """True when a chunk file is exactly one Blosc-1 container (the common case)."""
-        return len(self.codecs) == 1 and self.codecs[0].get("id") == "blosc" and self.disk_dtype.isnative
+        return self.native_kind == "blosc"
 
     def chunk_path(self, idx) -> str:
         if self.format == 2:
@@ -329,7 +339,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
     whole_rows = za.chunks[1] == ny and za.chunks[2] == nx
 
     def read_blosc_slab(k0, k1, out):
-        """Time-contiguous store (every chunk spans the whole grid): each Blosc chunk decodes straight
+        """Time-contiguous store (every chunk spans the whole grid): each chunk (raw / Blosc / zstd / zlib) decodes straight
         into its rows of the staging slab, all chunks of the slab on one OpenMP team — no per-chunk
         temporary, no Python between chunks."""
         from . import codec
@@ -346,7 +356,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
                 tmp = np.empty((tc, ny, nx), dtype=za.dtype)
                 outs.append(tmp)
                 tails.append(tmp)
-        res = codec.blosc_decode_files(paths, outs, threads=threads)
+        res = codec.decode_files(za.native_kind, paths, outs, threads=threads)
         for (t0, t1), r, tmp in zip(spans, res, tails):
             if r == -100:                           # absent chunk = fill value
                 out[t0 - k0:t1 - k0] = np.nan
@@ -354,7 +364,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
                 out[t0 - k0:t1 - k0] = tmp[:t1 - t0]
 
     def read(k0, k1, out):
-        if whole_rows and za.blosc_only and out.flags.c_contiguous:
+        if whole_rows and za.native_kind is not None and out.flags.c_contiguous:
             return read_blosc_slab(k0, k1, out)
         jobs = [(it, iy, ix) for it in range(k0 // tc, (k1 + tc - 1) // tc) for (iy, ix) in grid_yx]
 
@@ -379,7 +389,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             dst[dst == fv] = float("nan")
 
     try:
-        if not whole_rows and za.blosc_only:
+        if not whole_rows and za.native_kind is not None:
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if fv is not None else None), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if fv is not None else None), za
     finally:
@@ -414,7 +424,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             done[k].synchronize()                       # both staging buffers of slot k are free again
         hbuf = host[k][:len(batch) * cb].numpy()
         outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
-        res = codec.blosc_decode_files([za.chunk_path(i) for i in batch], outs, threads=threads)
+        res = codec.decode_files(za.native_kind, [za.chunk_path(i) for i in batch], outs, threads=threads)
         with torch.cuda.stream(copy_stream):
             dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):

@@ -35,12 +35,12 @@ def main():
     with tempfile.TemporaryDirectory(dir=base) as d:
         layouts = {"tiled": {"time": 744, "latitude": 52, "longitude": 118},      # space-tiled, like a generic store
                    "rows": {"time": 24, "latitude": ny, "longitude": nx}}          # time-contiguous: whole grid per chunk
-        for comp in (False, "zlib", "blosc"):
+        for comp in (False, "zlib", "blosc", "zstd"):
             for lname, chunks in layouts.items():
                 if comp is False and lname == "rows":
                     continue
                 store = os.path.join(d, f"s_{comp}_{lname}.zarr")
-                af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks, compress=comp)
+                af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks, compress=comp, zarr_format=3 if comp == "zstd" else 2)
                 size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(store) for f in fs)
                 tag = f"zarr_{comp or 'raw'}_{lname}"
                 out[tag + "_ratio"] = arr.nbytes / size
