@@ -1,0 +1,53 @@
+/* aggfly_codec.h — C ABI of libaggfly_codec.so: host-side chunk codecs of the ingestion path
+ * (SURVEY.md §8f row N2).  Plain C, no GPU code; every function is re-entrant (OpenMP inside the
+ * *_files / *_many calls only).
+ *
+ * Replaces, for this path, the numcodecs calls the reference makes inside its dask graph when a Zarr
+ * store is opened (aggfly/dataset/dataset.py:697-728: zarr chunk decode per task;
+ * benchmarks/bench_read_scheduler.py:4-8: GIL-limited to ~2 cores warm).
+ *
+ * Return values: >= 0 = bytes produced (decode / encode), or AFCODEC_OK for the batch calls;
+ * < 0 = error code, text in afcodec_last_error() (thread-local).
+ */
+#ifndef AGGFLY_CODEC_H
+#define AGGFLY_CODEC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFCODEC_OK 0
+#define AFCODEC_E_FORMAT (-1)      /* not a well-formed container / truncated */
+#define AFCODEC_E_UNSUPPORTED (-2) /* codec or library not available (snappy; liblz4 / libzstd missing) */
+#define AFCODEC_E_SIZE (-3)        /* destination too small, sizes out of range, out of memory */
+#define AFCODEC_E_CODEC (-4)       /* the inner codec failed */
+#define AFCODEC_MISSING (-100)     /* results[i] of the *_files calls: the chunk file does not exist */
+
+const char* afcodec_last_error(void);
+int afcodec_have(int codec); /* Blosc codec ids: 0 blosclz, 1 lz4, 3 zlib, 4 zstd -> 1 if usable */
+
+/* Blosc-1 container (format version 2; codecs blosclz / lz4 / lz4hc / zlib / zstd; byte- and bit-shuffle). */
+int afcodec_blosc_info(const void* chunk, int64_t size, int64_t* nbytes, int64_t* blocksize, int32_t* typesize, int32_t* flags);
+int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dst, int64_t dstsize);
+int afcodec_blosc_decode_many(int64_t n, const void* const* chunks, const int64_t* csizes, void* const* dsts,
+                              const int64_t* dstsizes, int nthreads, int64_t* results);
+int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                               int nthreads, int64_t* results);
+int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize);
+int64_t afcodec_blosc_encode_lz4(const void* src, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
+                                 void* dst, int64_t cap);
+
+/* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream): read and
+ * decoded paths[i] -> dsts[i], one chunk per OpenMP thread. */
+int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                         int nthreads, int64_t* results);
+
+/* Plain Zstandard frames (Zarr compressor / codec "zstd"). */
+int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap);
+int64_t afcodec_zstd_bound(int64_t n);
+int64_t afcodec_zstd_encode(const void* src, int64_t n, int level, void* dst, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -26,8 +26,12 @@ def _id(c):
 
 
 def test_library_exports_every_symbol():
+    import re
     lib = codec.load()
-    assert all(hasattr(lib, s) for s in codec.EXPORTS)
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "aggfly_codec.h")).read()
+    declared = set(re.findall(r"\b(afcodec_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(codec.EXPORTS), declared ^ set(codec.EXPORTS)
+    assert all(hasattr(lib, s) for s in declared)
     assert lib.afcodec_have(1) and lib.afcodec_have(4) and lib.afcodec_have(3) and lib.afcodec_have(0)
 
 
