@@ -90,6 +90,31 @@ def inst(v):
     return f"k_fused_temporal<{CT[dtype]}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {max(depth, 1)}, {feat}>"
 
 
+class _KeepIfSame:
+    """Write a file only when its content changes, so `make` does not recompile an unchanged menu."""
+
+    def __init__(self, fn):
+        self.fn, self.parts = fn, []
+
+    def __enter__(self):
+        return self
+
+    def write(self, text):
+        self.parts.append(text)
+
+    def __exit__(self, *exc):
+        new = "".join(self.parts)
+        try:
+            with open(self.fn) as f:
+                if f.read() == new:
+                    return False
+        except OSError:
+            pass
+        with open(self.fn, "w") as f:
+            f.write(new)
+        return False
+
+
 def main():
     outdir = sys.argv[1]
     kind = "full"
@@ -110,7 +135,7 @@ def main():
         idx = i // per_file
         ngroups += 1
         fn = os.path.join(outdir, f"variants_{idx:02d}.hip")
-        with open(fn, "w") as f:
+        with _KeepIfSame(fn) as f:
             f.write("// generated by gen_variants.py — do not edit\n")
             f.write('#include "afhip_kernels.h"\n#include "afhip_variants.h"\n')
             f.write("namespace afhip {\n")
@@ -123,7 +148,7 @@ def main():
                 f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
             f.write("    return n;\n}\n}\n")
         files.append(fn)
-    with open(os.path.join(outdir, "variants_table.hip"), "w") as f:
+    with _KeepIfSame(os.path.join(outdir, "variants_table.hip")) as f:
         f.write("// generated by gen_variants.py — do not edit\n")
         f.write('#include "afhip_variants.h"\n')
         f.write("namespace afhip {\n")
