@@ -452,6 +452,16 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         // one cell per lane measured 1.6x faster on the 13-bin plan (profiles/r01_kbench_c4_f32.json)
         if (C_ % 2 == 0 && pl->nthr < 4 && pl->K < 8) want_vec = 2;
     }
+    // short inner groups: the direct path keeps DEPTH rows in flight only INSIDE a group, the LDS-DMA ring
+    // prefetches across group ends.  Measured (mean plan, 721x1440 / 1801x3600): 2-step groups f64 4.5 vs
+    // 6.0 TB/s, f32 3.5 vs 4.3; 4-step groups f32 4.4 vs 5.6, f64 equal; 8 steps and longer: equal.
+    {
+        const double avg_group = desc->G1 > 0 ? (double)desc->T / (double)desc->G1 : 0.0;
+        const int vec16 = desc->dtype == AFHIP_F64 ? 2 : 4;
+        bool sine = false;                          // sine_dd on short windows is fp64-VALU-bound: direct loads measured 4 % faster
+        for (const ColOp& c : pl->cols) sine = sine || c.src == SRC_SINE;
+        if (!sine && avg_group > 0 && avg_group < (desc->dtype == AFHIP_F64 ? 4.0 : 8.0) && C_ % vec16 == 0) { want_pipe = 1; want_vec = vec16; }
+    }
     int tuning = desc->tuning;
     if (tuning > 0) {
         const int tvec = ((tuning % 10000) % 1000) / 100;
