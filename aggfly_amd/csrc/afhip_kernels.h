@@ -114,6 +114,11 @@ __device__ __forceinline__ void powi_dd_vec(double (&x)[N], int e) {
     double hi[N], lo[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { hi[i] = x[i]; lo[i] = 0.0; }
+    if (n == 2) {                       // the chain's first step is RN(x * x) exactly: one multiply
+        KEEP_BRANCH();
+#pragma unroll
+        for (int i = 0; i < N; ++i) hi[i] = x[i] * x[i];
+    } else
     for (int it = 1; it < n; ++it) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
