@@ -263,6 +263,16 @@ class ZarrArray:
 # --------------------------------------------------------------------------------------
 # host -> HBM streaming
 # --------------------------------------------------------------------------------------
+def _torch_dtype(np_dtype):
+    import torch
+    table = {"float32": torch.float32, "float64": torch.float64, "int8": torch.int8, "uint8": torch.uint8,
+             "int16": torch.int16, "int32": torch.int32, "int64": torch.int64}
+    name = np.dtype(np_dtype).name
+    if name not in table:
+        raise ValueError(f"dtype {name} has no device representation on the streaming path")
+    return table[name]
+
+
 _PINNED_STAGE = {}      # (nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
 
 
@@ -279,7 +289,7 @@ def _pinned_stage(nbytes: int, count: int):
     return bufs[:count]
 
 
-def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: int, device="cuda", post=None):
+def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: int, device="cuda", post=None, out_dtype=None):
     """Fill a (T, *spatial) HBM tensor slab by slab through two cached page-locked staging buffers.
 
     ``read_slab(k0, k1, out)`` fills ``out[:k1-k0]`` with time steps [k0, k1) (a Zarr chunk
@@ -289,8 +299,8 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     pageable H2D 56 GB/s."""
     import torch
     np_dtype = np.dtype(np_dtype)
-    tdt = {np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64}[np_dtype]
-    cube = torch.empty((T,) + tuple(spatial), dtype=tdt, device=device)
+    tdt = _torch_dtype(np_dtype)                                    # as stored (packed integers stay packed on the wire)
+    cube = torch.empty((T,) + tuple(spatial), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
     if T == 0:
         return cube
     slab_steps = max(1, min(slab_steps, T))
@@ -326,8 +336,13 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
     za = ZarrArray(os.path.join(path, var))
     if len(za.shape) != 3:
         raise ValueError("zarr_to_device expects a (time, y, x) array")
-    if za.attrs.get("scale_factor") is not None or za.attrs.get("add_offset") is not None or za.dtype.kind != "f":
-        raise ValueError("packed integer stores go through dataset_from_path (host decode), not the streaming path")
+    sf, ao = za.attrs.get("scale_factor"), za.attrs.get("add_offset")
+    packed = za.dtype.kind in "iu" or sf is not None or ao is not None
+    if za.dtype.kind not in "fiu":
+        raise ValueError(f"dtype {za.dtype} is not streamed")
+    # CF decoding as on the host route (`_cf_mask_scale`): int8/int16 -> float32, wider integers -> float64
+    out_np = za.dtype if za.dtype.kind == "f" else np.dtype(np.float64 if za.dtype.itemsize > 2 else np.float32)
+    _torch_dtype(za.dtype)                                          # refuses what torch cannot hold (uint16, ...)
     T, ny, nx = za.shape
     tc = za.chunks[0]
     grid_yx = [(iy, ix) for iy in range((ny + za.chunks[1] - 1) // za.chunks[1]) for ix in range((nx + za.chunks[2] - 1) // za.chunks[2])]
@@ -359,7 +374,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
         res = codec.decode_files(za.native_kind, paths, outs, threads=threads)
         for (t0, t1), r, tmp in zip(spans, res, tails):
             if r == -100:                           # absent chunk = fill value
-                out[t0 - k0:t1 - k0] = np.nan
+                out[t0 - k0:t1 - k0] = za._fill()
             elif tmp is not None:
                 out[t0 - k0:t1 - k0] = tmp[:t1 - t0]
 
@@ -383,21 +398,29 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
                 work(j)
 
     fv = _attr_fill(za.attrs)
+    has_fv = fv is not None and not (isinstance(fv, float) and np.isnan(fv))
 
     def post(dst):
-        if fv is not None and not (isinstance(fv, float) and np.isnan(fv)):
-            dst[dst == fv] = float("nan")
+        """CF mask + unpack in HBM, in the order and precision of the host route: the packed integers travel
+        over PCIe as stored (half / quarter of the decoded bytes) and are unpacked at HBM speed."""
+        if has_fv:
+            dst[dst == fv] = float("nan")                   # exact: the cast from the stored integers is exact
+        if sf is not None:
+            dst.mul_(sf)
+        if ao is not None:
+            dst.add_(ao)
 
+    need_post = has_fv or packed
     try:
         if not whole_rows and za.native_kind is not None:
-            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if fv is not None else None), za
-        return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if fv is not None else None), za
+            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
+        return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if need_post else None, out_np), za
     finally:
         if pool is not None:
             pool.shutdown()
 
 
-def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None):
+def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None):
     """Any chunk grid (e.g. the whole-time-series-per-spatial-tile layout `_auto_chunks` writes): the host
     only ever decodes chunks CONTIGUOUSLY — a batch of Blosc chunk files is read and decoded by one OpenMP
     team back to back into a cached page-locked buffer — the batch goes to HBM in one asynchronous copy,
@@ -407,8 +430,8 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     from . import codec
     T, ny, nx = za.shape
     tc, yc, xc = za.chunks
-    tdt = {np.dtype("float32"): torch.float32, np.dtype("float64"): torch.float64}[za.dtype]
-    cube = torch.empty((T, ny, nx), dtype=tdt, device=device)
+    tdt = _torch_dtype(za.dtype)
+    cube = torch.empty((T, ny, nx), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
     cb = za.chunk_nbytes
     per = max(1, min(max(threads, slab_bytes // cb), 4096))
     idxs = [(it, iy, ix) for it in range(-(-T // tc)) for iy in range(-(-ny // yc)) for ix in range(-(-nx // xc))]
@@ -433,7 +456,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
                 x0, x1 = ix * xc, min((ix + 1) * xc, nx)
                 dst = cube[t0:t1, y0:y1, x0:x1]
                 if r == -100:                           # absent chunk = fill value
-                    dst.fill_(float("nan"))
+                    dst.fill_(float(za._fill()))
                 else:
                     blk = dev[k][i * cb:(i + 1) * cb].view(tdt).view(tc, yc, xc)
                     dst.copy_(blk[:t1 - t0, :y1 - y0, :x1 - x0])
