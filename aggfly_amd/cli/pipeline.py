@@ -35,6 +35,11 @@ def load_dataset(config, path, georegions):
     if config.reader_engine is not None:
         kwargs["engine"] = config.reader_engine
     clip = georegions if config.clip_to_regions and _has_bounds(georegions) else None
+    from .. import hip
+    if hip.device_count() > 0 and "device" not in kwargs:
+        # Zarr stores stream straight into HBM (native chunk decode, cached pinned staging); other
+        # containers and codec chains fall back to the host route inside dataset_from_path
+        kwargs["device"] = "cuda"
     return af.dataset_from_path(path, var=config.var, xycoords=config.xycoords, timecoord=config.timecoord,
                                 time_sel=config.time_sel, georegions=clip, lon_is_360=config.lon_is_360,
                                 preprocess=preprocess_mod.resolve_from_config(config), name=config.var, **kwargs)

@@ -71,6 +71,12 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C aggfly_amd/csrc`).  There is no CPU fallback.")
     try:
+        # torch ships its own HIP runtime (same SONAME as /opt/rocm's).  Whichever is loaded first serves the
+        # whole process; with the system one first, torch later reports "No HIP GPUs are available".
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - C / ctypes-only consumers
+        pass
+    try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the box
         raise HipEngineError(f"cannot load {LIB_PATH}: {e}") from e
