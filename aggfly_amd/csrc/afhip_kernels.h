@@ -730,10 +730,19 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 load_block(r);
                 use_block(r);
             }
-            for (; kk < gend; ++kk) {
-                RawVec<TIn, VEC> r0 = ld_stream<TIn, VEC, AUX>(p);
-                p += C;
-                consume(r0);
+            // the group's last rows (fewer than DEPTH; ALL rows of a group shorter than DEPTH): their loads
+            // are issued together too — one at a time, a 4-step group ran at a quarter of the bandwidth
+            if (kk < gend) {
+                const int rem = gend - kk;
+                RawVec<TIn, VEC> r[DEPTH];
+#pragma unroll
+                for (int d = 0; d < DEPTH - 1; ++d)
+                    if (d < rem) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
+                p += (int64_t)rem * C;
+#pragma unroll
+                for (int d = 0; d < DEPTH - 1; ++d)
+                    if (d < rem) consume(r[d]);
+                kk = gend;
             }
             group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63));
             ++g;
