@@ -25,7 +25,7 @@ import pandas as pd
 from . import engine as eng
 from . import hip
 from .cfcalendar import CFTimeIndex
-from .dataarray import DataArray, _is_torch
+from .dataarray import DataArray
 from .dataset import Dataset
 from .timegroups import resample_groups, translate_groupby
 

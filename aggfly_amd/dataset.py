@@ -17,14 +17,11 @@ into the GPU kernels instead of materialising new datasets.
 from __future__ import annotations
 
 import copy
-from typing import Optional
 
 import numpy as np
 import pandas as pd
 
-from .cfcalendar import CFTimeIndex
 from .dataarray import DataArray, _is_torch, from_any
-from .timegroups import as_time_index
 
 
 def lon_to_180(lon):

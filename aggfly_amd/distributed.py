@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from .cfcalendar import CFTimeIndex
 from .timegroups import resample_groups
 
 

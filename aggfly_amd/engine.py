@@ -21,14 +21,14 @@ from __future__ import annotations
 import hashlib
 import os
 import weakref
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
 import pandas as pd
 
 from . import hip
-from .dataarray import DataArray, _is_torch
+from .dataarray import _is_torch
 from .dataset import Dataset
 from .timegroups import resample_groups, translate_groupby
 

@@ -3,7 +3,7 @@ with a forced load-path arm, and (float32 seeds) with match_reference_f32 agains
 float32 run."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import numpy as np, torch
+import torch
 import test_gpu_fuzz as f
 from aggfly_amd import engine as eng
 bad = 0

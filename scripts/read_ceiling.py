@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Read-only bandwidth reference on this box: torch's own reductions over the same 21.7 GB
 cube (what a tuned library kernel reaches) beside the fused temporal kernel."""
-import json, os, sys, time
+import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

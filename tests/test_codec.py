@@ -163,7 +163,6 @@ def test_zarr_format_3_store_round_trip(tmp_path, compress):
 def test_zarr_format_3_details(tmp_path):
     """v2-style chunk keys inside a format-3 array, a crc32c trailer, big-endian bytes, a missing chunk
     (fill value), and the refusals."""
-    import zlib as _z
     d = str(tmp_path / "a")
     os.makedirs(d)
     data = np.arange(24, dtype=">i4").reshape(4, 6)

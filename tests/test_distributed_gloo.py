@@ -4,7 +4,6 @@ The per-shard numbers come from the oracle, so what is checked is exactly that
 "shard -> local reduce -> exchange" equals the unsharded result."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pandas as pd

@@ -7,7 +7,7 @@ sine_dd (device acos/sin/atan/cos vs libm), as BASELINE.json's north_star states
 import numpy as np
 import pytest
 
-from oracle import cport, ref_temporal as rt
+from oracle import cport
 from oracle.ref_spatial import scatter_block as ref_scatter, spatial_num_den
 from aggfly_amd import synth
 
