@@ -329,7 +329,7 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     return cube
 
 
-def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20):
+def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20, t_range=None):
     """Decode a time-major Zarr v2 array straight into HBM: each slab is a whole number of
     time chunks, decoded chunk-parallel on host threads into pinned memory and uploaded while
     the next slab decodes.  Returns (tensor, ZarrArray)."""
@@ -411,7 +411,13 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             dst.add_(ao)
 
     need_post = has_fv or packed
+    if t_range is not None and tuple(t_range) == (0, T):
+        t_range = None
     try:
+        if t_range is not None:
+            if za.native_kind is None:
+                raise ValueError("a time window on a codec chain goes through the host route")
+            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np, t_range), za
         if not whole_rows and za.native_kind is not None:
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if need_post else None, out_np), za
@@ -420,7 +426,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             pool.shutdown()
 
 
-def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None):
+def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None, t_range=None):
     """Any chunk grid (e.g. the whole-time-series-per-spatial-tile layout `_auto_chunks` writes): the host
     only ever decodes chunks CONTIGUOUSLY — a batch of Blosc chunk files is read and decoded by one OpenMP
     team back to back into a cached page-locked buffer — the batch goes to HBM in one asynchronous copy,
@@ -431,10 +437,11 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     T, ny, nx = za.shape
     tc, yc, xc = za.chunks
     tdt = _torch_dtype(za.dtype)
-    cube = torch.empty((T, ny, nx), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
+    ka, kb = (0, T) if t_range is None else (max(0, int(t_range[0])), min(T, int(t_range[1])))   # time window [ka, kb)
+    cube = torch.empty((kb - ka, ny, nx), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
     cb = za.chunk_nbytes
     per = max(1, min(max(threads, slab_bytes // cb), 4096))
-    idxs = [(it, iy, ix) for it in range(-(-T // tc)) for iy in range(-(-ny // yc)) for ix in range(-(-nx // xc))]
+    idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(-(-ny // yc)) for ix in range(-(-nx // xc))]
     nstage = 2 if len(idxs) > per else 1
     host = _pinned_stage(per * cb, nstage)
     dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
@@ -451,15 +458,16 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
         with torch.cuda.stream(copy_stream):
             dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
-                t0, t1 = it * tc, min((it + 1) * tc, T)
+                c0 = it * tc                            # first step of the chunk
+                t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
                 y0, y1 = iy * yc, min((iy + 1) * yc, ny)
                 x0, x1 = ix * xc, min((ix + 1) * xc, nx)
-                dst = cube[t0:t1, y0:y1, x0:x1]
+                dst = cube[t0 - ka:t1 - ka, y0:y1, x0:x1]
                 if r == -100:                           # absent chunk = fill value
                     dst.fill_(float(za._fill()))
                 else:
                     blk = dev[k][i * cb:(i + 1) * cb].view(tdt).view(tc, yc, xc)
-                    dst.copy_(blk[:t1 - t0, :y1 - y0, :x1 - x0])
+                    dst.copy_(blk[t0 - c0:t1 - c0, :y1 - y0, :x1 - x0])
             ev = torch.cuda.Event()
             ev.record(copy_stream)
             done[k] = ev
@@ -682,6 +690,35 @@ def _open_netcdf3(path, var):
     return DataArray(data, dims, coords, name=var, attrs=attrs)
 
 
+def _time_window(tindex, time_sel):
+    """(k0, k1) when ``time_sel`` (as `Dataset` applies it, `dataset.py:88-92`) picks one contiguous run of an
+    ascending time index, else None (the selection is then applied after the load)."""
+    n = len(tindex)
+    try:
+        if isinstance(tindex, pd.DatetimeIndex):
+            if not tindex.is_monotonic_increasing:
+                return None
+            loc = tindex.slice_indexer(time_sel.start, time_sel.stop) if isinstance(time_sel, slice) else tindex.get_loc(time_sel)
+            if isinstance(loc, (int, np.integer)):
+                return int(loc), int(loc) + 1
+            if isinstance(loc, slice) and loc.step in (None, 1):
+                k0, k1, _ = loc.indices(n)
+                return (k0, k1) if k1 > k0 else None
+            return None
+        y = np.asarray(tindex.fields()[0])
+        if isinstance(time_sel, slice):
+            lo = int(str(time_sel.start)[:4]) if time_sel.start is not None else y.min()
+            hi = int(str(time_sel.stop)[:4]) if time_sel.stop is not None else y.max()
+            idx = np.nonzero((y >= lo) & (y <= hi))[0]
+        else:
+            idx = np.nonzero(y == int(str(time_sel)[:4]))[0]
+        if len(idx) and idx[-1] - idx[0] + 1 == len(idx):
+            return int(idx[0]), int(idx[-1]) + 1
+    except (KeyError, TypeError, ValueError, AttributeError):
+        pass
+    return None
+
+
 def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="time", time_sel=None,
                       georegions=None, lon_is_360=True, time_fix=False, preprocess=None, name=None,
                       chunks=None, preprocess_at_load=False, parallel=True, device=None, **kwargs) -> Dataset:
@@ -697,11 +734,9 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
         raise FileNotFoundError(path)
     engine = kwargs.pop("engine", None)
     if device is not None and len(paths) == 1 and (engine == "zarr" or (engine is None and _looks_like_zarr(paths[0]))):
+        data = None
         try:
-            data, za = zarr_to_device(paths[0], var, device=device)
-        except ValueError:
-            data = None
-        if data is not None:
+            za = ZarrArray(os.path.join(paths[0], var))
             coords = {}
             for d in za.dims:
                 cp = os.path.join(paths[0], d)
@@ -709,6 +744,17 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
                     c = ZarrArray(cp)
                     v = c.read(threads=1)
                     coords[d] = _decode_time(v, c.attrs) if " since " in str(c.attrs.get("units", "")) else v
+            # a time selection on a time-leading store: only the chunks that hold the selected steps are
+            # read and decoded (a decade out of a 40-year store reads a quarter of it)
+            window = None
+            if time_sel is not None and za.dims and za.dims[0] == timecoord and timecoord in coords:
+                window = _time_window(coords[timecoord], time_sel)
+            data, za = zarr_to_device(paths[0], var, device=device, t_range=window)
+            if window is not None:
+                coords[timecoord] = coords[timecoord][window[0]:window[1]]
+        except ValueError:
+            data = None
+        if data is not None:
             da = DataArray(data, za.dims, coords, name=var, attrs=za.attrs)
             return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                            preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)

@@ -371,6 +371,32 @@ def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
         np.testing.assert_array_equal(dev2.cube().cpu().numpy(), host.cube())
 
 
+def test_time_selection_reads_only_its_chunks(torch_cuda, tmp_path, monkeypatch):
+    """time_sel on the streaming route decodes just the chunks that hold the selected steps (window not
+    aligned to chunk edges, both chunk layouts, datetime and noleap calendars) and equals the host route."""
+    from aggfly_amd import codec, io as afio
+    T, ny, nx = 24 * 90, 6, 10
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=61, scattered_nan=15)
+    lat, lon = 30 + 0.5 * np.arange(ny), 200 + 0.5 * np.arange(nx)
+    calls = []
+    real = codec.decode_files
+    monkeypatch.setattr(codec, "decode_files", lambda kind, paths, outs, threads=8: calls.append(len(paths)) or real(kind, paths, outs, threads))
+    for label, time, sel, nsel in (("dt", pd.date_range("2002-01-01", periods=T, freq="h"), slice("2002-02-03", "2002-02-20"), 18 * 24),
+                                   ("cf", af.cf_range("1999-06-01", T, "D", "noleap"), slice("2001", "2002"), 730)):
+        ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
+        for chunks in ({"time": 100, "latitude": ny, "longitude": nx}, {"time": 500, "latitude": 4, "longitude": 5}):
+            store = str(tmp_path / f"w_{label}_{chunks['time']}.zarr")
+            af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks)
+            host = af.dataset_from_path(store, "t2m", time_sel=sel)
+            calls.clear()
+            dev = af.dataset_from_path(store, "t2m", time_sel=sel, device="cuda")
+            assert dev.cube().is_cuda and len(dev.time) == len(host.time) == nsel
+            assert list(dev.time) == list(host.time)
+            np.testing.assert_array_equal(dev.cube().cpu().numpy(), host.cube())
+            n_all = -(-T // chunks["time"]) * -(-ny // chunks["latitude"]) * -(-nx // chunks["longitude"])
+            assert 0 < sum(calls) < n_all, (sum(calls), n_all)                       # fewer chunk files than the store holds
+
+
 def test_packed_int16_store_streams_packed_and_unpacks_in_hbm(torch_cuda, tmp_path):
     """ERA5-style packing (int16 + scale_factor / add_offset / _FillValue): the streaming route moves the
     packed integers over PCIe and applies the CF decoding in HBM — bit-identical to the host route, for
