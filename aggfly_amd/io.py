@@ -329,7 +329,7 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     return cube
 
 
-def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20, t_range=None):
+def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20, t_range=None, yx_box=None):
     """Decode a time-major Zarr v2 array straight into HBM: each slab is a whole number of
     time chunks, decoded chunk-parallel on host threads into pinned memory and uploaded while
     the next slab decodes.  Returns (tensor, ZarrArray)."""
@@ -413,11 +413,13 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
     need_post = has_fv or packed
     if t_range is not None and tuple(t_range) == (0, T):
         t_range = None
+    if yx_box is not None and tuple(yx_box) == (0, ny, 0, nx):
+        yx_box = None
     try:
-        if t_range is not None:
+        if t_range is not None or yx_box is not None:
             if za.native_kind is None:
-                raise ValueError("a time window on a codec chain goes through the host route")
-            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np, t_range), za
+                raise ValueError("a time / space window on a codec chain goes through the host route")
+            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np, t_range, yx_box), za
         if not whole_rows and za.native_kind is not None:
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if need_post else None, out_np), za
@@ -426,7 +428,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
             pool.shutdown()
 
 
-def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None, t_range=None):
+def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None, t_range=None, yx_box=None):
     """Any chunk grid (e.g. the whole-time-series-per-spatial-tile layout `_auto_chunks` writes): the host
     only ever decodes chunks CONTIGUOUSLY — a batch of Blosc chunk files is read and decoded by one OpenMP
     team back to back into a cached page-locked buffer — the batch goes to HBM in one asynchronous copy,
@@ -438,10 +440,11 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     tc, yc, xc = za.chunks
     tdt = _torch_dtype(za.dtype)
     ka, kb = (0, T) if t_range is None else (max(0, int(t_range[0])), min(T, int(t_range[1])))   # time window [ka, kb)
-    cube = torch.empty((kb - ka, ny, nx), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
+    ya, yb, xa, xb = (0, ny, 0, nx) if yx_box is None else yx_box                                  # spatial box [ya, yb) x [xa, xb)
+    cube = torch.empty((kb - ka, yb - ya, xb - xa), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
     cb = za.chunk_nbytes
     per = max(1, min(max(threads, slab_bytes // cb), 4096))
-    idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(-(-ny // yc)) for ix in range(-(-nx // xc))]
+    idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
     nstage = 2 if len(idxs) > per else 1
     host = _pinned_stage(per * cb, nstage)
     dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
@@ -460,14 +463,14 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
                 c0 = it * tc                            # first step of the chunk
                 t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
-                y0, y1 = iy * yc, min((iy + 1) * yc, ny)
-                x0, x1 = ix * xc, min((ix + 1) * xc, nx)
-                dst = cube[t0 - ka:t1 - ka, y0:y1, x0:x1]
+                y0, y1 = max(iy * yc, ya), min((iy + 1) * yc, yb)
+                x0, x1 = max(ix * xc, xa), min((ix + 1) * xc, xb)
+                dst = cube[t0 - ka:t1 - ka, y0 - ya:y1 - ya, x0 - xa:x1 - xa]
                 if r == -100:                           # absent chunk = fill value
                     dst.fill_(float(za._fill()))
                 else:
                     blk = dev[k][i * cb:(i + 1) * cb].view(tdt).view(tc, yc, xc)
-                    dst.copy_(blk[t0 - c0:t1 - c0, :y1 - y0, :x1 - x0])
+                    dst.copy_(blk[t0 - c0:t1 - c0, y0 - iy * yc:y1 - iy * yc, x0 - ix * xc:x1 - ix * xc])
             ev = torch.cuda.Event()
             ev.record(copy_stream)
             done[k] = ev
@@ -690,6 +693,33 @@ def _open_netcdf3(path, var):
     return DataArray(data, dims, coords, name=var, attrs=attrs)
 
 
+def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
+    """(y0, y1, x0, x1) on the STORED axes when the clip to the regions' extent (`grid.py:150-217`) keeps one
+    contiguous run along both spatial axes, else None (the clip then happens after the load)."""
+    from .dataset import Grid
+    xname, yname = xycoords
+    if dims[1] not in (xname, yname) or dims[2] not in (xname, yname) or dims[1] == dims[2]:
+        return None
+    if xname not in coords or yname not in coords:
+        return None
+    try:
+        g = Grid(np.asarray(coords[xname], dtype=float), np.asarray(coords[yname], dtype=float), lon_is_360=lon_is_360)
+        inlat, inlon = g.clip_grid_to_georegions_extent(georegions)
+    except (ValueError, AttributeError, TypeError):
+        return None
+
+    def run(mask):
+        idx = np.nonzero(np.asarray(mask))[0]
+        if len(idx) == 0 or idx[-1] - idx[0] + 1 != len(idx):
+            return None
+        return int(idx[0]), int(idx[-1]) + 1
+
+    ry, rx = run(inlat), run(inlon)
+    if ry is None or rx is None:
+        return None
+    return (ry + rx) if dims[1] == yname else (rx + ry)
+
+
 def _time_window(tindex, time_sel):
     """(k0, k1) when ``time_sel`` (as `Dataset` applies it, `dataset.py:88-92`) picks one contiguous run of an
     ascending time index, else None (the selection is then applied after the load)."""
@@ -749,9 +779,17 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             window = None
             if time_sel is not None and za.dims and za.dims[0] == timecoord and timecoord in coords:
                 window = _time_window(coords[timecoord], time_sel)
-            data, za = zarr_to_device(paths[0], var, device=device, t_range=window)
+            # a clip to the regions' extent (`dataset.py:150-175`): only the chunks that touch the box are read,
+            # and only the box reaches HBM; `Dataset` repeats the clip on the clipped grid (a no-op)
+            box = None
+            if georegions is not None and len(za.dims) == 3:
+                box = _clip_box(za.dims, coords, xycoords, georegions, lon_is_360)
+            data, za = zarr_to_device(paths[0], var, device=device, t_range=window, yx_box=box)
             if window is not None:
                 coords[timecoord] = coords[timecoord][window[0]:window[1]]
+            if box is not None:
+                coords[za.dims[1]] = coords[za.dims[1]][box[0]:box[1]]
+                coords[za.dims[2]] = coords[za.dims[2]][box[2]:box[3]]
         except ValueError:
             data = None
         if data is not None:

@@ -397,6 +397,34 @@ def test_time_selection_reads_only_its_chunks(torch_cuda, tmp_path, monkeypatch)
             assert 0 < sum(calls) < n_all, (sum(calls), n_all)                       # fewer chunk files than the store holds
 
 
+def test_clip_to_regions_reads_only_the_box(torch_cuda, tmp_path, monkeypatch):
+    """georegions= on the streaming route: only the chunks touching the regions' extent are read and only the
+    box reaches HBM; same dataset (data, coordinates, cell ids) as the host route, 0-360 and +-180 stores."""
+    from aggfly_amd import codec
+    T, ny, nx = 48, 40, 72
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=71, scattered_nan=9)
+    time = pd.date_range("2005-07-01", periods=T, freq="h")
+    lat = 20 + 1.0 * np.arange(ny)
+    calls = []
+    real = codec.decode_files
+    monkeypatch.setattr(codec, "decode_files", lambda kind, paths, outs, threads=8: calls.append(len(paths)) or real(kind, paths, outs, threads))
+    regions = af.GeoRegions(pd.DataFrame({"geoid": ["a", "b"], "minx": [-100.2, -95.0], "miny": [31.3, 35.0],
+                                          "maxx": [-96.0, -90.4], "maxy": [38.0, 41.7]}))
+    for lon, is360 in ((230 + 1.0 * np.arange(nx), True), (-130 + 1.0 * np.arange(nx), False)):
+        ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=is360)
+        store = str(tmp_path / f"clip_{is360}.zarr")
+        af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 24, "latitude": 8, "longitude": 12})
+        host = af.dataset_from_path(store, "t2m", georegions=regions, lon_is_360=is360)
+        calls.clear()
+        dev = af.dataset_from_path(store, "t2m", georegions=regions, lon_is_360=is360, device="cuda")
+        assert dev.cube().is_cuda and dev.cube().shape == host.cube().shape and dev.cube().shape[1] < ny and dev.cube().shape[2] < nx
+        np.testing.assert_array_equal(dev.cube().cpu().numpy(), host.cube())
+        np.testing.assert_array_equal(dev.latitude, host.latitude)
+        np.testing.assert_array_equal(dev.longitude, host.longitude)
+        np.testing.assert_array_equal(dev.grid.cell_id, host.grid.cell_id)
+        assert 0 < sum(calls) < 2 * 5 * 6                                             # of 60 chunk files
+
+
 def test_packed_int16_store_streams_packed_and_unpacks_in_hbm(torch_cuda, tmp_path):
     """ERA5-style packing (int16 + scale_factor / add_offset / _FillValue): the streaming route moves the
     packed integers over PCIe and applies the CF decoding in HBM — bit-identical to the host route, for
