@@ -574,12 +574,16 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format:
     else:
         raise ValueError("zarr_format must be 2 or 3")
     grid = [range((s + c - 1) // c) for s, c in zip(data.shape, chunks)]
-    for idx in np.ndindex(*[len(g) for g in grid]):
-        blk = np.full(chunks, np.nan if data.dtype.kind == "f" else 0, dtype=data.dtype)
+
+    def write_chunk(idx):
         sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, data.shape))
         part = data[sl]
-        blk[tuple(slice(0, n) for n in part.shape)] = part
-        raw = blk.tobytes()
+        if part.shape == tuple(chunks):
+            blk = np.ascontiguousarray(part)
+        else:                                               # edge chunk: padded with the fill value
+            blk = np.full(chunks, np.nan if data.dtype.kind == "f" else 0, dtype=data.dtype)
+            blk[tuple(slice(0, n) for n in part.shape)] = part
+        raw = blk.tobytes() if cid in (None, "zlib", "gzip") else None
         if cid == "zlib":
             raw = zlib.compress(raw, compressor.get("level", 1))
         elif cid == "gzip":
@@ -597,6 +601,14 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format:
         os.makedirs(os.path.dirname(fn), exist_ok=True)
         with open(fn, "wb") as f:
             f.write(raw)
+
+    idxs = list(np.ndindex(*[len(g) for g in grid]))
+    if len(idxs) > 4 and data.nbytes > (8 << 20):           # compress + write chunk-parallel (the codecs drop the GIL)
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            list(ex.map(write_chunk, idxs))
+    else:
+        for idx in idxs:
+            write_chunk(idx)
 
 
 def _encode_time(t):
