@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import torch
 import test_gpu_fuzz as f
 bad = 0
-for seed in range(28, 90):
+for seed in range(int(os.environ.get("FUZZ_LO", 28)), int(os.environ.get("FUZZ_HI", 90))):
     try:
         f.test_random_specs_match_oracle(torch, seed)
     except Exception as e:

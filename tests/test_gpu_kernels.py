@@ -263,6 +263,37 @@ def test_every_load_path_arm_gives_identical_cells(torch_cuda, dtype):
     assert len(seen) == len(arms), seen          # every arm resolved to its own kernel
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ragged_group_lengths_on_every_arm(torch_cuda, dtype):
+    """Inner groups of every length 0..19 in random order (shorter than, equal to and just past the 4 / 8 / 16
+    rows a burst holds; the short-group rule picks the LDS ring by itself for some of them): bursts, batched
+    tails and the ring give the same cells, and those equal the oracle."""
+    from aggfly_amd import hip
+    rng = np.random.default_rng(31)
+    lens = np.concatenate([rng.permutation(20), rng.integers(0, 20, 60), [1, 1, 2, 3, 0, 0, 17]])
+    ib = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T, ny, nx = int(ib[-1]), 6, 44
+    cube = _cube(T, ny, nx, dtype, seed=17)
+    G = len(lens)
+    ob = np.array([0, 7, 7, 30, G], dtype=np.int64)                      # an empty outer period too
+    cols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="mean", transform="pow", transform_arg=2, outer="mean"),
+            dict(inner="max", outer="max"), dict(inner="nanmean", outer="min"), dict(inner="bins", inner_args=(5, 25, 0), outer="sum")]
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    d = torch_cuda.from_numpy(cube).cuda()
+    want = _oracle_two_level(cube.astype(np.float64), ib, ob, cols)
+    arms = [0, 104, 108, 204, 208, 1204, 1208] if dtype == np.float64 else [0, 104, 108, 204, 208, 404, 408, 1404, 1408]
+    for arm in arms:
+        got = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True, tuning=arm).run_temporal(d).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=f"arm {arm}")
+    # single level on the same ragged groups (sine_dd rides on min / max / mean of 0..19-step windows)
+    cols1 = [dict(inner="sum"), dict(inner="min"), dict(inner="sine_dd", inner_args=(10, 30, 0)), dict(inner="dd", inner_args=(12, 28, 1))]
+    want1 = _oracle_two_level(cube.astype(np.float64), ib, None, cols1)
+    for arm in arms[:5]:
+        got1 = hip.FusedPlan(T, ny * nx, code, ib, np.arange(G + 1), cols1, tuning=arm).run_temporal(d).cpu().numpy()
+        np.testing.assert_array_equal(got1[[0, 1, 3]], want1[[0, 1, 3]], err_msg=f"arm {arm}")
+        np.testing.assert_allclose(got1[2], want1[2], rtol=1e-10, atol=1e-10, equal_nan=True)
+
+
 def test_edge_shapes(torch_cuda):
     """Ragged and degenerate inputs: odd row length (scalar-load fallback), one time step, groups
     shorter than the prefetch depth, an all-NaN cube, a weights table with a region whose cells
