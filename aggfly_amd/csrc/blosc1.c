@@ -239,7 +239,7 @@ int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64
     if (codec == 1) { if ((rc = need_lz4())) return rc; }
     else if (codec == 4) { if ((rc = need_zstd())) return rc; }
     else if (codec != 0 && codec != 3) return fail(AFCODEC_E_UNSUPPORTED, "blosc codec not supported (snappy)");
-    if (blocksize <= 0 || ts <= 0) return fail(AFCODEC_E_FORMAT, "bad blocksize / typesize");
+    if (blocksize <= 0 || ts <= 0 || blocksize > nbytes) return fail(AFCODEC_E_FORMAT, "bad blocksize / typesize");
     const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
     const int64_t leftover = nbytes % blocksize;
     if (16 + 4 * nblocks > cbytes) return fail(AFCODEC_E_FORMAT, "block table beyond the chunk");
