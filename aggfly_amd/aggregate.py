@@ -275,18 +275,42 @@ def _zero_weight_regions(wdf) -> set:
     return zr
 
 
-def _assemble_frame(res: np.ndarray, names, region_ids, labels, weights) -> pd.DataFrame:
-    """Long frame + NaN-row policy (`spatial.py:136-154`).  res: [K, R, P]."""
-    n_regions, n_time = res.shape[1], res.shape[2]
-    out = pd.DataFrame({"region_id": np.repeat(region_ids, n_time),
-                        "time": np.tile(_label_values(labels), n_regions)})
-    for k, nm in enumerate(names):
-        out[nm] = res[k].reshape(-1)
+def _assemble_frame(res, names, region_ids, labels, weights) -> pd.DataFrame:
+    """Long frame + NaN-row policy (`spatial.py:136-154`).  res: [K, R, P], a numpy array or an HBM tensor.
+
+    The rows to keep are found on the [R, P] panel and only those are materialised — on the GPU when the
+    panel is still there (mask, compaction, then one download of the kept values).  The reference builds
+    the full R*P frame and drops rows (`spatial.py:144-153`); at configs[3] (3,600 regions x 251 years x
+    13 bins) that pandas work costs ~100x the GPU time of the whole job."""
+    names = list(names)
+    rid = np.asarray(region_ids)
+    zero_mask = None
     if getattr(weights, "zero_weight", "area") == "nan":
         zero_regions = _zero_weight_regions(weights.weights)
-        keep = out["region_id"].isin(zero_regions) | out[list(names)].notna().all(axis=1)
-        return out.loc[keep].reset_index(drop=True)
-    return out.dropna(subset=list(names)).reset_index(drop=True)
+        if zero_regions:
+            zero_mask = np.isin(rid, np.fromiter(zero_regions, dtype=rid.dtype, count=len(zero_regions)))
+    if isinstance(res, np.ndarray):
+        n_regions, n_time = res.shape[1], res.shape[2]
+        ok = ~np.isnan(res).any(axis=0) if names else np.ones((n_regions, n_time), dtype=bool)      # [R, P]
+        if zero_mask is not None:
+            ok = ok | zero_mask[:, None]
+        ri, ti = np.nonzero(ok)                                           # row-major: region, then time, like repeat/tile
+        vals = [res[k][ri, ti] for k in range(len(names))]
+    else:
+        import torch
+        n_regions, n_time = res.shape[1], res.shape[2]
+        ok = ~torch.isnan(res).any(dim=0) if names else torch.ones((n_regions, n_time), dtype=torch.bool, device=res.device)
+        if zero_mask is not None:
+            ok = ok | torch.as_tensor(zero_mask, device=res.device)[:, None]
+        flat = ok.reshape(-1).nonzero().squeeze(1)
+        kept = res.reshape(res.shape[0], -1).index_select(1, flat).cpu().numpy() if names else None
+        flat = flat.cpu().numpy()
+        ri, ti = np.divmod(flat, n_time)
+        vals = [kept[k] for k in range(len(names))]
+    cols = {"region_id": rid[ri], "time": _label_values(labels)[ti]}
+    for nm, v in zip(names, vals):
+        cols[nm] = v
+    return pd.DataFrame(cols, copy=False)
 
 
 class SpatialAggregator:
@@ -315,7 +339,7 @@ class SpatialAggregator:
             xs.append(c.reshape(c.shape[0], -1).t().to(torch.float64))
         x = torch.stack(xs).contiguous()
         _, _, res = csr.wavg(x)
-        return _assemble_frame(res.cpu().numpy(), self.names, region_ids, labels, self.weights_obj)
+        return _assemble_frame(res, self.names, region_ids, labels, self.weights_obj)
 
 
 def aggregate_space(dataset_dict: Dict[str, Dataset], weights, npartitions=None, **kwargs) -> pd.DataFrame:
@@ -327,9 +351,24 @@ def aggregate_space(dataset_dict: Dict[str, Dataset], weights, npartitions=None,
 # the whole path
 # --------------------------------------------------------------------------------------
 def _merge_regions(df: pd.DataFrame, weights) -> pd.DataFrame:
-    """`aggregate.py:276-280`."""
+    """`aggregate.py:276-280`: ``shp[[regionid]].merge(df, left_index=True, right_on="region_id")`` minus the
+    key column.  When the region table's index is unique and ascending and the panel is region-major (it
+    always is here), that merge is a lookup: same rows, order, index and columns without pandas' generic join
+    (which takes 60 ms on the 900 k-row panel of configs[3], ten times the kernels)."""
     gr = weights.georegions
-    return gr.shp[[gr.regionid]].merge(df, left_index=True, right_on="region_id").drop(columns="region_id")
+    shp = gr.shp
+    idx = shp.index
+    rid = df["region_id"].to_numpy()
+    if (idx.is_unique and idx.is_monotonic_increasing and gr.regionid not in df.columns and isinstance(df.index, pd.RangeIndex)
+            and (len(rid) < 2 or bool((rid[1:] >= rid[:-1]).all()))):
+        pos = idx.get_indexer(rid)
+        cols = {gr.regionid: shp[gr.regionid].to_numpy()[pos]}
+        if (pos >= 0).all():
+            for c in df.columns:
+                if c != "region_id":
+                    cols[c] = df[c].to_numpy()
+            return pd.DataFrame(cols, index=df.index, copy=False)
+    return shp[[gr.regionid]].merge(df, left_index=True, right_on="region_id").drop(columns="region_id")
 
 
 def panel_arrays(weights, dataset: Dataset, aggregator_dict, engine: str = "auto"):
@@ -381,7 +420,7 @@ def aggregate_dataset(weights, dataset: Dataset = None, aggregator_dict=None, da
         aggregator_dict = kwargs
     if aggregator_dict is not None:
         res, names, region_ids, labels = panel_arrays(weights, dataset, aggregator_dict, engine)
-        df = _assemble_frame(res.cpu().numpy(), names, region_ids, labels, weights)
+        df = _assemble_frame(res, names, region_ids, labels, weights)
     else:
         if dataset_dict is None:
             dataset_dict = {"variable": dataset}

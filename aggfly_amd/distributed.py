@@ -161,5 +161,5 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
         _, _, full = reduce_num_den(pr[0].panel["num"], pr[0].panel["den"], group)
     else:
         raise ValueError("shard must be 'time' or 'cells'")
-    df = agg._assemble_frame(full.cpu().numpy(), names, region_ids, labels, weights)
+    df = agg._assemble_frame(full, names, region_ids, labels, weights)
     return agg._merge_regions(df, weights)
