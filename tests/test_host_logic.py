@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import sys
+from types import SimpleNamespace
 
 import numpy as np
 import pandas as pd
@@ -206,3 +207,46 @@ def test_duplicate_output_keys_follow_dict_semantics():
     assert len(fused) == 3
     assert by_key["a_5.0_95.0"].inner.ddargs == (5.0, 95.0, 1.0)          # the later row won
     assert by_key["a_1.0_2.0"].inner.calc == "max"                        # the later NAME won that key
+
+
+def test_frame_assembly_and_region_merge_equal_the_reference_recipe():
+    """`_assemble_frame` / `_merge_regions` take shortcuts (rows chosen on the [R, P] panel, lookup instead of a
+    generic join); on random panels they must give exactly what the reference's pandas recipe gives
+    (`spatial.py:136-154`: full frame, NaN-row policy; `aggregate.py:276-280`: merge with the region table)."""
+    from aggfly_amd import aggregate as agg
+
+    def recipe(res, names, region_ids, labels, weights):
+        n_regions, n_time = res.shape[1], res.shape[2]
+        out = pd.DataFrame({"region_id": np.repeat(region_ids, n_time), "time": np.tile(agg._label_values(labels), n_regions)})
+        for k, nm in enumerate(names):
+            out[nm] = res[k].reshape(-1)
+        if getattr(weights, "zero_weight", "area") == "nan":
+            zr = agg._zero_weight_regions(weights.weights)
+            keep = out["region_id"].isin(zr) | out[list(names)].notna().all(axis=1)
+            return out.loc[keep].reset_index(drop=True)
+        return out.dropna(subset=list(names)).reset_index(drop=True)
+
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        R, P, K = int(rng.integers(1, 30)), int(rng.integers(1, 12)), int(rng.integers(1, 5))
+        res = rng.normal(size=(K, R, P))
+        res[rng.random((K, R, P)) < 0.15] = np.nan
+        if trial % 3 == 0:
+            res[:, rng.integers(0, R), :] = np.nan
+        names = [f"c{i}" for i in range(K)]
+        index = pd.RangeIndex(R + 3) if trial % 3 else pd.Index(np.sort(rng.choice(100, R + 3, replace=False)))
+        if trial % 7 == 0:
+            index = pd.Index(rng.permutation(R + 3))                      # not ascending: the merge falls back to pandas
+        rid = np.sort(rng.choice(np.asarray(index), R, replace=False))
+        if trial % 11 == 0:
+            rid[-1] = 9999                                                # a region the table does not hold: dropped by the merge
+        labels = pd.date_range("2000-01-31", periods=P, freq="ME") if trial % 2 else af.cf_range("2000-01-01", P, "D", "noleap")
+        wdf = pd.DataFrame({"index_right": np.repeat(rid, 2), "weight": np.where(np.repeat(rng.random(R) < 0.3, 2), 0.0, 1.0), "cell_id": 0})
+        shp = pd.DataFrame({"geoid": [f"r{i}" for i in range(R + 3)], "other": 1.0}, index=index)
+        for zw in ("area", "nan"):
+            w = SimpleNamespace(zero_weight=zw, weights=wdf, georegions=af.GeoRegions(shp))
+            want = recipe(res, names, rid, labels, w)
+            got = agg._assemble_frame(res, names, rid, labels, w)
+            pd.testing.assert_frame_equal(got, want)
+            merged = shp[["geoid"]].merge(want, left_index=True, right_on="region_id").drop(columns="region_id")
+            pd.testing.assert_frame_equal(agg._merge_regions(got, w), merged)
