@@ -775,13 +775,13 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
     if not paths:
         raise FileNotFoundError(path)
     engine = kwargs.pop("engine", None)
-    if device is not None and len(paths) == 1 and (engine == "zarr" or (engine is None and _looks_like_zarr(paths[0]))):
-        data = None
-        try:
-            za = ZarrArray(os.path.join(paths[0], var))
+    if device is not None and all(engine == "zarr" or (engine is None and _looks_like_zarr(p)) for p in paths):
+
+        def part_to_device(path1):
+            za = ZarrArray(os.path.join(path1, var))
             coords = {}
             for d in za.dims:
-                cp = os.path.join(paths[0], d)
+                cp = os.path.join(path1, d)
                 if is_zarr_array(cp):
                     c = ZarrArray(cp)
                     v = c.read(threads=1)
@@ -796,12 +796,30 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             box = None
             if georegions is not None and len(za.dims) == 3:
                 box = _clip_box(za.dims, coords, xycoords, georegions, lon_is_360)
-            data, za = zarr_to_device(paths[0], var, device=device, t_range=window, yx_box=box)
+            data, za = zarr_to_device(path1, var, device=device, t_range=window, yx_box=box)
             if window is not None:
                 coords[timecoord] = coords[timecoord][window[0]:window[1]]
             if box is not None:
                 coords[za.dims[1]] = coords[za.dims[1]][box[0]:box[1]]
                 coords[za.dims[2]] = coords[za.dims[2]][box[2]:box[3]]
+            return data, za, coords
+
+        try:
+            got = [part_to_device(p_) for p_ in paths]
+            if len(got) > 1:                        # a list / glob of stores: concatenated along time like open_mfdataset
+                import torch
+                if any(g[1].dims != got[0][1].dims or g[1].dims[0] != timecoord for g in got):
+                    raise ValueError("stores of a multi-file dataset must share their (time-leading) dimensions")
+                t0 = got[0][2][timecoord]
+                if isinstance(t0, CFTimeIndex):
+                    time = CFTimeIndex(np.concatenate([g[2][timecoord].seconds for g in got]), t0.calendar)
+                else:
+                    time = pd.DatetimeIndex(np.concatenate([np.asarray(g[2][timecoord]) for g in got]))
+                coords = dict(got[0][2])
+                coords[timecoord] = time
+                data, za = torch.cat([g[0] for g in got], dim=0), got[0][1]
+            else:
+                data, za, coords = got[0]
         except ValueError:
             data = None
         if data is not None:

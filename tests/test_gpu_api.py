@@ -397,6 +397,30 @@ def test_time_selection_reads_only_its_chunks(torch_cuda, tmp_path, monkeypatch)
             assert 0 < sum(calls) < n_all, (sum(calls), n_all)                       # fewer chunk files than the store holds
 
 
+def test_multi_file_dataset_streams_every_store(torch_cuda, tmp_path):
+    """A list / glob of per-year stores goes through the streaming route store by store and is joined along
+    time in HBM, like the host route's open_mfdataset-style concatenation (preprocess applied either way)."""
+    ny, nx = 7, 9
+    lat, lon = 30 + 0.5 * np.arange(ny), 200 + 0.5 * np.arange(nx)
+    cubes = []
+    for i, year in enumerate((2001, 2002, 2003)):
+        T = 24 * (10 + i)
+        cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=80 + i, scattered_nan=5) + np.float32(273.15)
+        cubes.append(cube)
+        ds = af.Dataset(_xr(cube, pd.date_range(f"{year}-01-01", periods=T, freq="h"), lat, lon), lon_is_360=True)
+        af.dataset_to_zarr(ds, str(tmp_path / f"era_{year}.zarr"), var="t2m", chunks={"time": 50, "latitude": ny, "longitude": nx})
+    pattern = str(tmp_path / "era_*.zarr")
+    pre = lambda x: x - 273.15
+    host = af.dataset_from_path(pattern, "t2m", preprocess=pre)
+    dev = af.dataset_from_path(pattern, "t2m", preprocess=pre, device="cuda")
+    assert dev.cube().is_cuda and dev.cube().shape == (24 * 33, ny, nx) and dev.time.equals(host.time)
+    np.testing.assert_array_equal(dev.cube().cpu().numpy(), host.cube())
+    dev2 = af.dataset_from_path(pattern, "t2m", preprocess=pre, device="cuda", time_sel=slice("2002-01-03", "2003-01-02"))
+    host2 = af.dataset_from_path(pattern, "t2m", preprocess=pre, time_sel=slice("2002-01-03", "2003-01-02"))
+    assert dev2.time.equals(host2.time)
+    np.testing.assert_array_equal(dev2.cube().cpu().numpy(), host2.cube())
+
+
 def test_clip_to_regions_reads_only_the_box(torch_cuda, tmp_path, monkeypatch):
     """georegions= on the streaming route: only the chunks touching the regions' extent are read and only the
     box reaches HBM; same dataset (data, coordinates, cell ids) as the host route, 0-360 and +-180 stores."""
