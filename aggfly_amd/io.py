@@ -745,7 +745,7 @@ def _time_window(tindex, time_sel):
                 return int(loc), int(loc) + 1
             if isinstance(loc, slice) and loc.step in (None, 1):
                 k0, k1, _ = loc.indices(n)
-                return (k0, k1) if k1 > k0 else None
+                return (k0, k1) if k1 > k0 else (0, 0)          # nothing selected in this store: nothing is read
             return None
         y = np.asarray(tindex.fields()[0])
         if isinstance(time_sel, slice):
@@ -754,7 +754,9 @@ def _time_window(tindex, time_sel):
             idx = np.nonzero((y >= lo) & (y <= hi))[0]
         else:
             idx = np.nonzero(y == int(str(time_sel)[:4]))[0]
-        if len(idx) and idx[-1] - idx[0] + 1 == len(idx):
+        if len(idx) == 0:
+            return 0, 0
+        if idx[-1] - idx[0] + 1 == len(idx):
             return int(idx[0]), int(idx[-1]) + 1
     except (KeyError, TypeError, ValueError, AttributeError):
         pass
