@@ -43,6 +43,8 @@ def load():
                                                    C.c_int, C.POINTER(C.c_int64)]
         lib.afcodec_decode_files.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                              C.c_int, C.POINTER(C.c_int64)]
+        lib.afcodec_decode_ranges.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64)]
         lib.afcodec_blosc_bound.restype = C.c_int64
         lib.afcodec_blosc_bound.argtypes = [C.c_int64, C.c_int64]
         lib.afcodec_blosc_encode_lz4.restype = C.c_int64
@@ -58,7 +60,7 @@ def load():
 
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
-           "afcodec_blosc_decode_files", "afcodec_decode_files",
+           "afcodec_blosc_decode_files", "afcodec_decode_files", "afcodec_decode_ranges",
            "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode")
 
 
@@ -134,6 +136,23 @@ def decode_files(kind: str, paths, outs, threads: int = 8):
     if lib.afcodec_decode_files(KIND[kind], n, pp, dp, ds, int(threads), res):
         bad = [paths[i] for i in range(n) if res[i] < 0 and res[i] != -100]
         raise CodecError(f"decode_files({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+    return [int(res[i]) for i in range(n)]
+
+
+def decode_ranges(kind: str, locators, outs, threads: int = 8):
+    """Like `decode_files` for ``locators[i] = (path, offset, nbytes)`` — nbytes < 0 = the whole file, None =
+    an absent chunk (reported as -100 without touching the disk)."""
+    lib = load()
+    n = len(locators)
+    pp = (C.c_char_p * n)(*[os.fsencode(l[0]) if l is not None else b"" for l in locators])
+    offs = (C.c_int64 * n)(*[int(l[1]) if l is not None else 0 for l in locators])
+    lens = (C.c_int64 * n)(*[int(l[2]) if l is not None else -1 for l in locators])
+    dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ds = (C.c_int64 * n)(*[o.nbytes for o in outs])
+    res = (C.c_int64 * n)()
+    if lib.afcodec_decode_ranges(KIND[kind], n, pp, offs, lens, dp, ds, int(threads), res):
+        bad = [locators[i] for i in range(n) if res[i] < 0 and res[i] != -100]
+        raise CodecError(f"decode_ranges({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
     return [int(res[i]) for i in range(n)]
 
 

@@ -329,10 +329,12 @@ static int64_t decode_kind(int kind, const uint8_t* buf, int64_t sz, void* dst, 
     }
 }
 
-/* Reads and decodes the chunk files paths[i] -> dsts[i] on an OpenMP team (no Python between chunks).
- * A missing file leaves results[i] = -100 (the caller fills the Zarr fill value). */
-int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
-                         int nthreads, int64_t* results) {
+/* Reads and decodes byte ranges of chunk files -> dsts[i] on an OpenMP team (no Python between chunks):
+ * [offsets[i], offsets[i] + lengths[i]) of paths[i]; lengths[i] < 0 (or offsets == NULL) = the whole file.
+ * Ranges serve the inner chunks of Zarr v3 shards.  A missing file leaves results[i] = -100 (the caller
+ * fills the Zarr fill value). */
+int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths,
+                          void* const* dsts, const int64_t* dstsizes, int nthreads, int64_t* results) {
     int bad = 0;
     if (nthreads < 1) nthreads = 1;
     if (kind == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
@@ -344,11 +346,16 @@ int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* co
         for (int64_t i = 0; i < n; ++i) {
             FILE* f = fopen(paths[i], "rb");
             if (!f) { results[i] = -100; continue; }
-            fseek(f, 0, SEEK_END);
-            const int64_t sz = ftell(f);
-            fseek(f, 0, SEEK_SET);
+            int64_t off = 0, sz = -1;
+            if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
+            if (sz < 0) {
+                fseek(f, 0, SEEK_END);
+                sz = ftell(f);
+            }
             int64_t r;
-            if (kind == 0 && sz <= dstsizes[i]) {            /* raw: straight into the destination */
+            if (fseek(f, (long)off, SEEK_SET) != 0) {
+                r = fail(AFCODEC_E_FORMAT, "chunk range beyond the file");
+            } else if (kind == 0 && sz <= dstsizes[i]) {     /* raw: straight into the destination */
                 r = (int64_t)fread(dsts[i], 1, (size_t)sz, f) == sz ? sz : fail(AFCODEC_E_FORMAT, "chunk file could not be read");
             } else {
                 if (sz > cap) { free(buf); buf = (uint8_t*)malloc((size_t)sz + 64); cap = buf ? sz : 0; }
@@ -361,7 +368,11 @@ int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* co
         }
         free(buf);
     }
-    return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files failed to decode (see results[])") : AFCODEC_OK;
+    return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
+}
+int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
+                         int nthreads, int64_t* results) {
+    return afcodec_decode_ranges(kind, n, paths, NULL, NULL, dsts, dstsizes, nthreads, results);
 }
 int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
                                int nthreads, int64_t* results) {

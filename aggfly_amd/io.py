@@ -91,8 +91,8 @@ class ZarrArray:
     write by default.  Both reduce to: a chunk file name, a chain of bytes -> bytes decoders, a dtype.
 
     Format 3 is implemented from the specification (bytes / gzip / zstd / blosc / crc32c codecs, default
-    and v2 chunk-key encodings, ``dimension_names``); no zarr-python 3 is available in this image to
-    cross-check against, sharded arrays are refused."""
+    and v2 chunk-key encodings, ``dimension_names``, ``sharding_indexed`` shards); no zarr-python 3 is available
+    in this image to cross-check against."""
 
     def __init__(self, path: str):
         self.path = path
@@ -117,6 +117,7 @@ class ZarrArray:
         if self.meta.get("filters"):
             raise ValueError("Zarr filters are not supported")
         self.format = 2
+        self.shard_shape = None
         self.shape = tuple(self.meta["shape"])
         self.chunks = tuple(self.meta["chunks"])
         self.dtype = np.dtype(self.meta["dtype"])
@@ -156,9 +157,29 @@ class ZarrArray:
             self.sep, self.key_prefix = conf.get("separator", "."), ""
         else:
             raise ValueError(f"unsupported chunk key encoding {enc.get('name')!r}")
+        codecs = m.get("codecs", [])
+        self.shard_shape = None
+        if len(codecs) == 1 and codecs[0].get("name") == "sharding_indexed":
+            # a chunk file is a SHARD: inner chunks back to back plus an index of (offset, nbytes) uint64 pairs,
+            # one per inner chunk in C order, at the end (default) or the start of the file
+            cf = codecs[0].get("configuration", {}) or {}
+            if "chunk_shape" not in cf:
+                raise ValueError("sharding_indexed without an inner chunk_shape")
+            self.shard_shape, self.chunks = self.chunks, tuple(cf["chunk_shape"])
+            if any(s_ % c_ for s_, c_ in zip(self.shard_shape, self.chunks)):
+                raise ValueError("shard shape must be a multiple of the inner chunk shape")
+            idx_names = [c.get("name") for c in cf.get("index_codecs", [{"name": "bytes"}, {"name": "crc32c"}])]
+            if idx_names not in (["bytes"], ["bytes", "crc32c"]):
+                raise ValueError(f"unsupported shard index codecs {idx_names}")
+            self.shard_index_crc = "crc32c" in idx_names
+            self.shard_index_at_end = cf.get("index_location", "end") == "end"
+            self._shard_index_cache = {}
+            codecs = cf.get("codecs", [])
+        elif any(c.get("name") == "sharding_indexed" for c in codecs):
+            raise ValueError("sharding_indexed must be the only codec of the array")
         self.codecs = []
         seen_bytes = False
-        for c in m.get("codecs", []):
+        for c in codecs:
             name, cf = c.get("name"), c.get("configuration", {}) or {}
             if name == "bytes":
                 if cf.get("endian", "little") != "little" and self.dtype.itemsize > 1:
@@ -170,7 +191,7 @@ class ZarrArray:
             elif name in ("gzip", "zstd", "blosc", "crc32c"):
                 self.codecs.insert(0, dict(cf, id=name))                # decode order is the reverse of encode order
             elif name == "sharding_indexed":
-                raise ValueError("sharded Zarr v3 arrays are not supported")
+                raise ValueError("nested sharding is not supported")
             else:
                 raise ValueError(f"unsupported Zarr v3 codec {name!r}")
         if not seen_bytes:
@@ -206,6 +227,42 @@ class ZarrArray:
             key = self.sep.join([self.key_prefix] + [str(i) for i in idx]) if self.key_prefix else self.sep.join(str(i) for i in idx)
         return os.path.join(self.path, *key.split("/"))
 
+    def _shard_index(self, path):
+        """(offsets, nbytes) uint64 arrays of one shard file, C order over its inner chunks; None if absent."""
+        hit = self._shard_index_cache.get(path)
+        if hit is not None or path in self._shard_index_cache:
+            return hit
+        n = int(np.prod([s_ // c_ for s_, c_ in zip(self.shard_shape, self.chunks)]))
+        nb = n * 16 + (4 if self.shard_index_crc else 0)
+        idx = None
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                if self.shard_index_at_end:
+                    f.seek(-nb, os.SEEK_END)
+                raw = f.read(nb)
+            tab = np.frombuffer(raw[:n * 16], dtype="<u8").reshape(n, 2)
+            idx = (tab[:, 0].copy(), tab[:, 1].copy())
+        if len(self._shard_index_cache) > 4096:
+            self._shard_index_cache.clear()
+        self._shard_index_cache[path] = idx
+        return idx
+
+    def chunk_locator(self, idx):
+        """(file, offset, nbytes) of chunk ``idx`` — nbytes -1 = the whole file — or None when it is absent."""
+        if self.shard_shape is None:
+            fn = self.chunk_path(idx)
+            return (fn, 0, -1) if os.path.exists(fn) else None
+        per = [s_ // c_ for s_, c_ in zip(self.shard_shape, self.chunks)]
+        fn = self.chunk_path(tuple(i // p_ for i, p_ in zip(idx, per)))
+        tab = self._shard_index(fn)
+        if tab is None:
+            return None
+        k = int(np.ravel_multi_index(tuple(i % p_ for i, p_ in zip(idx, per)), per))
+        off, nb = int(tab[0][k]), int(tab[1][k])
+        if off == 0xFFFFFFFFFFFFFFFF and nb == 0xFFFFFFFFFFFFFFFF:
+            return None
+        return fn, off, nb
+
     def _fill(self):
         fv = self.fill_value
         if self.dtype.kind == "f":
@@ -225,11 +282,12 @@ class ZarrArray:
         return buf
 
     def _chunk(self, idx):
-        fn = self.chunk_path(idx)
-        if not os.path.exists(fn):
+        loc = self.chunk_locator(idx)
+        if loc is None:
             return np.full(self.chunks, self._fill(), dtype=self.dtype)
-        with open(fn, "rb") as f:
-            raw = self.decode(f.read())
+        with open(loc[0], "rb") as f:
+            f.seek(loc[1])
+            raw = self.decode(f.read() if loc[2] < 0 else f.read(loc[2]))
         arr = np.frombuffer(raw, dtype=self.disk_dtype, count=int(np.prod(self.chunks)) if self.shape else 1).reshape(self.chunks)
         return arr if self.disk_dtype.isnative else arr.astype(self.dtype)
 
@@ -362,7 +420,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
         paths, outs, spans, tails = [], [], [], []
         for it in its:
             t0, t1 = it * tc, min((it + 1) * tc, T)
-            paths.append(za.chunk_path((it, 0, 0)))
+            paths.append(za.chunk_locator((it, 0, 0)))
             spans.append((t0, t1))
             if t1 - t0 == tc:
                 outs.append(out[t0 - k0:t1 - k0])
@@ -371,7 +429,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
                 tmp = np.empty((tc, ny, nx), dtype=za.dtype)
                 outs.append(tmp)
                 tails.append(tmp)
-        res = codec.decode_files(za.native_kind, paths, outs, threads=threads)
+        res = codec.decode_ranges(za.native_kind, paths, outs, threads=threads)
         for (t0, t1), r, tmp in zip(spans, res, tails):
             if r == -100:                           # absent chunk = fill value
                 out[t0 - k0:t1 - k0] = za._fill()
@@ -457,7 +515,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             done[k].synchronize()                       # both staging buffers of slot k are free again
         hbuf = host[k][:len(batch) * cb].numpy()
         outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
-        res = codec.decode_files(za.native_kind, [za.chunk_path(i) for i in batch], outs, threads=threads)
+        res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], outs, threads=threads)
         with torch.cuda.stream(copy_stream):
             dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
@@ -540,7 +598,27 @@ def open_zarr(path: str, var: str, threads: int = 8) -> DataArray:
     return DataArray(data, dims, coords, name=var, attrs=arr.attrs)
 
 
-def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format: int = 2):
+_CRC32C_TABLE = None
+
+
+def _crc32c(data: bytes) -> int:
+    """CRC-32C (Castagnoli), bytewise table — only ever run over a shard index (a few KiB)."""
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC32C_TABLE = tab
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC32C_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format: int = 2, shards=None):
     d = os.path.join(path, name)
     os.makedirs(d, exist_ok=True)
     data = np.ascontiguousarray(data)
@@ -564,8 +642,15 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format:
         elif cid in ("zlib", "gzip"):
             cid = "gzip"
             codecs.append({"name": "gzip", "configuration": {"level": compressor.get("level", 1)}})
+        if shards is not None:
+            shards = tuple(int(x) for x in shards)
+            if any(s_ % c_ for s_, c_ in zip(shards, chunks)):
+                raise ValueError("shards must be multiples of chunks")
+            codecs = [{"name": "sharding_indexed", "configuration": {
+                "chunk_shape": list(chunks), "codecs": codecs, "index_location": "end",
+                "index_codecs": [{"name": "bytes", "configuration": {"endian": "little"}}, {"name": "crc32c"}]}}]
         meta = {"zarr_format": 3, "node_type": "array", "shape": list(data.shape), "data_type": v3name,
-                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(chunks)}},
+                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(shards if shards is not None else chunks)}},
                 "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
                 "fill_value": "NaN" if data.dtype.kind == "f" else 0, "codecs": codecs, "attributes": dict(attrs),
                 "dimension_names": list(dims), "storage_transformers": []}
@@ -575,7 +660,10 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format:
         raise ValueError("zarr_format must be 2 or 3")
     grid = [range((s + c - 1) // c) for s, c in zip(data.shape, chunks)]
 
-    def write_chunk(idx):
+    if shards is not None and zarr_format != 3:
+        raise ValueError("shards need zarr_format=3")
+
+    def encode_chunk(idx):
         sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, data.shape))
         part = data[sl]
         if part.shape == tuple(chunks):
@@ -597,10 +685,35 @@ def _write_array(path, name, data, dims, chunks, attrs, compressor, zarr_format:
             raw = codec.zstd_encode(blk, compressor.get("level", 3) or 3)
         elif cid is not None:
             raise ValueError(f"cannot write Zarr compressor {cid!r}")
+        return raw
+
+    def write_chunk(idx):
+        raw = encode_chunk(idx)
         fn = os.path.join(d, ".".join(str(i) for i in idx)) if zarr_format == 2 else os.path.join(d, "c", *[str(i) for i in idx])
         os.makedirs(os.path.dirname(fn), exist_ok=True)
         with open(fn, "wb") as f:
             f.write(raw)
+
+    if shards is not None:
+        per = [s_ // c_ for s_, c_ in zip(shards, chunks)]
+        nshard = [-(-n // s_) for n, s_ in zip(data.shape, shards)]
+        for sidx in np.ndindex(*nshard):
+            body, index = [], np.full((int(np.prod(per)), 2), 0xFFFFFFFFFFFFFFFF, dtype="<u8")
+            pos = 0
+            for k, inner in enumerate(np.ndindex(*per)):
+                idx = tuple(si * p_ + ii for si, p_, ii in zip(sidx, per, inner))
+                if any(i * c >= n for i, c, n in zip(idx, chunks, data.shape)):
+                    continue                                # an inner chunk wholly outside the array stays empty
+                raw = encode_chunk(idx)
+                index[k] = (pos, len(raw))
+                body.append(raw)
+                pos += len(raw)
+            tail = index.tobytes()
+            fn = os.path.join(d, "c", *[str(i) for i in sidx])
+            os.makedirs(os.path.dirname(fn), exist_ok=True)
+            with open(fn, "wb") as f:
+                f.write(b"".join(body) + tail + _crc32c(tail).to_bytes(4, "little"))
+        return
 
     idxs = list(np.ndindex(*[len(g) for g in grid]))
     if len(idxs) > 4 and data.nbytes > (8 << 20):           # compress + write chunk-parallel (the codecs drop the GIL)
@@ -633,11 +746,13 @@ def _auto_chunks(sizes: dict, itemsize: int, target_mb: float = 256) -> dict:
     return {"time": int(min(max(1, budget // (side * side)), nt)), "latitude": side, "longitude": side}
 
 
-def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress=True, mode: str = "w", zarr_format: int = 2):
+def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, compress=True, mode: str = "w", zarr_format: int = 2,
+                    shards=None):
     """`dataset_to_zarr` (`zarr_convert.py:50-121`): write a time-major, time-contiguous store.
     ``compress``: True / "blosc" -> Blosc-1 LZ4 + byte shuffle (what zarr-python 2 / numcodecs write by
     default and read back), "zstd" (zarr-python 3's default codec), "zlib" -> zlib level 1, False -> raw.
-    ``zarr_format``: 2 (``.zarray``) or 3 (``zarr.json``, ``c/`` chunk keys)."""
+    ``zarr_format``: 2 (``.zarray``) or 3 (``zarr.json``, ``c/`` chunk keys); ``shards`` (format 3): a dict like
+    ``chunks`` giving the shard shape in which the chunks are bundled (``sharding_indexed``)."""
     cube = dataset.cube()
     if not isinstance(cube, np.ndarray):
         cube = cube.cpu().numpy()
@@ -661,7 +776,11 @@ def dataset_to_zarr(dataset: Dataset, path: str, var: str = "var", chunks=None, 
         comp = None
     else:
         raise ValueError(f"compress must be True, False, 'blosc', 'zstd' or 'zlib', got {compress!r}")
-    _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp, zarr_format)
+    stuple = None
+    if shards is not None:
+        stuple = tuple(sizes[d] if shards.get(d, -1) in (-1, None) else shards[d] for d in ("time", "latitude", "longitude"))
+        stuple = tuple(-(-s_ // c_) * c_ for s_, c_ in zip(stuple, ctuple))          # whole chunks per shard
+    _write_array(path, var, cube, ("time", "latitude", "longitude"), ctuple, {}, comp, zarr_format, stuple)
     tv, tattrs = _encode_time(dataset.time)
     _write_array(path, "time", np.asarray(tv, dtype=np.float64), ("time",), (len(tv),), tattrs, None, zarr_format)
     _write_array(path, "latitude", dataset.latitude, ("latitude",), (len(dataset.latitude),), {}, None, zarr_format)

@@ -42,6 +42,11 @@ int64_t afcodec_blosc_encode_lz4(const void* src, int64_t nbytes, int typesize, 
 int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
                          int nthreads, int64_t* results);
 
+/* The same for byte ranges [offsets[i], offsets[i] + lengths[i]) of the files (inner chunks of Zarr v3
+ * shards); lengths[i] < 0 or offsets == NULL = the whole file. */
+int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths,
+                          void* const* dsts, const int64_t* dstsizes, int nthreads, int64_t* results);
+
 /* Plain Zstandard frames (Zarr compressor / codec "zstd"). */
 int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap);
 int64_t afcodec_zstd_bound(int64_t n);

@@ -180,7 +180,39 @@ def test_zarr_format_3_details(tmp_path):
     np.testing.assert_array_equal(got[:2], np.arange(12).reshape(2, 6))
     assert (got[2:] == -1).all()                                          # chunk 1.0 is absent
     for bad in ({"codecs": [{"name": "sharding_indexed", "configuration": {}}]}, {"data_type": "complex64"},
+                {"codecs": [{"name": "bytes"}, {"name": "sharding_indexed", "configuration": {"chunk_shape": [1, 6]}}]},
                 {"chunk_grid": {"name": "rectilinear", "configuration": {}}}):
         json.dump(dict(meta, **bad), open(os.path.join(d, "zarr.json"), "w"))
         with pytest.raises(ValueError):
             afio.ZarrArray(d)
+
+
+@pytest.mark.parametrize("compress", ["zstd", "blosc", False])
+def test_zarr_format_3_sharded_store(tmp_path, compress):
+    """`sharding_indexed`: several chunks bundled per shard file, located through the (offset, nbytes) index at
+    the end of the shard (crc32c trailer); ragged edges, an inner chunk outside the array (empty entry) and a
+    missing shard (fill value).  Written by this package's writer — no zarr-python 3 here to cross-check."""
+    import pandas as pd
+    import aggfly_amd as af
+    rng = np.random.default_rng(9)
+    T, ny, nx = 50, 7, 9
+    cube = rng.normal(280, 8, (T, ny, nx)).astype(np.float32)
+    time = pd.date_range("2003-02-01", periods=T, freq="h")
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": time, "latitude": 10 + np.arange(ny) * 0.5, "longitude": 100 + np.arange(nx) * 0.5}), lon_is_360=True)
+    store = str(tmp_path / "sh.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 8, "latitude": 4, "longitude": 3}, shards={"time": 24, "latitude": 8, "longitude": 9},
+                       compress=compress, zarr_format=3)
+    meta = json.load(open(os.path.join(store, "t2m", "zarr.json")))
+    assert meta["codecs"][0]["name"] == "sharding_indexed" and meta["chunk_grid"]["configuration"]["chunk_shape"] == [24, 8, 9]
+    assert sorted(os.listdir(os.path.join(store, "t2m", "c"))) == ["0", "1", "2"]          # 3 shards along time, 1 x 1 in space
+    za = afio.ZarrArray(os.path.join(store, "t2m"))
+    assert za.chunks == (8, 4, 3) and za.shard_shape == (24, 8, 9)
+    assert za.chunk_locator((0, 1, 2)) is not None and za.chunk_locator((6, 1, 2)) is not None
+    np.testing.assert_array_equal(za.read(), cube)
+    back = af.dataset_from_path(store, "t2m")
+    np.testing.assert_array_equal(back.cube(), cube)
+    os.remove(os.path.join(store, "t2m", "c", "1", "0", "0"))                               # a missing shard = fill value
+    got = afio.ZarrArray(os.path.join(store, "t2m")).read()
+    assert np.isnan(got[24:48]).all()
+    np.testing.assert_array_equal(got[:24], cube[:24])

@@ -369,6 +369,13 @@ def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):
         af.dataset_to_zarr(ds, store2, var="t2m", chunks={"time": 70, "latitude": ny, "longitude": nx}, compress=comp, zarr_format=fmt)
         dev2 = af.dataset_from_path(store2, "t2m", preprocess=lambda x: x - 273.15, device="cuda")
         np.testing.assert_array_equal(dev2.cube().cpu().numpy(), host.cube())
+    # format-3 shards: the inner chunks are located through each shard's index and decoded by byte range
+    for comp, chunks, shards in (("zstd", {"time": 30, "latitude": ny, "longitude": nx}, {"time": 240, "latitude": ny, "longitude": nx}),
+                                 ("blosc", {"time": 100, "latitude": 4, "longitude": 5}, {"time": 300, "latitude": 8, "longitude": 10})):
+        store3 = str(tmp_path / f"shard_{comp}.zarr")
+        af.dataset_to_zarr(ds, store3, var="t2m", chunks=chunks, shards=shards, compress=comp, zarr_format=3)
+        dev3 = af.dataset_from_path(store3, "t2m", preprocess=lambda x: x - 273.15, device="cuda")
+        np.testing.assert_array_equal(dev3.cube().cpu().numpy(), host.cube())
 
 
 def test_time_selection_reads_only_its_chunks(torch_cuda, tmp_path, monkeypatch):
@@ -379,8 +386,8 @@ def test_time_selection_reads_only_its_chunks(torch_cuda, tmp_path, monkeypatch)
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=61, scattered_nan=15)
     lat, lon = 30 + 0.5 * np.arange(ny), 200 + 0.5 * np.arange(nx)
     calls = []
-    real = codec.decode_files
-    monkeypatch.setattr(codec, "decode_files", lambda kind, paths, outs, threads=8: calls.append(len(paths)) or real(kind, paths, outs, threads))
+    real = codec.decode_ranges
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8: calls.append(len(locs)) or real(kind, locs, outs, threads))
     for label, time, sel, nsel in (("dt", pd.date_range("2002-01-01", periods=T, freq="h"), slice("2002-02-03", "2002-02-20"), 18 * 24),
                                    ("cf", af.cf_range("1999-06-01", T, "D", "noleap"), slice("2001", "2002"), 730)):
         ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
@@ -430,8 +437,8 @@ def test_clip_to_regions_reads_only_the_box(torch_cuda, tmp_path, monkeypatch):
     time = pd.date_range("2005-07-01", periods=T, freq="h")
     lat = 20 + 1.0 * np.arange(ny)
     calls = []
-    real = codec.decode_files
-    monkeypatch.setattr(codec, "decode_files", lambda kind, paths, outs, threads=8: calls.append(len(paths)) or real(kind, paths, outs, threads))
+    real = codec.decode_ranges
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8: calls.append(len(locs)) or real(kind, locs, outs, threads))
     regions = af.GeoRegions(pd.DataFrame({"geoid": ["a", "b"], "minx": [-100.2, -95.0], "miny": [31.3, 35.0],
                                           "maxx": [-96.0, -90.4], "maxy": [38.0, 41.7]}))
     for lon, is360 in ((230 + 1.0 * np.arange(nx), True), (-130 + 1.0 * np.arange(nx), False)):
