@@ -49,6 +49,8 @@ def load():
         lib.afcodec_blosc_bound.argtypes = [C.c_int64, C.c_int64]
         lib.afcodec_blosc_encode_lz4.restype = C.c_int64
         lib.afcodec_blosc_encode_lz4.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+        lib.afcodec_lz4_decode.restype = C.c_int64
+        lib.afcodec_lz4_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         lib.afcodec_zstd_decode.restype = C.c_int64
         lib.afcodec_zstd_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         lib.afcodec_zstd_bound.restype = C.c_int64
@@ -61,7 +63,7 @@ def load():
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
            "afcodec_blosc_decode_files", "afcodec_decode_files", "afcodec_decode_ranges",
-           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode")
+           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode")
 
 
 def _err(lib, what):
@@ -120,7 +122,7 @@ def blosc_decode_many(bufs, outs, threads: int = 8):
     return [int(res[i]) for i in range(n)]
 
 
-KIND = {"raw": 0, "blosc": 1, "zstd": 2, "zlib": 3, "gzip": 3}
+KIND = {"raw": 0, "blosc": 1, "zstd": 2, "zlib": 3, "gzip": 3, "lz4": 4}
 
 
 def decode_files(kind: str, paths, outs, threads: int = 8):
@@ -193,3 +195,15 @@ def zstd_encode(data, level: int = 3) -> bytes:
     if r < 0:
         raise _err(lib, "zstd_encode")
     return dst[:r].tobytes()
+
+
+def lz4_decode(buf, nbytes: int, out: np.ndarray | None = None) -> np.ndarray:
+    """numcodecs LZ4 chunk (int32 size header + raw block) of at most ``nbytes`` decoded bytes."""
+    lib = load()
+    p, n = _addr(buf)
+    if out is None:
+        out = np.empty(nbytes, dtype=np.uint8)
+    r = lib.afcodec_lz4_decode(p, n, out.ctypes.data, out.nbytes)
+    if r < 0:
+        raise _err(lib, "lz4_decode")
+    return out[:r] if r != out.nbytes and out.ndim == 1 else out

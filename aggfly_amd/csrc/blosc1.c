@@ -315,7 +315,20 @@ static int64_t inflate_any(const uint8_t* src, int64_t n, uint8_t* dst, int64_t 
     return got;
 }
 
-/* One chunk file -> dst, by codec kind: 0 raw bytes, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip. */
+/* numcodecs' LZ4 codec (Zarr v2 compressor id "lz4"): int32 decoded size, then one raw LZ4 block. */
+int64_t afcodec_lz4_decode(const void* srcv, int64_t n, void* dst, int64_t cap) {
+    const uint8_t* src = (const uint8_t*)srcv;
+    int rc = need_lz4();
+    if (rc) return rc;
+    if (n < 4) return fail(AFCODEC_E_FORMAT, "lz4 chunk shorter than its size header");
+    const int64_t want = (int64_t)(int32_t)le32(src);
+    if (want < 0 || want > cap) return fail(AFCODEC_E_SIZE, "lz4 chunk decodes to more than its destination");
+    const int got = p_lz4_dec((const char*)src + 4, (char*)dst, (int)(n - 4), (int)want);
+    if (got != want) return fail(AFCODEC_E_CODEC, "lz4 block failed to decode to its recorded size");
+    return want;
+}
+
+/* One chunk file -> dst, by codec kind: 0 raw bytes, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip, 4 numcodecs LZ4. */
 static int64_t decode_kind(int kind, const uint8_t* buf, int64_t sz, void* dst, int64_t cap) {
     switch (kind) {
         case 0:
@@ -325,6 +338,7 @@ static int64_t decode_kind(int kind, const uint8_t* buf, int64_t sz, void* dst, 
         case 1: return afcodec_blosc_decode(buf, sz, dst, cap);
         case 2: return afcodec_zstd_decode(buf, sz, dst, cap);
         case 3: return inflate_any(buf, sz, (uint8_t*)dst, cap);
+        case 4: return afcodec_lz4_decode(buf, sz, dst, cap);
         default: return fail(AFCODEC_E_UNSUPPORTED, "unknown codec kind");
     }
 }

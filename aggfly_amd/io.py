@@ -6,7 +6,7 @@ to time-contiguous Zarr with `dataset_to_zarr` / `zarr_from_path`
 or on the GPU box, so this module reads what can be read with numpy + the standard
 library:
 
-* Zarr directory stores, format 2 and format 3 (``zarr.json``): C-order chunks, ``compressor`` null / zlib / gzip / blosc (every
+* Zarr directory stores, format 2 and format 3 (``zarr.json``): C-order chunks, ``compressor`` null / zlib / gzip / lz4 / blosc (every
   Blosc-1 codec and shuffle, decoded natively by ``csrc/blosc1.c``) / zstd, ``_ARRAY_DIMENSIONS``
   attributes, CF time decoding (``units`` + ``calendar``; non-standard calendars go to
   ``cfcalendar``), ``scale_factor`` / ``add_offset`` / ``_FillValue``;
@@ -68,6 +68,11 @@ def _decompress(buf: bytes, comp, nbytes: Optional[int] = None):
         if nbytes is None:
             raise ValueError("zstd chunks need the decoded size")
         return codec.zstd_decode(buf, nbytes)
+    if cid == "lz4":
+        from . import codec
+        if nbytes is None:
+            raise ValueError("lz4 chunks need the decoded size")
+        return codec.lz4_decode(buf, nbytes)
     raise ValueError(f"unsupported Zarr compressor {cid!r}")
 
 
@@ -214,7 +219,7 @@ class ZarrArray:
         if not self.codecs:
             return "raw"
         cid = self.codecs[0].get("id")
-        return cid if cid in ("blosc", "zstd", "zlib", "gzip") else None
+        return cid if cid in ("blosc", "zstd", "zlib", "gzip", "lz4") else None
 
     @property
     def blosc_only(self) -> bool:

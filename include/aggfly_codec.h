@@ -37,7 +37,7 @@ int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize);
 int64_t afcodec_blosc_encode_lz4(const void* src, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
                                  void* dst, int64_t cap);
 
-/* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream): read and
+/* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream, 4 numcodecs LZ4): read and
  * decoded paths[i] -> dsts[i], one chunk per OpenMP thread. */
 int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
                          int nthreads, int64_t* results);
@@ -46,6 +46,9 @@ int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* co
  * shards); lengths[i] < 0 or offsets == NULL = the whole file. */
 int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths,
                           void* const* dsts, const int64_t* dstsizes, int nthreads, int64_t* results);
+
+/* numcodecs' LZ4 codec (Zarr v2 compressor id "lz4"): int32 decoded size + one raw LZ4 block. */
+int64_t afcodec_lz4_decode(const void* src, int64_t n, void* dst, int64_t cap);
 
 /* Plain Zstandard frames (Zarr compressor / codec "zstd"). */
 int64_t afcodec_zstd_decode(const void* src, int64_t n, void* dst, int64_t cap);

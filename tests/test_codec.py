@@ -128,6 +128,17 @@ def test_zarr_zstd_compressor_and_blosc_writer(tmp_path):
     _zarr_v2_from_chunks(str(tmp_path), "v", data.shape, (24, 6, 8), "<f8", {"id": "zstd", "level": 3}, files,
                          ("time", "latitude", "longitude"))
     np.testing.assert_array_equal(afio.ZarrArray(os.path.join(str(tmp_path), "v")).read(threads=2), data)
+    # numcodecs' LZ4 codec: int32 decoded size + one raw LZ4 block
+    files = {f"{it}.0.0": len(data[it * 24:(it + 1) * 24].tobytes()).to_bytes(4, "little")
+             + pa.Codec("lz4_raw").compress(data[it * 24:(it + 1) * 24].tobytes(), asbytes=True) for it in range(2)}
+    _zarr_v2_from_chunks(str(tmp_path), "l", data.shape, (24, 6, 8), "<f8", {"id": "lz4", "acceleration": 1}, files,
+                         ("time", "latitude", "longitude"))
+    za = afio.ZarrArray(os.path.join(str(tmp_path), "l"))
+    assert za.native_kind == "lz4"
+    np.testing.assert_array_equal(za.read(threads=2), data)
+    outs = [np.empty((24, 6, 8)), np.empty((24, 6, 8))]
+    assert codec.decode_ranges("lz4", [za.chunk_locator((0, 0, 0)), za.chunk_locator((1, 0, 0))], outs, threads=2) == [9216, 9216]
+    np.testing.assert_array_equal(np.concatenate(outs), data)
     # the writer's default is Blosc-LZ4 + shuffle, ragged edge chunks included
     afio._write_array(str(tmp_path), "w", data, ("time", "latitude", "longitude"), (20, 4, 8), {},
                       {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0})
