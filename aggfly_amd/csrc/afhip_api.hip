@@ -319,6 +319,9 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
     // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
     pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count()) ? 64 : WG;
+    // the LDS-histogram kernel keeps more waves per CU as 4-wave workgroups (configs[3] f32: 3.97 ms with
+    // single-wave workgroups, 3.57 ms with 256 threads; f64 unchanged)
+    if (pl->variant && pl->variant->hb) pl->wg = WG;
     if (const char* e = getenv("AFHIP_FORCE_WG")) { int w = atoi(e); if (w == 64 || w == 128 || w == 256) pl->wg = w; }   // experiment knob
     pl->tiles = (C + (int64_t)pl->wg * vec - 1) / ((int64_t)pl->wg * vec);
     // aim for ~4 workgroups per CU over the whole grid, never streaming fewer than 64 steps
