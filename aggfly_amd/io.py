@@ -506,7 +506,9 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     ya, yb, xa, xb = (0, ny, 0, nx) if yx_box is None else yx_box                                  # spatial box [ya, yb) x [xa, xb)
     cube = torch.empty((kb - ka, yb - ya, xb - xa), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
     cb = za.chunk_nbytes
-    per = max(1, min(max(threads, slab_bytes // cb), 4096))
+    # chunks per batch: ~slab_bytes, at least one per decode thread, but never more than 1 GiB of page-locked
+    # staging per buffer (the reference's own converter writes ~256 MB chunks)
+    per = max(1, min(max(threads, slab_bytes // cb), max(1, (1 << 30) // cb), 4096))
     idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
     nstage = 2 if len(idxs) > per else 1
     host = _pinned_stage(per * cb, nstage)
