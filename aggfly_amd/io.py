@@ -411,6 +411,7 @@ def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_b
     grid_yx = [(iy, ix) for iy in range((ny + za.chunks[1] - 1) // za.chunks[1]) for ix in range((nx + za.chunks[2] - 1) // za.chunks[2])]
     # a slab is a whole number of time chunks: ~slab_bytes, but never fewer chunks than decode threads
     slab = max(tc * -(-threads // len(grid_yx)), (slab_bytes // max(ny * nx * za.dtype.itemsize, 1)) // tc * tc)
+    slab = max(tc, min(slab, ((1 << 30) // max(tc * ny * nx * za.dtype.itemsize, 1)) * tc))      # <= 1 GiB of staging per buffer
 
     pool = ThreadPoolExecutor(max_workers=threads) if threads > 1 else None
 
