@@ -37,6 +37,8 @@ def load():
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.afcodec_blosc_decode.restype = C.c_int64
         lib.afcodec_blosc_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.afcodec_blosc_decode_mt.restype = C.c_int64
+        lib.afcodec_blosc_decode_mt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]
         lib.afcodec_blosc_decode_many.argtypes = [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                                   C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64)]
         lib.afcodec_blosc_decode_files.argtypes = [C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -61,7 +63,7 @@ def load():
     return _lib
 
 
-EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_many",
+EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_mt", "afcodec_blosc_decode_many",
            "afcodec_blosc_decode_files", "afcodec_decode_files", "afcodec_decode_ranges",
            "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode")
 
@@ -91,15 +93,19 @@ def blosc_info(buf) -> dict:
             "shuffle": 1 if f & 1 else (2 if f & 4 else 0), "stored": bool(f & 2), "split": not (f & 0x10)}
 
 
-def blosc_decode(buf, out: np.ndarray | None = None) -> np.ndarray:
-    """Decode one Blosc-1 chunk; ``out`` (C-contiguous, >= nbytes) is filled in place when given."""
+def blosc_decode(buf, out: np.ndarray | None = None, threads: int = 1) -> np.ndarray:
+    """Decode one Blosc-1 chunk; ``out`` (C-contiguous, >= nbytes) is filled in place when given;
+    ``threads`` > 1 spreads the chunk's blocks over an OpenMP team (for large chunks)."""
     lib = load()
     p, n = _addr(buf)
     if out is None:
         out = np.empty(blosc_info(buf)["nbytes"], dtype=np.uint8)
     if not out.flags.c_contiguous:
         raise ValueError("blosc_decode: out must be C-contiguous")
-    r = lib.afcodec_blosc_decode(p, n, out.ctypes.data, out.nbytes)
+    if threads > 1:
+        r = lib.afcodec_blosc_decode_mt(p, n, out.ctypes.data, out.nbytes, int(threads))
+    else:
+        r = lib.afcodec_blosc_decode(p, n, out.ctypes.data, out.nbytes)
     if r < 0:
         raise _err(lib, "blosc_decode")
     return out

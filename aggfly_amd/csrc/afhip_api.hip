@@ -199,6 +199,28 @@ extern "C" int afhip_scatter_block(const afhip_csr* csr, const double* block_dev
     return launch_spmm(csr, block_dev, out_dev, nt, (hipStream_t)stream);
 }
 
+extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
+                               int64_t by, int64_t bx, int64_t st, int64_t sy, int64_t sx,
+                               int64_t nt, int64_t ny, int64_t nx,
+                               int64_t NY, int64_t NX, int64_t t0, int64_t y0, int64_t x0, void* stream) {
+    if (!chunk_dev || !cube_dev || by <= 0 || bx <= 0 || NY <= 0 || NX <= 0 || nt < 0 || ny < 0 || nx < 0 ||
+        st < 0 || sy < 0 || sx < 0 || t0 < 0 || y0 < 0 || x0 < 0 || sy + ny > by || sx + nx > bx || y0 + ny > NY || x0 + nx > NX)
+        return fail(AFHIP_E_INVALID, "place_box: box outside the chunk or the cube");
+    const int64_t n = nt * ny * nx;
+    if (n == 0) return AFHIP_OK;
+    if (n > (int64_t)0x7fffffff * WG) return fail(AFHIP_E_INVALID, "place_box: box too large for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + WG - 1) / WG)), block(WG);
+    switch (elem_size) {
+        case 2: hipLaunchKernelGGL(k_place_box<uint16_t>, grid, block, 0, s, (const uint16_t*)chunk_dev, (uint16_t*)cube_dev, by, bx, st, sy, sx, nt, ny, nx, NY, NX, t0, y0, x0); break;
+        case 4: hipLaunchKernelGGL(k_place_box<uint32_t>, grid, block, 0, s, (const uint32_t*)chunk_dev, (uint32_t*)cube_dev, by, bx, st, sy, sx, nt, ny, nx, NY, NX, t0, y0, x0); break;
+        case 8: hipLaunchKernelGGL(k_place_box<uint64_t>, grid, block, 0, s, (const uint64_t*)chunk_dev, (uint64_t*)cube_dev, by, bx, st, sy, sx, nt, ny, nx, NY, NX, t0, y0, x0); break;
+        default: return fail(AFHIP_E_INVALID, "place_box: elem_size must be 2, 4 or 8");
+    }
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
 extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int64_t K, int64_t nt,
                                   double* num_dev, double* den_dev, double* res_dev, void* stream) {
     if (!csr || !x_dev || !res_dev || K <= 0 || nt < 0) return fail(AFHIP_E_INVALID, "spatial_wavg: bad arguments");

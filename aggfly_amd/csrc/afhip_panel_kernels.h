@@ -229,4 +229,21 @@ __global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict_
     panel[c * Q + t * (K + 1) + K] = valid ? 1.0 : 0.0;
 }
 
+// ---------------------------------------------------------------------------------------
+// k_place_box: a decoded chunk [bt][by][bx] (contiguous) -> its box of the time-major cube
+// [T][NY][NX] at (t0, y0, x0), only the part [st, st+nt) x [sy, sy+ny) x [sx, sx+nx) of the chunk.
+// The ingestion route's scatter (aggfly_amd/io.py): reads are contiguous in x runs, writes are
+// nx-element runs; one thread per element, x fastest.  TE = element as stored (2, 4 or 8 bytes).
+// ---------------------------------------------------------------------------------------
+template <typename TE>
+__global__ __launch_bounds__(WG) void k_place_box(const TE* __restrict__ src, TE* __restrict__ dst,
+                                                  int64_t by, int64_t bx, int64_t st, int64_t sy, int64_t sx,
+                                                  int64_t nt, int64_t ny, int64_t nx,
+                                                  int64_t NY, int64_t NX, int64_t t0, int64_t y0, int64_t x0) {
+    const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= nt * ny * nx) return;
+    const int64_t x = i % nx, r = i / nx, y = r % ny, t = r / ny;
+    dst[((t0 + t) * NY + (y0 + y)) * NX + (x0 + x)] = src[((st + t) * by + (sy + y)) * bx + (sx + x)];
+}
+
 }  // namespace afhip

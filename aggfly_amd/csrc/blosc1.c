@@ -25,7 +25,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #define AFCODEC_OK 0
@@ -219,72 +224,115 @@ static int decode_stream(int codec, const uint8_t* src, int32_t csize, uint8_t* 
 static __thread uint8_t* t_scratch;
 static __thread int64_t t_scratch_cap;
 
-/* Decodes one chunk into dst (capacity dstsize); returns the number of bytes written or < 0. */
-int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64_t dstsize) {
-    const uint8_t* c = (const uint8_t*)chunk;
-    uint8_t* dst = (uint8_t*)dstv;
-    int64_t nbytes, blocksize;
+typedef struct {
+    const uint8_t* c;
+    uint8_t* dst;
+    int64_t nbytes, blocksize, cbytes, nblocks, leftover;
+    int ts, flags, codec, dont_split, want_shuffle, stored;
+} blosc_ctx;
+
+/* Parses and validates the header; > 0 = nothing left to do (empty chunk), < 0 = error. */
+static int blosc_open(blosc_ctx* x, const void* chunk, int64_t csize, void* dstv, int64_t dstsize) {
     int32_t ts, flags;
-    int rc = afcodec_blosc_info(chunk, csize, &nbytes, &blocksize, &ts, &flags);
+    x->c = (const uint8_t*)chunk;
+    x->dst = (uint8_t*)dstv;
+    int rc = afcodec_blosc_info(chunk, csize, &x->nbytes, &x->blocksize, &ts, &flags);
     if (rc) return rc;
-    if (nbytes > dstsize) return fail(AFCODEC_E_SIZE, "destination smaller than the chunk's nbytes");
-    if (nbytes == 0) return 0;
-    const int64_t cbytes = le32(c + 12);
-    if (flags & 0x02) {
-        if (cbytes < 16 + nbytes) return fail(AFCODEC_E_FORMAT, "stored chunk shorter than nbytes");
-        memcpy(dst, c + 16, (size_t)nbytes);
-        return nbytes;
+    x->ts = ts; x->flags = flags;
+    if (x->nbytes > dstsize) return fail(AFCODEC_E_SIZE, "destination smaller than the chunk's nbytes");
+    if (x->nbytes == 0) return 1;
+    x->cbytes = le32(x->c + 12);
+    x->stored = (flags & 0x02) != 0;
+    if (x->stored) {
+        if (x->cbytes < 16 + x->nbytes) return fail(AFCODEC_E_FORMAT, "stored chunk shorter than nbytes");
+        return AFCODEC_OK;
     }
-    const int codec = (flags >> 5) & 7;
-    if (codec == 1) { if ((rc = need_lz4())) return rc; }
-    else if (codec == 4) { if ((rc = need_zstd())) return rc; }
-    else if (codec != 0 && codec != 3) return fail(AFCODEC_E_UNSUPPORTED, "blosc codec not supported (snappy)");
-    if (blocksize <= 0 || ts <= 0 || blocksize > nbytes) return fail(AFCODEC_E_FORMAT, "bad blocksize / typesize");
-    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
-    const int64_t leftover = nbytes % blocksize;
-    if (16 + 4 * nblocks > cbytes) return fail(AFCODEC_E_FORMAT, "block table beyond the chunk");
-    const int dont_split = (flags >> 4) & 1;
-    const int want_shuffle = (flags & 0x01) && ts > 1;
+    x->codec = (flags >> 5) & 7;
+    if (x->codec == 1) { if ((rc = need_lz4())) return rc; }
+    else if (x->codec == 4) { if ((rc = need_zstd())) return rc; }
+    else if (x->codec != 0 && x->codec != 3) return fail(AFCODEC_E_UNSUPPORTED, "blosc codec not supported (snappy)");
+    if (x->blocksize <= 0 || ts <= 0 || x->blocksize > x->nbytes) return fail(AFCODEC_E_FORMAT, "bad blocksize / typesize");
+    x->nblocks = (x->nbytes + x->blocksize - 1) / x->blocksize;
+    x->leftover = x->nbytes % x->blocksize;
+    if (16 + 4 * x->nblocks > x->cbytes) return fail(AFCODEC_E_FORMAT, "block table beyond the chunk");
+    x->dont_split = (flags >> 4) & 1;
+    x->want_shuffle = (flags & 0x01) && ts > 1;
+    return AFCODEC_OK;
+}
+
+/* One block of an opened chunk; blocks are independent, so a big chunk decodes on many threads. */
+static int blosc_block(const blosc_ctx* x, int64_t b) {
+    const uint8_t* c = x->c;
+    const int ts = x->ts;
     uint8_t* tmp = NULL;
-    if (want_shuffle || (flags & 0x04)) {
+    if (x->want_shuffle || (x->flags & 0x04)) {
         /* per-thread scratch, kept between calls: a fresh malloc of a block (>= 128 KiB -> mmap/munmap)
          * per chunk page-faults every time and serialises the threads on the process's mmap lock */
-        if (t_scratch_cap < blocksize) {
+        if (t_scratch_cap < x->blocksize) {
             free(t_scratch);
-            t_scratch = (uint8_t*)malloc((size_t)blocksize);
-            t_scratch_cap = t_scratch ? blocksize : 0;
+            t_scratch = (uint8_t*)malloc((size_t)x->blocksize);
+            t_scratch_cap = t_scratch ? x->blocksize : 0;
         }
         tmp = t_scratch;
         if (!tmp) return fail(AFCODEC_E_SIZE, "out of memory");
     }
-    for (int64_t b = 0; b < nblocks; ++b) {
-        const int last_short = (b == nblocks - 1) && leftover > 0;
-        const int64_t bsize = last_short ? leftover : blocksize;
-        const int do_shuf = want_shuffle;
-        const int do_bits = !do_shuf && (flags & 0x04) && bsize >= ts;
-        uint8_t* out = dst + b * blocksize;
-        uint8_t* into = (do_shuf || do_bits) ? tmp : out;
-        int nsplits = 1;
-        if (!dont_split && ts <= 16 && blocksize / ts >= 128 && !last_short) nsplits = ts;
-        const int64_t neblock = bsize / nsplits;
-        const int64_t start = (int64_t)(int32_t)le32(c + 16 + 4 * b);
-        if (start < 16 + 4 * nblocks || start >= cbytes) { return fail(AFCODEC_E_FORMAT, "block offset out of range"); }
-        const uint8_t* src = c + start;
-        for (int j = 0; j < nsplits; ++j) {
-            if (src + 4 > c + cbytes) { return fail(AFCODEC_E_FORMAT, "stream header beyond the chunk"); }
-            const int32_t sz = (int32_t)le32(src);
-            src += 4;
-            if (sz < 0 || src + sz > c + cbytes) { return fail(AFCODEC_E_FORMAT, "stream beyond the chunk"); }
-            if (sz == neblock) memcpy(into + j * neblock, src, (size_t)neblock);
-            else if (decode_stream(codec, src, sz, into + j * neblock, (int32_t)neblock)) {
-                return fail(AFCODEC_E_CODEC, "block failed to decompress to its recorded size");
-            }
-            src += sz;
-        }
-        if (do_shuf) unshuffle_bytes(ts, bsize, tmp, out);
-        else if (do_bits) unshuffle_bits(ts, bsize, tmp, out);
+    const int last_short = (b == x->nblocks - 1) && x->leftover > 0;
+    const int64_t bsize = last_short ? x->leftover : x->blocksize;
+    const int do_shuf = x->want_shuffle;
+    const int do_bits = !do_shuf && (x->flags & 0x04) && bsize >= ts;
+    uint8_t* out = x->dst + b * x->blocksize;
+    uint8_t* into = (do_shuf || do_bits) ? tmp : out;
+    int nsplits = 1;
+    if (!x->dont_split && ts <= 16 && x->blocksize / ts >= 128 && !last_short) nsplits = ts;
+    const int64_t neblock = bsize / nsplits;
+    const int64_t start = (int64_t)(int32_t)le32(c + 16 + 4 * b);
+    if (start < 16 + 4 * x->nblocks || start >= x->cbytes) return fail(AFCODEC_E_FORMAT, "block offset out of range");
+    const uint8_t* src = c + start;
+    for (int j = 0; j < nsplits; ++j) {
+        if (src + 4 > c + x->cbytes) return fail(AFCODEC_E_FORMAT, "stream header beyond the chunk");
+        const int32_t sz = (int32_t)le32(src);
+        src += 4;
+        if (sz < 0 || src + sz > c + x->cbytes) return fail(AFCODEC_E_FORMAT, "stream beyond the chunk");
+        if (sz == neblock) memcpy(into + j * neblock, src, (size_t)neblock);
+        else if (decode_stream(x->codec, src, sz, into + j * neblock, (int32_t)neblock))
+            return fail(AFCODEC_E_CODEC, "block failed to decompress to its recorded size");
+        src += sz;
     }
-    return nbytes;
+    if (do_shuf) unshuffle_bytes(ts, bsize, tmp, out);
+    else if (do_bits) unshuffle_bits(ts, bsize, tmp, out);
+    return AFCODEC_OK;
+}
+
+/* Decodes one chunk into dst (capacity dstsize); returns the number of bytes written or < 0. */
+int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64_t dstsize) {
+    blosc_ctx x;
+    int rc = blosc_open(&x, chunk, csize, dstv, dstsize);
+    if (rc < 0) return rc;
+    if (rc > 0) return 0;
+    if (x.stored) { memcpy(x.dst, x.c + 16, (size_t)x.nbytes); return x.nbytes; }
+    for (int64_t b = 0; b < x.nblocks; ++b)
+        if ((rc = blosc_block(&x, b))) return rc;
+    return x.nbytes;
+}
+
+/* The same with the blocks of the chunk spread over an OpenMP team: for chunks that are few and large
+ * (the reference's own converter writes ~256 MB chunks — one per thread would leave most threads idle). */
+int64_t afcodec_blosc_decode_mt(const void* chunk, int64_t csize, void* dstv, int64_t dstsize, int nthreads) {
+    blosc_ctx x;
+    int rc = blosc_open(&x, chunk, csize, dstv, dstsize);
+    if (rc < 0) return rc;
+    if (rc > 0) return 0;
+    if (x.stored) { memcpy(x.dst, x.c + 16, (size_t)x.nbytes); return x.nbytes; }
+    if (nthreads < 2 || x.nblocks < 2) {
+        for (int64_t b = 0; b < x.nblocks; ++b)
+            if ((rc = blosc_block(&x, b))) return rc;
+        return x.nbytes;
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : bad)
+    for (int64_t b = 0; b < x.nblocks; ++b)
+        if (blosc_block(&x, b)) bad += 1;
+    return bad ? fail(AFCODEC_E_CODEC, "one or more blocks of the chunk failed to decode") : x.nbytes;
 }
 
 /* Many chunks at once, one per OpenMP thread (ctypes releases the GIL around this call). */
@@ -352,6 +400,36 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
     int bad = 0;
     if (nthreads < 1) nthreads = 1;
     if (kind == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
+    if (kind == 1 && n * 2 <= nthreads) {
+        /* fewer Blosc chunks than half the team: one chunk at a time, its blocks over the whole team, decoded
+         * straight out of the page cache (mmap: no read() copy of a ~200 MB file in front of the decode) */
+        const long page = sysconf(_SC_PAGESIZE);
+        for (int64_t i = 0; i < n; ++i) {
+            const int fd = open(paths[i], O_RDONLY);
+            if (fd < 0) { results[i] = -100; continue; }
+            int64_t off = 0, sz = -1;
+            if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
+            struct stat stt;
+            int64_t r;
+            if (fstat(fd, &stt) != 0) {
+                r = fail(AFCODEC_E_FORMAT, "chunk file could not be read");
+            } else {
+                if (sz < 0) sz = (int64_t)stt.st_size - off;
+                const int64_t a0 = off - off % page, span = off + sz - a0;
+                void* m = (sz > 0 && off + sz <= (int64_t)stt.st_size) ? mmap(NULL, (size_t)span, PROT_READ, MAP_PRIVATE, fd, (off_t)a0) : MAP_FAILED;
+                if (m == MAP_FAILED) {
+                    r = fail(AFCODEC_E_FORMAT, "chunk file could not be mapped");
+                } else {
+                    r = afcodec_blosc_decode_mt((const uint8_t*)m + (off - a0), sz, dsts[i], dstsizes[i], nthreads);
+                    munmap(m, (size_t)span);
+                }
+            }
+            close(fd);
+            results[i] = r;
+            if (r < 0) bad += 1;
+        }
+        return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
+    }
 #pragma omp parallel num_threads(nthreads) reduction(+ : bad)
     {
         uint8_t* buf = NULL;

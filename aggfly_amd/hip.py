@@ -30,7 +30,7 @@ E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4
 EXPORTS = (
     "afhip_last_error", "afhip_abi_version", "afhip_device_count", "afhip_device_info",
     "afhip_group_stat", "afhip_group_dd", "afhip_group_bins", "afhip_group_sine_dd",
-    "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg",
+    "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
     "afhip_plan_profile_begin", "afhip_plan_profile_end",
@@ -92,6 +92,7 @@ def load():
     lib.afhip_csr_create.argtypes = [vp, vp, vp, i64, i64, i64, C.POINTER(vp)]
     lib.afhip_csr_destroy.argtypes = [vp]
     lib.afhip_scatter_block.argtypes = [vp, vp, i64, vp, vp]
+    lib.afhip_place_box.argtypes = [vp, vp, i32] + [i64] * 13 + [vp]
     lib.afhip_spatial_wavg.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp]
     lib.afhip_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(vp)]
     lib.afhip_plan_destroy.argtypes = [vp]
@@ -126,6 +127,14 @@ def device_info(dev: int = 0) -> dict:
     cus, mem = C.c_int(0), C.c_int64(0)
     _check(load().afhip_device_info(dev, name, 256, arch, 256, C.byref(cus), C.byref(mem)))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+
+def place_box(chunk, cube, box_in_chunk, at):
+    """cube[t0:t0+nt, y0:y0+ny, x0:x0+nx] = chunk[st:st+nt, sy:sy+ny, sx:sx+nx] on the current stream: the
+    ingestion route's device-side scatter.  Both tensors contiguous, same dtype (2 / 4 / 8-byte elements)."""
+    (st, sy, sx, nt, ny, nx), (t0, y0, x0) = box_in_chunk, at
+    _check(load().afhip_place_box(chunk.data_ptr(), cube.data_ptr(), chunk.element_size(), chunk.shape[1], chunk.shape[2],
+                                  st, sy, sx, nt, ny, nx, cube.shape[1], cube.shape[2], t0, y0, x0, _stream_ptr()))
 
 
 def require_gpu():

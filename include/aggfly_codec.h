@@ -29,6 +29,8 @@ int afcodec_have(int codec); /* Blosc codec ids: 0 blosclz, 1 lz4, 3 zlib, 4 zst
 /* Blosc-1 container (format version 2; codecs blosclz / lz4 / lz4hc / zlib / zstd; byte- and bit-shuffle). */
 int afcodec_blosc_info(const void* chunk, int64_t size, int64_t* nbytes, int64_t* blocksize, int32_t* typesize, int32_t* flags);
 int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dst, int64_t dstsize);
+/* the blocks of ONE (large) chunk spread over an OpenMP team */
+int64_t afcodec_blosc_decode_mt(const void* chunk, int64_t csize, void* dst, int64_t dstsize, int nthreads);
 int afcodec_blosc_decode_many(int64_t n, const void* const* chunks, const int64_t* csizes, void* const* dsts,
                               const int64_t* dstsizes, int nthreads, int64_t* results);
 int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,

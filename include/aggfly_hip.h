@@ -120,6 +120,15 @@ void afhip_csr_destroy(afhip_csr* csr);
 int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
                         double* out_dev, void* stream);
 
+/* Ingestion helper (no counterpart in the reference, whose chunks are assembled by dask on the host,
+ * aggfly/dataset/dataset.py:697-728): copies the part [st, st+nt) x [sy, sy+ny) x [sx, sx+nx) of a
+ * decoded chunk [*, by, bx] (contiguous, in HBM) into the time-major cube [*, NY, NX] at (t0, y0, x0).
+ * elem_size 2, 4 or 8 bytes; both pointers are device memory; nothing is retained. */
+int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
+                    int64_t by, int64_t bx, int64_t st, int64_t sy, int64_t sx,
+                    int64_t nt, int64_t ny, int64_t nx,
+                    int64_t NY, int64_t NX, int64_t t0, int64_t y0, int64_t x0, void* stream);
+
 /* Replaces the body of SpatialAggregator.compute (spatial.py:110-133) for K names:
  * shared validity (all K non-NaN), den = W.valid, num_k = W.where(valid, x_k, 0),
  * res = num/den where den != 0 else NaN.

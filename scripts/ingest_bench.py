@@ -34,10 +34,11 @@ def main():
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None          # stores in RAM: measure decode, not the disk
     with tempfile.TemporaryDirectory(dir=base) as d:
         layouts = {"tiled": {"time": 744, "latitude": 52, "longitude": 118},      # space-tiled, like a generic store
-                   "rows": {"time": 24, "latitude": ny, "longitude": nx}}          # time-contiguous: whole grid per chunk
+                   "rows": {"time": 24, "latitude": ny, "longitude": nx},          # time-contiguous: whole grid per chunk
+                   "auto": None}                                                    # the converter's own policy: whole series x ~85x85 tiles, ~250 MB chunks
         for comp in (False, "zlib", "blosc", "zstd"):
             for lname, chunks in layouts.items():
-                if comp is False and lname == "rows":
+                if (comp is False and lname == "rows") or (lname == "auto" and comp != "blosc"):
                     continue
                 store = os.path.join(d, f"s_{comp}_{lname}.zarr")
                 af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks, compress=comp, zarr_format=3 if comp == "zstd" else 2)

@@ -48,6 +48,9 @@ def test_decodes_real_cblosc_chunks_bit_exact(case):
     into = np.empty(raw.shape, dtype=raw.dtype)                                 # straight into a typed destination
     codec.blosc_decode(chunk, into)
     assert into.tobytes() == raw.tobytes()
+    into[...] = 0
+    codec.blosc_decode(chunk, into, threads=3)                                  # blocks spread over a team
+    assert into.tobytes() == raw.tobytes()
 
 
 def test_decode_many_on_threads():
