@@ -260,7 +260,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ERA5-like hourly t2m 0.25deg, 1 year per GPU, US-counties extent "
                                    f"{ny}x{nx} cells, {R} regions area weights, fused dd[10,30]@date->sum@year + "
-                                   "mean@date->power[1..4]->sum@year, fp64, K=5",
+                                   "mean@date->power[1..4]->sum@year, %s, K=5" % ("fp64" if args.dtype == "f64" else "fp32 storage / fp64 accumulation"),
                        "T": T, "cells": C, "regions": R, "columns": K, "nnz": int(csr.nnz),
                        "sharding": "time axis, one year per GPU; RCCL all-gather of the panel" if world > 1 else "single GPU",
                        "plan": plan.describe()},
