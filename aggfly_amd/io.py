@@ -119,8 +119,10 @@ class ZarrArray:
             raise ValueError("a .zarray file must declare zarr_format 2")
         if self.meta.get("order", "C") != "C":
             raise ValueError("only C-order Zarr chunks are supported")
-        if self.meta.get("filters"):
-            raise ValueError("Zarr filters are not supported")
+        self.filters = list(self.meta.get("filters") or [])
+        for flt in self.filters:
+            if flt.get("id") != "shuffle":
+                raise ValueError(f"Zarr filter {flt.get('id')!r} is not supported (only the byte shuffle is)")
         self.format = 2
         self.shard_shape = None
         self.shape = tuple(self.meta["shape"])
@@ -130,6 +132,9 @@ class ZarrArray:
         self.key_prefix = ""
         comp = self.meta.get("compressor")
         self.codecs = [] if comp is None else [dict(comp)]             # bytes -> bytes decoders, in decode order
+        # numcodecs filters run before the compressor on write, so they are undone after it on read
+        for flt in reversed(self.filters):
+            self.codecs.append({"id": "unshuffle", "elementsize": int(flt.get("elementsize", 4))})
         self.fill_value = self.meta.get("fill_value")
         self.attrs = {}
         ap = os.path.join(self.path, ".zattrs")
@@ -282,6 +287,11 @@ class ZarrArray:
         for c in self.codecs:
             if c["id"] == "crc32c":
                 buf = bytes(buf)[:-4]                                   # 4-byte checksum trailer (not verified)
+            elif c["id"] == "unshuffle":                                # numcodecs Shuffle: byte planes back to elements
+                es = c["elementsize"]
+                raw = np.frombuffer(buf, dtype=np.uint8)
+                n = len(raw) // es
+                buf = np.concatenate([raw[:n * es].reshape(es, n).T.reshape(-1), raw[n * es:]])
             else:
                 buf = _decompress(buf, c, self.chunk_nbytes)
         return buf

@@ -142,6 +142,24 @@ def test_zarr_zstd_compressor_and_blosc_writer(tmp_path):
     outs = [np.empty((24, 6, 8)), np.empty((24, 6, 8))]
     assert codec.decode_ranges("lz4", [za.chunk_locator((0, 0, 0)), za.chunk_locator((1, 0, 0))], outs, threads=2) == [9216, 9216]
     np.testing.assert_array_equal(np.concatenate(outs), data)
+    # numcodecs' Shuffle filter in front of a zlib compressor (what HDF5-style shuffle + deflate stores look like)
+    import zlib as _zl
+    files = {}
+    for it in range(2):
+        raw = np.frombuffer(data[it * 24:(it + 1) * 24].tobytes(), dtype=np.uint8)
+        files[f"{it}.0.0"] = _zl.compress(raw.reshape(-1, 8).T.tobytes(), 1)           # byte planes, then deflate
+    _zarr_v2_from_chunks(str(tmp_path), "f", data.shape, (24, 6, 8), "<f8", {"id": "zlib", "level": 1}, files,
+                         ("time", "latitude", "longitude"))
+    meta = json.load(open(os.path.join(str(tmp_path), "f", ".zarray")))
+    meta["filters"] = [{"id": "shuffle", "elementsize": 8}]
+    json.dump(meta, open(os.path.join(str(tmp_path), "f", ".zarray"), "w"))
+    zf = afio.ZarrArray(os.path.join(str(tmp_path), "f"))
+    assert zf.native_kind is None                                                # a chain: host route
+    np.testing.assert_array_equal(zf.read(), data)
+    meta["filters"] = [{"id": "delta", "dtype": "<f8"}]
+    json.dump(meta, open(os.path.join(str(tmp_path), "f", ".zarray"), "w"))
+    with pytest.raises(ValueError):
+        afio.ZarrArray(os.path.join(str(tmp_path), "f"))
     # the writer's default is Blosc-LZ4 + shuffle, ragged edge chunks included
     afio._write_array(str(tmp_path), "w", data, ("time", "latitude", "longitude"), (20, 4, 8), {},
                       {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0})
