@@ -1,0 +1,598 @@
+"""A small read-only HDF5 reader for netCDF-4 files (row R0 of SURVEY.md §8: the reference opens ``.nc``
+inputs through xarray + netCDF4 / h5netcdf, `aggfly/dataset/dataset.py:697-728`; neither library exists in
+this image).
+
+Written from the HDF5 File Format Specification (version 3.0) for what netCDF-4 / h5py files written with the
+library's default or v1.8 format bounds contain:
+
+* superblock versions 0-3; object headers versions 1 and 2 (with continuation blocks);
+* groups: symbol-table groups (v1 B-tree + local heap) and creation-order groups whose links are stored
+  compactly in the object header (what netCDF-4 writes for a handful of variables) or, beyond 8 links, in a
+  fractal heap located through the group's v2 B-tree name index (one level deep; nested indirect heap blocks
+  are refused);
+* datasets: fixed-point and IEEE float types of either endianness; contiguous, compact and chunked (version-3
+  layout, v1 B-tree chunk index) storage; filter pipeline deflate / shuffle / fletcher32;
+* attributes stored in the object header or (more than 8) in a fractal heap: numbers, fixed-length and variable-length strings (global heap),
+  and ``DIMENSION_LIST`` object references, through which dimension names are resolved exactly as netCDF-4
+  records them.
+
+Pinned against files written by the real HDF5 library (h5py 3.3 / libhdf5 1.10.6): `tests/golden/hdf5/`,
+`tests/golden/make_hdf5_fixtures.py`.  The "latest" format bounds (version-4 layouts, fixed / extensible
+array chunk indices) are not netCDF-4 output and are refused.
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class HDF5Error(ValueError):
+    pass
+
+
+class H5File:
+    """``H5File(path).datasets`` maps names (``"t2m"``, ``"forecast/lead"``) to `H5Dataset` objects."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._f = open(path, "rb")
+        self.buf = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        base = self._find_superblock()
+        self._parse_superblock(base)
+        self.datasets = {}
+        self.attrs = {}
+        self._by_addr = {}
+        self._walk(self.root_addr, "", top=True)
+        for ds in self.datasets.values():
+            ds._resolve_dims()
+
+    def close(self):
+        try:
+            self.buf.close()
+        finally:
+            self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- primitives ----
+    def u(self, off: int, n: int) -> int:
+        return int.from_bytes(self.buf[off:off + n], "little")
+
+    def addr(self, off: int) -> int:
+        v = self.u(off, self.O)
+        return UNDEF if v == (1 << (8 * self.O)) - 1 else v + self.base
+
+    def length(self, off: int) -> int:
+        return self.u(off, self.L)
+
+    # ---- superblock ----
+    def _find_superblock(self) -> int:
+        off = 0
+        while off < len(self.buf):
+            if self.buf[off:off + 8] == SIGNATURE:
+                return off
+            off = 512 if off == 0 else off * 2
+        raise HDF5Error(f"{self.path} is not an HDF5 file")
+
+    def _parse_superblock(self, sb: int):
+        ver = self.buf[sb + 8]
+        self.base = 0
+        if ver in (0, 1):
+            self.O, self.L = self.buf[sb + 13], self.buf[sb + 14]
+            p = sb + 24 + (4 if ver == 1 else 0)
+            self.base = self.u(p, self.O)
+            p += 4 * self.O                                    # base, free-space, end-of-file, driver info
+            self.root_addr = self.addr(p + self.O)             # root symbol-table entry: name offset, then header address
+        elif ver in (2, 3):
+            self.O, self.L = self.buf[sb + 9], self.buf[sb + 10]
+            self.base = self.u(sb + 12, self.O)
+            self.root_addr = self.addr(sb + 12 + 3 * self.O)
+        else:
+            raise HDF5Error(f"unsupported HDF5 superblock version {ver}")
+
+    # ---- object headers ----
+    def messages(self, addr: int):
+        """[(type, flags, offset, size)] of every message of the object header at ``addr``."""
+        out = []
+        if self.buf[addr:addr + 4] == b"OHDR":
+            flags = self.buf[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            nsz = 1 << (flags & 3)
+            size0 = self.u(p, nsz)
+            p += nsz
+            blocks = [(p, p + size0)]
+            track = bool(flags & 0x04)
+            while blocks:
+                q, end = blocks.pop(0)
+                while q + 4 <= end:                             # a gap shorter than a message header may remain
+                    mtype, msize, mflags = self.buf[q], self.u(q + 1, 2), self.buf[q + 3]
+                    q += 4 + (2 if track else 0)
+                    if mtype == 0x10:
+                        caddr, clen = self.addr(q), self.length(q + self.O)
+                        if self.buf[caddr:caddr + 4] != b"OCHK":
+                            raise HDF5Error("object header continuation block without its OCHK signature")
+                        blocks.append((caddr + 4, caddr + clen - 4))
+                    elif mtype != 0:
+                        out.append((mtype, mflags, q, msize))
+                    q += msize
+        else:
+            if self.buf[addr] != 1:
+                raise HDF5Error(f"unsupported object header at {addr:#x}")
+            nmsg, hsize = self.u(addr + 2, 2), self.u(addr + 8, 4)
+            blocks = [(addr + 16, addr + 16 + hsize)]
+            while blocks and len(out) < nmsg + 64:
+                q, end = blocks.pop(0)
+                while q + 8 <= end:
+                    mtype, msize, mflags = self.u(q, 2), self.u(q + 2, 2), self.buf[q + 4]
+                    q += 8
+                    if mtype == 0x10:
+                        blocks.append((self.addr(q), self.addr(q) + self.length(q + self.O)))
+                    elif mtype != 0:
+                        out.append((mtype, mflags, q, msize))
+                    q += msize
+        return out
+
+    # ---- groups ----
+    def _walk(self, addr: int, prefix: str, top: bool = False):
+        msgs = self.messages(addr)
+        types = {m[0] for m in msgs}
+        if top:
+            self.attrs = self._attributes(msgs)
+        if 0x0001 in types and 0x0003 in types and 0x0008 in types:      # dataspace + datatype + layout = a dataset
+            ds = H5Dataset(self, prefix.strip("/"), addr, msgs)
+            self.datasets[ds.name] = ds
+            self._by_addr[addr] = ds
+            return
+        for mtype, _, q, size in msgs:
+            if mtype == 0x0011:                                           # symbol table: v1 B-tree + local heap
+                for name, child in self._symbol_table(self.addr(q), self.addr(q + self.O)):
+                    self._walk(child, prefix + "/" + name)
+            elif mtype == 0x0006:                                         # link message (creation-order groups)
+                name, child, _ = self._link(q)
+                if child is not None:
+                    self._walk(child, prefix + "/" + name)
+            elif mtype == 0x0002:                                         # link info: a fractal heap means dense storage
+                flags = self.buf[q + 1]
+                p = q + 2 + (8 if flags & 1 else 0)
+                if self.addr(p) != UNDEF:                                 # > 8 links: messages in a fractal heap, names in a v2 B-tree
+                    heap = self._heap(self.addr(p))
+                    found = []
+                    for rec in self._btree2_records(self.addr(p + self.O)):    # type 5 record: name hash (4), heap ID
+                        w, _ = self._heap_get(heap, rec[4:4 + heap["id_len"]])
+                        name, child, _ = self._link(w)
+                        found.append((w, name, child))
+                    for _, name, child in sorted(found):                  # allocation order = creation order
+                        if child is not None:
+                            self._walk(child, prefix + "/" + name)
+
+    # ---- fractal heaps + v2 B-trees (dense link / attribute storage) ----
+    def _heap(self, heap: int) -> dict:
+        """Geometry of a fractal heap: where its direct blocks are and how its object IDs are packed."""
+        if self.buf[heap:heap + 4] != b"FRHP":
+            raise HDF5Error("fractal heap signature missing")
+        p = heap + 5
+        id_len, io_filter_len, hflags, max_managed = self.u(p, 2), self.u(p + 2, 2), self.buf[p + 4], self.u(p + 5, 4)
+        p += 9
+        p += self.L + self.O + self.L + self.O                             # next huge id, huge btree, free space, free-space manager
+        p += 8 * self.L                                                    # managed space / allocated / iterator / count, huge and tiny size / count
+        width, start_size, max_direct = self.u(p, 2), self.length(p + 2), self.length(p + 2 + self.L)
+        max_heap_bits = self.u(p + 2 + 2 * self.L, 2)
+        root = self.addr(p + 2 + 2 * self.L + 4)
+        cur_rows = self.u(p + 2 + 2 * self.L + 4 + self.O, 2)
+        if io_filter_len:
+            raise HDF5Error("filtered fractal heaps are not supported")
+        off_bytes = (max_heap_bits + 7) // 8
+        blocks = []                                                        # (heap offset, file address, size)
+        if root != UNDEF:
+            if cur_rows == 0:
+                blocks.append((0, root, start_size))
+            else:
+                if self.buf[root:root + 4] != b"FHIB":
+                    raise HDF5Error("fractal heap indirect block signature missing")
+                q = root + 5 + self.O + off_bytes
+                hoff = 0
+                for row in range(cur_rows):
+                    bsize = start_size if row < 2 else start_size << (row - 1)
+                    for _ in range(width):
+                        a = self.addr(q)
+                        q += self.O
+                        if bsize > max_direct:
+                            if a != UNDEF:
+                                raise HDF5Error("fractal heaps with nested indirect blocks are not supported")
+                        elif a != UNDEF:
+                            blocks.append((hoff, a, bsize))
+                        hoff += bsize
+        len_bytes = (min(max_direct, max_managed).bit_length() + 7) // 8
+        return {"blocks": blocks, "off_bytes": off_bytes, "len_bytes": len_bytes, "id_len": id_len}
+
+    def _heap_get(self, heap: dict, hid: bytes):
+        """(file offset, length) of the managed object with heap ID ``hid``."""
+        if (hid[0] >> 4) & 3 != 0:
+            raise HDF5Error("huge / tiny fractal heap objects are not supported")
+        off = int.from_bytes(hid[1:1 + heap["off_bytes"]], "little")
+        ln = int.from_bytes(hid[1 + heap["off_bytes"]:1 + heap["off_bytes"] + heap["len_bytes"]], "little")
+        for hoff, a, size in heap["blocks"]:
+            if hoff <= off < hoff + size:
+                return a + (off - hoff), ln
+        raise HDF5Error("fractal heap object outside the heap's direct blocks")
+
+    def _btree2_records(self, addr: int):
+        """Raw records of a version-2 B-tree of depth 0 or 1 (name indices of groups / attribute sets)."""
+        if self.buf[addr:addr + 4] != b"BTHD":
+            raise HDF5Error("v2 B-tree header signature missing")
+        node_size, rec_size, depth = self.u(addr + 6, 4), self.u(addr + 10, 2), self.u(addr + 12, 2)
+        root, nroot = self.addr(addr + 16), self.u(addr + 16 + self.O, 2)
+        out = []
+
+        def leaf(a, n):
+            if self.buf[a:a + 4] != b"BTLF":
+                raise HDF5Error("v2 B-tree leaf signature missing")
+            for i in range(n):
+                out.append(bytes(self.buf[a + 6 + i * rec_size:a + 6 + (i + 1) * rec_size]))
+
+        if root == UNDEF or nroot == 0:
+            return out
+        if depth == 0:
+            leaf(root, nroot)
+        elif depth == 1:
+            if self.buf[root:root + 4] != b"BTIN":
+                raise HDF5Error("v2 B-tree internal node signature missing")
+            max_leaf = (node_size - 10) // rec_size
+            nbytes = (max_leaf.bit_length() + 7) // 8
+            p = root + 6
+            recs = [bytes(self.buf[p + i * rec_size:p + (i + 1) * rec_size]) for i in range(nroot)]
+            p += nroot * rec_size
+            for i in range(nroot + 1):
+                child, n = self.addr(p), self.u(p + self.O, nbytes)
+                p += self.O + nbytes
+                leaf(child, n)
+            out.extend(recs)
+        else:
+            raise HDF5Error("v2 B-trees deeper than one level are not supported (thousands of objects in one group)")
+        return out
+
+    def _link(self, q: int):
+        flags = self.buf[q + 1]
+        p = q + 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = self.buf[p]
+            p += 1
+        if flags & 0x04:
+            p += 8
+        if flags & 0x10:
+            p += 1
+        nlen_size = 1 << (flags & 3)
+        nlen = self.u(p, nlen_size)
+        p += nlen_size
+        name = bytes(self.buf[p:p + nlen]).decode("utf-8", "replace")
+        p += nlen
+        if ltype == 0:
+            return name, self.addr(p), p + self.O
+        if ltype == 1:                                                    # soft link: length + path, skipped
+            return name, None, p + 2 + self.u(p, 2)
+        return name, None, p + 2 + self.u(p, 2)                           # external / user-defined: length + data, skipped
+
+    def _symbol_table(self, btree: int, heap: int):
+        if self.buf[heap:heap + 4] != b"HEAP":
+            raise HDF5Error("local heap signature missing")
+        data = self.addr(heap + 8 + 2 * self.L)
+        out = []
+
+        def node(a):
+            if self.buf[a:a + 4] != b"TREE":
+                raise HDF5Error("B-tree node signature missing")
+            level, used = self.buf[a + 5], self.u(a + 6, 2)
+            p = a + 8 + 2 * self.O
+            for _ in range(used):
+                p += self.L                                                # key
+                child = self.addr(p)
+                p += self.O
+                if level > 0:
+                    node(child)
+                else:
+                    if self.buf[child:child + 4] != b"SNOD":
+                        raise HDF5Error("symbol table node signature missing")
+                    n = self.u(child + 6, 2)
+                    e = child + 8
+                    for _ in range(n):
+                        noff = self.u(e, self.O)
+                        end = self.buf.find(b"\x00", data + noff)
+                        out.append((bytes(self.buf[data + noff:end]).decode("utf-8", "replace"), self.addr(e + self.O)))
+                        e += 2 * self.O + 24
+
+        node(btree)
+        return out
+
+    # ---- datatypes / attributes ----
+    def _datatype(self, q: int):
+        """-> (kind, numpy dtype or None, size, next offset).  kind: 'num', 'str', 'vlen_str', 'vlen_ref', 'ref', None."""
+        cls, bits0, size = self.buf[q] & 0x0F, self.buf[q + 1], self.u(q + 4, 4)
+        p = q + 8
+        if cls == 0:                                                       # fixed point
+            order = ">" if bits0 & 1 else "<"
+            kind = "i" if bits0 & 0x08 else "u"
+            return "num", np.dtype(f"{order}{kind}{size}"), size, p + 4
+        if cls == 1:                                                       # IEEE float
+            order = ">" if bits0 & 1 else "<"
+            return "num", np.dtype(f"{order}f{size}"), size, p + 12
+        if cls == 3:
+            return "str", None, size, p
+        if cls == 7:
+            return "ref", None, size, p
+        if cls == 9:                                                       # variable length: a base type follows
+            is_str = (bits0 & 0x0F) == 1
+            bkind, _, _, nxt = self._datatype(p)
+            if is_str:
+                return "vlen_str", None, size, nxt
+            return ("vlen_ref" if bkind == "ref" else None), None, size, nxt
+        return None, None, size, p
+
+    def _dataspace(self, q: int):
+        ver, rank, flags = self.buf[q], self.buf[q + 1], self.buf[q + 2]
+        p = q + (8 if ver == 1 else 4)
+        return tuple(self.length(p + i * self.L) for i in range(rank))
+
+    def _heap_object(self, coll: int, index: int) -> bytes:
+        if self.buf[coll:coll + 4] != b"GCOL":
+            raise HDF5Error("global heap collection signature missing")
+        size = self.length(coll + 8)
+        p, end = coll + 8 + self.L, coll + size
+        while p + 8 + self.L <= end:
+            idx, osz = self.u(p, 2), self.length(p + 8)
+            if idx == index:
+                return bytes(self.buf[p + 8 + self.L:p + 8 + self.L + osz])
+            if idx == 0:
+                break
+            p += 8 + self.L + ((osz + 7) // 8) * 8
+        raise HDF5Error("global heap object not found")
+
+    def _attribute(self, q: int):
+        """One attribute message at ``q`` -> (name, value or None, end offset)."""
+        ver = self.buf[q]
+        nsz, tsz, ssz = self.u(q + 2, 2), self.u(q + 4, 2), self.u(q + 6, 2)
+        p = q + 8 + (1 if ver == 3 else 0)
+        pad = (lambda n: (n + 7) // 8 * 8) if ver == 1 else (lambda n: n)
+        name = bytes(self.buf[p:p + nsz]).split(b"\x00")[0].decode("utf-8", "replace")
+        p += pad(nsz)
+        kind, dt, esize, _ = self._datatype(p)
+        p += pad(tsz)
+        shape = self._dataspace(p) if ssz >= 4 and self.buf[p] in (1, 2) else ()
+        p += pad(ssz)
+        n = int(np.prod(shape)) if shape else 1
+        value = None
+        try:
+            if kind == "num":
+                arr = np.frombuffer(self.buf[p:p + n * esize], dtype=dt).astype(dt.newbyteorder("="))
+                value = arr[0] if shape in ((), (1,)) else arr.reshape(shape)
+            elif kind == "str":
+                vals = [bytes(self.buf[p + i * esize:p + (i + 1) * esize]).split(b"\x00")[0].decode("utf-8", "replace").rstrip()
+                        for i in range(n)]
+                value = vals[0] if n == 1 else vals
+            elif kind in ("vlen_str", "vlen_ref"):
+                vals = []
+                for i in range(n):
+                    e = p + i * (4 + self.O + 4)
+                    ln, coll, idx = self.u(e, 4), self.addr(e + 4), self.u(e + 4 + self.O, 4)
+                    raw = self._heap_object(coll, idx) if ln else b""
+                    if kind == "vlen_str":
+                        vals.append(raw[:ln].decode("utf-8", "replace"))
+                    else:                                                  # DIMENSION_LIST: object addresses of one axis
+                        vals.append([int.from_bytes(raw[k * self.O:(k + 1) * self.O], "little") + self.base for k in range(ln)])
+                value = vals if kind == "vlen_ref" else (vals[0] if n == 1 else vals)
+        except (HDF5Error, ValueError):
+            value = None
+        return name, value, p + n * esize
+
+    def _attributes(self, msgs) -> dict:
+        out = {}
+        for mtype, _, q, size in msgs:
+            if mtype == 0x000C:
+                name, value, _ = self._attribute(q)
+                if value is not None:
+                    out[name] = value
+            elif mtype == 0x0015:                                          # attribute info: > 8 attributes live in a fractal heap
+                flags = self.buf[q + 1]
+                p = q + 2 + (2 if flags & 1 else 0)
+                heap_addr = self.addr(p)
+                if heap_addr != UNDEF:
+                    heap = self._heap(heap_addr)
+                    for rec in self._btree2_records(self.addr(p + self.O)):    # type 8 record: heap ID (8), flags, order, hash
+                        w, _ = self._heap_get(heap, rec[:heap["id_len"]])
+                        name, value, _ = self._attribute(w)
+                        if value is not None:
+                            out[name] = value
+        return out
+
+
+class H5Dataset:
+    def __init__(self, f: H5File, name: str, addr: int, msgs):
+        self.file, self.name, self.addr = f, name, addr
+        self.attrs = f._attributes(msgs)
+        self.filters = []
+        self.layout = None
+        self.fill = None
+        for mtype, _, q, size in msgs:
+            if mtype == 0x0001:
+                self.shape = f._dataspace(q)
+            elif mtype == 0x0003:
+                kind, dt, esize, _ = f._datatype(q)
+                if kind != "num":
+                    dt = None                                              # strings / compounds: not a numeric array
+                self.disk_dtype = dt
+            elif mtype == 0x0008:
+                self._parse_layout(q)
+            elif mtype == 0x000B:
+                self._parse_filters(q)
+        self.dtype = None if self.disk_dtype is None else self.disk_dtype.newbyteorder("=")
+        self.dims = None
+
+    def _parse_layout(self, q: int):
+        f = self.file
+        ver, cls = f.buf[q], f.buf[q + 1]
+        if ver == 3:
+            if cls == 0:
+                n = f.u(q + 2, 2)
+                self.layout = ("compact", q + 4, n)
+            elif cls == 1:
+                self.layout = ("contiguous", f.addr(q + 2), f.length(q + 2 + f.O))
+            elif cls == 2:
+                nd = f.buf[q + 2]
+                btree = f.addr(q + 3)
+                dims = tuple(f.u(q + 3 + f.O + 4 * i, 4) for i in range(nd))
+                self.layout = ("chunked", btree, dims[:-1])
+            else:
+                raise HDF5Error(f"unsupported data layout class {cls}")
+        elif ver == 4 and cls == 1:
+            self.layout = ("contiguous", f.addr(q + 2), f.length(q + 2 + f.O))
+        elif ver == 4 and cls == 0:
+            self.layout = ("compact", q + 4, f.u(q + 2, 2))
+        else:
+            self.layout = ("unsupported", f"data layout version {ver} class {cls} (written with the 'latest' format bounds)")
+
+    def _parse_filters(self, q: int):
+        f = self.file
+        ver, n = f.buf[q], f.buf[q + 1]
+        p = q + (8 if ver == 1 else 2)
+        for _ in range(n):
+            fid = f.u(p, 2)
+            if ver == 1 or fid >= 256:
+                nlen = f.u(p + 2, 2)
+                p += 2
+            else:
+                nlen = 0
+            ncd = f.u(p + 4, 2)
+            p += 6
+            p += ((nlen + 7) // 8 * 8) if ver == 1 else nlen
+            cd = [f.u(p + 4 * i, 4) for i in range(ncd)]
+            p += 4 * ncd
+            if ver == 1 and ncd % 2:
+                p += 4
+            self.filters.append((fid, cd))
+
+    def _resolve_dims(self):
+        """Dimension names as netCDF-4 records them: DIMENSION_LIST -> the scale datasets' names."""
+        refs = self.attrs.get("DIMENSION_LIST")
+        if isinstance(refs, list) and len(refs) == len(getattr(self, "shape", ())):
+            names = []
+            for axis in refs:
+                ds = self.file._by_addr.get(axis[0]) if axis else None
+                names.append(ds.name.split("/")[-1] if ds is not None else None)
+            if all(names):
+                self.dims = tuple(names)
+
+    # ---- data ----
+    def _chunks(self):
+        """[(offsets tuple, address, nbytes, filter mask)] of a chunked dataset."""
+        f = self.file
+        _, btree, cdims = self.layout
+        nd = len(cdims)
+        out = []
+        if btree == UNDEF:
+            return out
+
+        def node(a):
+            if f.buf[a:a + 4] != b"TREE" or f.buf[a + 4] != 1:
+                raise HDF5Error("chunk B-tree node signature missing")
+            level, used = f.buf[a + 5], f.u(a + 6, 2)
+            p = a + 8 + 2 * f.O
+            ksize = 8 + 8 * (nd + 1)
+            for _ in range(used):
+                nbytes, mask = f.u(p, 4), f.u(p + 4, 4)
+                offs = tuple(f.u(p + 8 + 8 * i, 8) for i in range(nd))
+                child = f.addr(p + ksize)
+                p += ksize + f.O
+                if level > 0:
+                    node(child)
+                else:
+                    out.append((offs, child, nbytes, mask))
+
+        node(btree)
+        return out
+
+    def _unfilter(self, raw: bytes, mask: int, nbytes_out: int) -> np.ndarray:
+        data = raw
+        for i in range(len(self.filters) - 1, -1, -1):                     # filters are undone in reverse order
+            if mask & (1 << i):
+                continue
+            fid, cd = self.filters[i]
+            if fid == 1:
+                data = zlib.decompress(data)
+            elif fid == 2:
+                es = cd[0] if cd else self.disk_dtype.itemsize
+                a = np.frombuffer(data, dtype=np.uint8)
+                n = len(a) // es
+                data = np.concatenate([a[:n * es].reshape(es, n).T.reshape(-1), a[n * es:]]).tobytes()
+            elif fid == 3:
+                data = data[:-4]                                           # fletcher32 checksum (not verified)
+            else:
+                raise HDF5Error(f"HDF5 filter {fid} is not supported (deflate, shuffle and fletcher32 are)")
+        return np.frombuffer(data, dtype=self.disk_dtype, count=nbytes_out // self.disk_dtype.itemsize)
+
+    def read(self, threads: int = 8) -> np.ndarray:
+        if self.disk_dtype is None:
+            raise HDF5Error(f"dataset {self.name!r} is not a numeric array")
+        f = self.file
+        kind = self.layout[0]
+        n = int(np.prod(self.shape)) if self.shape else 1
+        if kind == "unsupported":
+            raise HDF5Error(f"dataset {self.name!r}: {self.layout[1]} is not supported; re-write the file with the default "
+                            "(netCDF-4 compatible) format bounds or convert it to Zarr")
+        if kind in ("contiguous", "compact"):
+            _, a, size = self.layout
+            if a == UNDEF or size == 0:
+                return np.full(self.shape, self._fill_value(), dtype=self.dtype)
+            arr = np.frombuffer(f.buf[a:a + n * self.disk_dtype.itemsize], dtype=self.disk_dtype)
+            return arr.astype(self.dtype).reshape(self.shape)
+        cdims = self.layout[2]
+        out = np.full(self.shape, self._fill_value(), dtype=self.dtype)
+        cbytes = int(np.prod(cdims)) * self.disk_dtype.itemsize
+
+        def work(item):
+            offs, a, nbytes, mask = item
+            blk = self._unfilter(bytes(f.buf[a:a + nbytes]), mask, cbytes).reshape(cdims)
+            sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, self.shape))
+            sl_blk = tuple(slice(0, s.stop - s.start) for s in sl_out)
+            out[sl_out] = blk[sl_blk]
+
+        items = self._chunks()
+        if threads > 1 and len(items) > 1:
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                list(ex.map(work, items))
+        else:
+            for it in items:
+                work(it)
+        return out
+
+    def _fill_value(self):
+        fv = self.attrs.get("_FillValue")
+        if fv is not None and np.ndim(fv) == 0:
+            return fv
+        return np.nan if self.dtype.kind == "f" else 0
+
+
+def is_hdf5(path: str) -> bool:
+    try:
+        with open(path, "rb") as f:
+            return f.read(8) == SIGNATURE
+    except OSError:
+        return False
+
+
+def unpack(fmt, data):          # pragma: no cover - kept for interactive debugging of headers
+    return struct.unpack(fmt, data)

@@ -10,6 +10,8 @@ library:
   Blosc-1 codec and shuffle, decoded natively by ``csrc/blosc1.c``) / zstd, ``_ARRAY_DIMENSIONS``
   attributes, CF time decoding (``units`` + ``calendar``; non-standard calendars go to
   ``cfcalendar``), ``scale_factor`` / ``add_offset`` / ``_FillValue``;
+* netCDF-4 / HDF5 files through the built-in reader ``hdf5.py`` (chunked + shuffle + deflate variables,
+  dimension scales, either group style; no netCDF4 / h5py needed);
 * ``.npz`` bundles with ``data``, ``time``, ``latitude``, ``longitude``;
 * NetCDF-3 classic files through ``scipy.io.netcdf_file``.
 
@@ -831,6 +833,37 @@ def _open_npz(path, var):
     return DataArray(data, dims, {"time": time, "latitude": z["latitude"], "longitude": z["longitude"]}, name=var)
 
 
+def _open_hdf5(path, var, xycoords=("longitude", "latitude"), timecoord="time"):
+    """netCDF-4 / HDF5 containers through the built-in reader (`hdf5.py`): variable, CF mask / scale, coordinates
+    by dimension name (``DIMENSION_LIST``; for plain HDF5 files without dimension scales, by matching the axis
+    lengths to the 1-D datasets named like the coordinates)."""
+    from . import hdf5
+    with hdf5.H5File(path) as f:
+        if var not in f.datasets:
+            raise KeyError(f"{var!r} not in {path}: {sorted(f.datasets)}")
+        ds = f.datasets[var]
+        dims = ds.dims
+        if dims is None:
+            cands = {n: d for n, d in f.datasets.items() if len(d.shape) == 1 and n != var}
+            dims = []
+            for ax, n in enumerate(ds.shape):
+                names = [c for c in (timecoord, xycoords[1], xycoords[0]) if c in cands and cands[c].shape[0] == n and c not in dims]
+                names += [c for c, d in cands.items() if d.shape[0] == n and c not in dims and c not in names]
+                dims.append(names[0] if names else f"dim_{ax}")
+            dims = tuple(dims)
+        attrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in ds.attrs.items()
+                 if k not in ("DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates")}
+        data = _cf_mask_scale(ds.read(), attrs)
+        coords = {}
+        for d in dims:
+            if d in f.datasets and len(f.datasets[d].shape) == 1:
+                c = f.datasets[d]
+                cattrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in c.attrs.items()}
+                vals = c.read(threads=1)
+                coords[d] = _decode_time(vals, cattrs) if " since " in str(cattrs.get("units", "")) else vals
+    return DataArray(data, dims, coords, name=var, attrs=attrs)
+
+
 def _open_netcdf3(path, var):
     from scipy.io import netcdf_file
     with netcdf_file(path, "r", mmap=False) as nc:
@@ -873,6 +906,11 @@ def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
     if ry is None or rx is None:
         return None
     return (ry + rx) if dims[1] == yname else (rx + ry)
+
+
+def _is_hdf5(path) -> bool:
+    from . import hdf5
+    return isinstance(path, str) and os.path.isfile(path) and hdf5.is_hdf5(path)
 
 
 def _time_window(tindex, time_sel):
@@ -977,6 +1015,8 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             da = open_zarr(p, var)
         elif p.endswith(".npz"):
             da = _open_npz(p, var)
+        elif _is_hdf5(p):
+            da = _open_hdf5(p, var, xycoords, timecoord)
         else:
             da = _open_netcdf3(p, var)
         if preprocess is not None and (preprocess_at_load or len(paths) > 1):
@@ -999,5 +1039,6 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
         da = parts[0]
         if preprocess_at_load:
             preprocess = None
-    return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
-                   preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
+    ds = Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
+                 preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
+    return ds.to_device(device) if device is not None else ds      # containers without a streaming route: one upload
