@@ -149,7 +149,8 @@ def decode_files(kind: str, paths, outs, threads: int = 8):
 
 def decode_ranges(kind: str, locators, outs, threads: int = 8):
     """Like `decode_files` for ``locators[i] = (path, offset, nbytes)`` — nbytes < 0 = the whole file, None =
-    an absent chunk (reported as -100 without touching the disk)."""
+    an absent chunk (reported as -100 without touching the disk).  ``kind`` may be a pair ``(codec, element_size)``:
+    the codec's output is then byte-unshuffled (HDF5 shuffle + deflate chunks)."""
     lib = load()
     n = len(locators)
     pp = (C.c_char_p * n)(*[os.fsencode(l[0]) if l is not None else b"" for l in locators])
@@ -158,7 +159,8 @@ def decode_ranges(kind: str, locators, outs, threads: int = 8):
     dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
     ds = (C.c_int64 * n)(*[o.nbytes for o in outs])
     res = (C.c_int64 * n)()
-    if lib.afcodec_decode_ranges(KIND[kind], n, pp, offs, lens, dp, ds, int(threads), res):
+    code = KIND[kind] if isinstance(kind, str) else KIND[kind[0]] + 16 * int(kind[1])      # (codec, element size): + byte unshuffle
+    if lib.afcodec_decode_ranges(code, n, pp, offs, lens, dp, ds, int(threads), res):
         bad = [locators[i] for i in range(n) if res[i] < 0 and res[i] != -100]
         raise CodecError(f"decode_ranges({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
     return [int(res[i]) for i in range(n)]

@@ -376,8 +376,28 @@ int64_t afcodec_lz4_decode(const void* srcv, int64_t n, void* dst, int64_t cap) 
     return want;
 }
 
-/* One chunk file -> dst, by codec kind: 0 raw bytes, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip, 4 numcodecs LZ4. */
+/* One chunk file -> dst, by codec kind: 0 raw bytes, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip, 4 numcodecs LZ4.
+ * kind >> 4 = element size of a byte-unshuffle stage applied AFTER the codec (HDF5's shuffle + deflate filter
+ * pair, numcodecs' Shuffle filter): the codec then decodes into per-thread scratch and the planes are woven
+ * into dst. */
+static int64_t decode_kind_plain(int kind, const uint8_t* buf, int64_t sz, void* dst, int64_t cap);
+static __thread uint8_t* t_plane;
+static __thread int64_t t_plane_cap;
 static int64_t decode_kind(int kind, const uint8_t* buf, int64_t sz, void* dst, int64_t cap) {
+    const int es = kind >> 4;
+    if (es <= 1) return decode_kind_plain(kind & 15, buf, sz, dst, cap);
+    if (t_plane_cap < cap) {
+        free(t_plane);
+        t_plane = (uint8_t*)malloc((size_t)cap);
+        t_plane_cap = t_plane ? cap : 0;
+    }
+    if (!t_plane) return fail(AFCODEC_E_SIZE, "out of memory");
+    const int64_t got = decode_kind_plain(kind & 15, buf, sz, t_plane, cap);
+    if (got < 0) return got;
+    unshuffle_bytes(es, got, t_plane, (uint8_t*)dst);
+    return got;
+}
+static int64_t decode_kind_plain(int kind, const uint8_t* buf, int64_t sz, void* dst, int64_t cap) {
     switch (kind) {
         case 0:
             if (sz > cap) return fail(AFCODEC_E_SIZE, "raw chunk larger than its destination");
@@ -399,7 +419,7 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
                           void* const* dsts, const int64_t* dstsizes, int nthreads, int64_t* results) {
     int bad = 0;
     if (nthreads < 1) nthreads = 1;
-    if (kind == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
+    if ((kind & 15) == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
     if (kind == 1 && n * 2 <= nthreads) {
         /* fewer Blosc chunks than half the team: one chunk at a time, its blocks over the whole team, decoded
          * straight out of the page cache (mmap: no read() copy of a ~200 MB file in front of the decode) */
@@ -447,7 +467,7 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
             int64_t r;
             if (fseek(f, (long)off, SEEK_SET) != 0) {
                 r = fail(AFCODEC_E_FORMAT, "chunk range beyond the file");
-            } else if (kind == 0 && sz <= dstsizes[i]) {     /* raw: straight into the destination */
+            } else if (kind == 0 && sz <= dstsizes[i]) {     /* raw, no unshuffle: straight into the destination */
                 r = (int64_t)fread(dsts[i], 1, (size_t)sz, f) == sz ? sz : fail(AFCODEC_E_FORMAT, "chunk file could not be read");
             } else {
                 if (sz > cap) { free(buf); buf = (uint8_t*)malloc((size_t)sz + 64); cap = buf ? sz : 0; }

@@ -586,6 +586,54 @@ class H5Dataset:
         return np.nan if self.dtype.kind == "f" else 0
 
 
+class ChunkSource:
+    """An `H5Dataset` seen the way the streaming route (`io.array_to_device`) sees a Zarr array: shape, chunk
+    grid, a codec kind the native batch decoder knows, and (file, offset, nbytes) locators of the chunks."""
+
+    def __init__(self, ds: H5Dataset):
+        if ds.disk_dtype is None or ds.layout[0] != "chunked":
+            raise HDF5Error("only chunked numeric datasets stream chunk by chunk")
+        self.ds = ds
+        self.path = ds.file.path
+        self.shape, self.chunks = tuple(ds.shape), tuple(ds.layout[2])
+        self.dtype, self.disk_dtype = ds.dtype, ds.disk_dtype
+        self.chunk_nbytes = int(np.prod(self.chunks)) * self.disk_dtype.itemsize
+        self.attrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in ds.attrs.items()
+                      if k not in ("DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates")}
+        self.dims = ds.dims if ds.dims is not None else tuple(f"dim_{i}" for i in range(len(self.shape)))
+        ids = [fid for fid, _ in ds.filters]
+        self._trailer = 4 if ids and ids[-1] == 3 else 0                   # fletcher32: 4 checksum bytes after the payload
+        core = ids[:-1] if self._trailer else ids
+        self.native_kind = None
+        if self.disk_dtype.isnative:
+            if core == []:
+                self.native_kind = "raw"
+            elif core == [1]:
+                self.native_kind = "zlib"
+            elif core == [2, 1]:
+                self.native_kind = ("zlib", self.disk_dtype.itemsize)      # deflate, then byte-unshuffle
+        self._index = {}
+        for offs, a, nbytes, mask in ds._chunks():
+            if mask:
+                self.native_kind = None                                    # a chunk written with filters skipped: host route
+            self._index[tuple(o // c for o, c in zip(offs, self.chunks))] = (a, nbytes)
+
+    def chunk_locator(self, idx):
+        hit = self._index.get(tuple(idx))
+        return None if hit is None else (self.path, hit[0], hit[1] - self._trailer)
+
+    def _fill(self):
+        return self.ds._fill_value()
+
+    def _chunk(self, idx):
+        hit = self._index.get(tuple(idx))
+        if hit is None:
+            return np.full(self.chunks, self._fill(), dtype=self.dtype)
+        f = self.ds.file
+        blk = self.ds._unfilter(bytes(f.buf[hit[0]:hit[0] + hit[1]]), 0, self.chunk_nbytes).reshape(self.chunks)
+        return blk if self.disk_dtype.isnative else blk.astype(self.dtype)
+
+
 def is_hdf5(path: str) -> bool:
     try:
         with open(path, "rb") as f:

@@ -405,10 +405,14 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
 
 
 def zarr_to_device(path: str, var: str, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20, t_range=None, yx_box=None):
-    """Decode a time-major Zarr v2 array straight into HBM: each slab is a whole number of
-    time chunks, decoded chunk-parallel on host threads into pinned memory and uploaded while
-    the next slab decodes.  Returns (tensor, ZarrArray)."""
-    za = ZarrArray(os.path.join(path, var))
+    """Decode a time-major Zarr array straight into HBM.  Returns (tensor, ZarrArray)."""
+    return array_to_device(ZarrArray(os.path.join(path, var)), device, threads, slab_bytes, t_range, yx_box)
+
+
+def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 << 20, t_range=None, yx_box=None):
+    """Stream a chunked (time, y, x) array — a `ZarrArray` or an `hdf5.ChunkSource` — straight into HBM: each
+    slab is a whole number of time chunks, decoded chunk-parallel by the native codec into page-locked memory
+    and uploaded while the next slab decodes.  Returns (tensor, source)."""
     if len(za.shape) != 3:
         raise ValueError("zarr_to_device expects a (time, y, x) array")
     sf, ao = za.attrs.get("scale_factor"), za.attrs.get("add_offset")
@@ -908,6 +912,39 @@ def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
     return (ry + rx) if dims[1] == yname else (rx + ry)
 
 
+def _hdf5_to_device(path, var, xycoords, timecoord, time_sel, georegions, lon_is_360, device):
+    """A chunked netCDF-4 variable through the streaming route (native inflate + unshuffle, GPU-side placement);
+    None when the variable does not qualify (contiguous, not time-leading, ...): the host route then reads it."""
+    from . import hdf5
+    f = hdf5.H5File(path)
+    try:
+        ds = f.datasets.get(var)
+        if ds is None or ds.layout[0] != "chunked" or ds.dims is None or len(ds.shape) != 3 or ds.dims[0] != timecoord:
+            return None
+        src = hdf5.ChunkSource(ds)
+        coords = {}
+        for d in src.dims:
+            if d in f.datasets and len(f.datasets[d].shape) == 1:
+                c = f.datasets[d]
+                cattrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in c.attrs.items()}
+                vals = c.read(threads=1)
+                coords[d] = _decode_time(vals, cattrs) if " since " in str(cattrs.get("units", "")) else vals
+        window = _time_window(coords[timecoord], time_sel) if time_sel is not None and timecoord in coords else None
+        box = _clip_box(src.dims, coords, xycoords, georegions, lon_is_360) if georegions is not None else None
+        try:
+            data, _ = array_to_device(src, device=device, t_range=window, yx_box=box)
+        except ValueError:
+            return None
+        if window is not None:
+            coords[timecoord] = coords[timecoord][window[0]:window[1]]
+        if box is not None:
+            coords[src.dims[1]] = coords[src.dims[1]][box[0]:box[1]]
+            coords[src.dims[2]] = coords[src.dims[2]][box[2]:box[3]]
+        return data, src, coords
+    finally:
+        f.close()
+
+
 def _is_hdf5(path) -> bool:
     from . import hdf5
     return isinstance(path, str) and os.path.isfile(path) and hdf5.is_hdf5(path)
@@ -1007,6 +1044,13 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             data = None
         if data is not None:
             da = DataArray(data, za.dims, coords, name=var, attrs=za.attrs)
+            return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
+                           preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
+    if device is not None and len(paths) == 1 and engine is None and _is_hdf5(paths[0]):
+        got = _hdf5_to_device(paths[0], var, xycoords, timecoord, time_sel, georegions, lon_is_360, device)
+        if got is not None:
+            data, src, coords = got
+            da = DataArray(data, src.dims, coords, name=var, attrs=src.attrs)
             return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                            preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
     parts = []

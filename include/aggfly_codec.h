@@ -39,7 +39,8 @@ int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize);
 int64_t afcodec_blosc_encode_lz4(const void* src, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
                                  void* dst, int64_t cap);
 
-/* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream, 4 numcodecs LZ4): read and
+/* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream, 4 numcodecs LZ4;
+ * kind + 16 * element_size adds a byte-unshuffle after the codec: HDF5 / netCDF-4 shuffle + deflate chunks): read and
  * decoded paths[i] -> dsts[i], one chunk per OpenMP thread. */
 int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
                          int nthreads, int64_t* results);

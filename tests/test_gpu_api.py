@@ -456,6 +456,29 @@ def test_clip_to_regions_reads_only_the_box(torch_cuda, tmp_path, monkeypatch):
         assert 0 < sum(calls) < 2 * 5 * 6                                             # of 60 chunk files
 
 
+def test_netcdf4_chunked_variable_streams_into_hbm(torch_cuda, monkeypatch):
+    """A chunked netCDF-4 variable (shuffle + deflate [+ fletcher32] chunks, or unfiltered chunks) takes the same
+    streaming route as a Zarr array: byte ranges of the .nc file inflated and unshuffled by the native codec,
+    placed on the GPU.  Files written by the real HDF5 library (tests/golden/hdf5)."""
+    from aggfly_amd import codec
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdf5")
+    calls = []
+    real = codec.decode_ranges
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8: calls.append(kind) or real(kind, locs, outs, threads))
+    for fn in ("nc4_like.nc", "old_style.h5"):
+        for var in ("t2m", "t2m_chunked_nofilter", "t2m_packed"):                 # the packed one is contiguous: host read, one upload
+            host = af.dataset_from_path(os.path.join(fix, fn), var)
+            dev = af.dataset_from_path(os.path.join(fix, fn), var, device="cuda")
+            assert dev.cube().is_cuda and dev.time.equals(host.time)
+            np.testing.assert_array_equal(dev.cube().cpu().numpy(), host.cube())
+            np.testing.assert_array_equal(dev.latitude, host.latitude)
+        sel = af.dataset_from_path(os.path.join(fix, fn), "t2m", device="cuda", time_sel=slice("2000-01-03", "2000-01-05"))
+        hsel = af.dataset_from_path(os.path.join(fix, fn), "t2m", time_sel=slice("2000-01-03", "2000-01-05"))
+        assert sel.time.equals(hsel.time) and len(sel.time) == 12
+        np.testing.assert_array_equal(sel.cube().cpu().numpy(), hsel.cube())
+    assert ("zlib", 4) in calls and "raw" in calls                                 # the native route really ran
+
+
 def test_packed_int16_store_streams_packed_and_unpacks_in_hbm(torch_cuda, tmp_path):
     """ERA5-style packing (int16 + scale_factor / add_offset / _FillValue): the streaming route moves the
     packed integers over PCIe and applies the CF decoding in HBM — bit-identical to the host route, for
