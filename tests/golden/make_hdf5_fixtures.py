@@ -66,6 +66,23 @@ def main():
     write(os.path.join(OUT, "old_style.h5"), h5py, track_order=False, libver=None, big_endian=True, fletcher=True)
     write(os.path.join(OUT, "v18.h5"), h5py, track_order=True, libver=("earliest", "v108"))
     write(os.path.join(OUT, "latest.h5"), h5py, track_order=True, libver="latest")
+    with h5py.File(os.path.join(OUT, "unlimited_time.nc"), "w", track_order=True) as f:               # a record dimension, grown in steps
+        r = recipe()
+        tm = f.create_dataset("time", shape=(0,), maxshape=(None,), dtype="<i4", chunks=(8,))
+        la = f.create_dataset("latitude", data=r["latitude"])
+        lo = f.create_dataset("longitude", data=r["longitude"])
+        v = f.create_dataset("t2m", shape=(0, NY, NX), maxshape=(None, NY, NX), dtype="<f4", chunks=(1, NY, NX), compression="gzip",
+                             compression_opts=2, shuffle=True, fillvalue=np.float32(9.96921e36))
+        tm.attrs["units"] = np.bytes_("hours since 1900-01-01 00:00:00.0")
+        for d, n in ((tm, "time"), (la, "latitude"), (lo, "longitude")):
+            d.make_scale(n)
+        for i, d in enumerate((tm, la, lo)):
+            v.dims[i].attach_scale(d)
+        for k0 in range(0, T, 10):                                                                     # appended like a model writes records
+            k1 = min(T, k0 + 10)
+            tm.resize((k1,)); v.resize((k1, NY, NX))
+            tm[k0:k1] = r["time"][k0:k1]
+            v[k0:k1] = r["t2m"][k0:k1]
     with h5py.File(os.path.join(OUT, "dense_group.h5"), "w", track_order=True) as f:                   # > 8 links: fractal heap
         for i in range(12):
             f.create_dataset(f"v{i:02d}", data=np.arange(3, dtype="<f4") + i)

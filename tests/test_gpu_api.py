@@ -465,6 +465,8 @@ def test_netcdf4_chunked_variable_streams_into_hbm(torch_cuda, monkeypatch):
     calls = []
     real = codec.decode_ranges
     monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8: calls.append(kind) or real(kind, locs, outs, threads))
+    rec = af.dataset_from_path(os.path.join(fix, "unlimited_time.nc"), "t2m", device="cuda")     # record dimension, 1-step chunks
+    np.testing.assert_array_equal(rec.cube().cpu().numpy(), af.dataset_from_path(os.path.join(fix, "unlimited_time.nc"), "t2m").cube())
     for fn in ("nc4_like.nc", "old_style.h5"):
         for var in ("t2m", "t2m_chunked_nofilter", "t2m_packed"):                 # the packed one is contiguous: host read, one upload
             host = af.dataset_from_path(os.path.join(fix, fn), var)

@@ -60,6 +60,17 @@ def test_dense_groups_and_attributes():
         assert len(f.datasets) == 40 and all(np.array_equal(f.datasets[f"var_{i:03d}"].read(), np.arange(5) * i) for i in range(40))
 
 
+def test_record_dimension_grown_in_steps():
+    """An unlimited time dimension written record block by record block (v1 B-tree with many small chunks)."""
+    with hdf5.H5File(os.path.join(FIX, "unlimited_time.nc")) as f:
+        d = f.datasets["t2m"]
+        assert d.shape == (37, 9, 14) and d.layout[2] == (1, 9, 14) and d.dims == ("time", "latitude", "longitude")
+        np.testing.assert_array_equal(d.read(), R["t2m"])
+        np.testing.assert_array_equal(f.datasets["time"].read(), R["time"])
+    ds = af.dataset_from_path(os.path.join(FIX, "unlimited_time.nc"), "t2m")
+    assert ds.cube().shape == (37, 9, 14) and ds.time[0] == pd.Timestamp("2000-01-01")
+
+
 def test_latest_format_bounds_are_refused_clearly():
     with hdf5.H5File(os.path.join(FIX, "latest.h5")) as f:
         np.testing.assert_array_equal(f.datasets["t2m_packed"].read(), R["packed"])      # contiguous data still reads
