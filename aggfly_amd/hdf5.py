@@ -17,8 +17,9 @@ library's default or v1.8 format bounds contain:
   records them.
 
 Pinned against files written by the real HDF5 library (h5py 3.3 / libhdf5 1.10.6): `tests/golden/hdf5/`,
-`tests/golden/make_hdf5_fixtures.py`.  The "latest" format bounds (version-4 layouts, fixed / extensible
-array chunk indices) are not netCDF-4 output and are refused.
+`tests/golden/make_hdf5_fixtures.py`.  With the "latest" format bounds (not netCDF-4 output) version-4 layouts
+are read when the chunk index is a single chunk, implicit or a fixed array; the indices for growing datasets
+(extensible array, v2 B-tree) are refused.
 """
 from __future__ import annotations
 
@@ -462,6 +463,32 @@ class H5Dataset:
             self.layout = ("contiguous", f.addr(q + 2), f.length(q + 2 + f.O))
         elif ver == 4 and cls == 0:
             self.layout = ("compact", q + 4, f.u(q + 2, 2))
+        elif ver == 4 and cls == 2:
+            # version-4 chunked layout (HDF5 >= 1.10 with the "latest" format bounds): the chunk index is one of
+            # five structures; single chunk, implicit and fixed array are read, the two for growing datasets
+            # (extensible array, v2 B-tree) are refused
+            lflags, nd, enc = f.buf[q + 2], f.buf[q + 3], f.buf[q + 4]
+            p = q + 5
+            dims = tuple(f.u(p + enc * i, enc) for i in range(nd))
+            p += enc * nd
+            itype = f.buf[p]
+            p += 1
+            info = {}
+            if itype == 1:                                                 # single chunk
+                if lflags & 0x02:
+                    info = {"size": f.length(p), "mask": f.u(p + f.L, 4)}
+                    p += f.L + 4
+            elif itype == 3:                                               # fixed array
+                info = {"page_bits": f.buf[p]}
+                p += 1
+            elif itype == 4:
+                p += 5
+            elif itype == 5:
+                p += 6
+            self.layout = ("chunked", f.addr(p), dims[:-1])
+            self._v4 = (itype, info)
+            if itype not in (1, 2, 3):
+                self.layout = ("unsupported", "a chunk index for growing datasets (extensible array / v2 B-tree, 'latest' format bounds)")
         else:
             self.layout = ("unsupported", f"data layout version {ver} class {cls} (written with the 'latest' format bounds)")
 
@@ -505,6 +532,9 @@ class H5Dataset:
         out = []
         if btree == UNDEF:
             return out
+        v4 = getattr(self, "_v4", None)
+        if v4 is not None:
+            return self._chunks_v4(btree, cdims, *v4)
 
         def node(a):
             if f.buf[a:a + 4] != b"TREE" or f.buf[a + 4] != 1:
@@ -523,6 +553,56 @@ class H5Dataset:
                     out.append((offs, child, nbytes, mask))
 
         node(btree)
+        return out
+
+    def _chunks_v4(self, addr: int, cdims, itype: int, info: dict):
+        f = self.file
+        grid = [-(-s // c) for s, c in zip(self.shape, cdims)]
+        nchunks = int(np.prod(grid))
+        cbytes = int(np.prod(cdims)) * self.disk_dtype.itemsize
+        offsets = [tuple(i * c for i, c in zip(np.unravel_index(k, grid), cdims)) for k in range(nchunks)]
+        if itype == 1:                                                     # the whole dataset is one chunk
+            return [(offsets[0], addr, info.get("size", cbytes), info.get("mask", 0))]
+        if itype == 2:                                                     # implicit: unfiltered chunks back to back
+            return [(offsets[k], addr + k * cbytes, cbytes, 0) for k in range(nchunks)]
+        # fixed array: header -> data block (-> pages) of per-chunk entries in row-major chunk order
+        if f.buf[addr:addr + 4] != b"FAHD":
+            raise HDF5Error("fixed array header signature missing")
+        client, esize, page_bits = f.buf[addr + 5], f.buf[addr + 6], f.buf[addr + 7]
+        nelmts, dblk = f.length(addr + 8), f.addr(addr + 8 + f.L)
+        if dblk == UNDEF:
+            return []
+        if f.buf[dblk:dblk + 4] != b"FADB":
+            raise HDF5Error("fixed array data block signature missing")
+        p = dblk + 6 + f.O
+        page_n = 1 << page_bits
+
+        def entry(q):
+            a = f.addr(q)
+            if client == 1:                                                # filtered chunks: address, size, filter mask
+                return a, f.u(q + f.O, esize - f.O - 4), f.u(q + esize - 4, 4)
+            return a, cbytes, 0
+
+        out = []
+        if nelmts > page_n:                                                # paged: bitmap, checksum, then pages with a checksum each
+            npages = -(-nelmts // page_n)
+            bitmap = f.buf[p:p + (npages + 7) // 8]
+            p += (npages + 7) // 8 + 4
+            k = 0
+            for pg in range(npages):
+                n_here = min(page_n, nelmts - pg * page_n)
+                if bitmap[pg // 8] & (0x80 >> (pg % 8)):
+                    for i in range(n_here):
+                        a, sz, mask = entry(p + i * esize)
+                        if a != UNDEF and k + i < nchunks:
+                            out.append((offsets[k + i], a, sz, mask))
+                    p += n_here * esize + 4
+                k += n_here
+        else:
+            for k in range(min(nelmts, nchunks)):
+                a, sz, mask = entry(p + k * esize)
+                if a != UNDEF:
+                    out.append((offsets[k], a, sz, mask))
         return out
 
     def _unfilter(self, raw: bytes, mask: int, nbytes_out: int) -> np.ndarray:

@@ -83,6 +83,18 @@ def main():
             tm.resize((k1,)); v.resize((k1, NY, NX))
             tm[k0:k1] = r["time"][k0:k1]
             v[k0:k1] = r["t2m"][k0:k1]
+    with h5py.File(os.path.join(OUT, "latest_indices.h5"), "w", libver="latest") as f:                # version-4 layouts, every index type
+        a = np.arange(42, dtype="<f4").reshape(6, 7)
+        f.create_dataset("single", data=a, chunks=(6, 7))
+        f.create_dataset("single_filtered", data=a, chunks=(6, 7), compression="gzip", shuffle=True)
+        b = np.arange(1200, dtype="<f4").reshape(40, 30)
+        f.create_dataset("paged", data=b, chunks=(1, 1), compression="gzip")                          # 1,200 chunks: a paged fixed array
+        f.create_dataset("growing", data=a, chunks=(2, 7), maxshape=(None, 7))                        # extensible array: refused
+        dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+        dcpl.set_chunk((2, 7)); dcpl.set_alloc_time(h5py.h5d.ALLOC_TIME_EARLY)
+        space = h5py.h5s.create_simple((6, 7))
+        did = h5py.h5d.create(f.id, b"implicit", h5py.h5t.IEEE_F32LE, space, dcpl=dcpl)               # early allocation, no filter: implicit index
+        did.write(h5py.h5s.ALL, h5py.h5s.ALL, a)
     with h5py.File(os.path.join(OUT, "dense_group.h5"), "w", track_order=True) as f:                   # > 8 links: fractal heap
         for i in range(12):
             f.create_dataset(f"v{i:02d}", data=np.arange(3, dtype="<f4") + i)

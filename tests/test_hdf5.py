@@ -71,12 +71,19 @@ def test_record_dimension_grown_in_steps():
     assert ds.cube().shape == (37, 9, 14) and ds.time[0] == pd.Timestamp("2000-01-01")
 
 
-def test_latest_format_bounds_are_refused_clearly():
+def test_latest_format_bounds():
+    """Version-4 layouts (HDF5 >= 1.10, "latest" bounds; not what netCDF-4 writes): single-chunk, implicit and
+    fixed-array (also paged) chunk indices are read, the indices of growing datasets are refused clearly."""
     with hdf5.H5File(os.path.join(FIX, "latest.h5")) as f:
-        np.testing.assert_array_equal(f.datasets["t2m_packed"].read(), R["packed"])      # contiguous data still reads
+        for name, key in (("t2m", "t2m"), ("t2m_chunked_nofilter", "t2m"), ("t2m_packed", "packed")):
+            np.testing.assert_array_equal(f.datasets[name].read(), R[key])
         assert f.datasets["t2m"].dims == ("time", "latitude", "longitude")
-        with pytest.raises(hdf5.HDF5Error, match="latest"):
-            f.datasets["t2m"].read()
+    a, b = np.arange(42, dtype="f4").reshape(6, 7), np.arange(1200, dtype="f4").reshape(40, 30)
+    with hdf5.H5File(os.path.join(FIX, "latest_indices.h5")) as f:
+        for name, want in (("single", a), ("single_filtered", a), ("paged", b), ("implicit", a)):
+            np.testing.assert_array_equal(f.datasets[name].read(), want)
+        with pytest.raises(hdf5.HDF5Error, match="growing"):
+            f.datasets["growing"].read()
     assert not hdf5.is_hdf5(os.path.join(HERE, "golden", "reference_goldens.json"))
     with pytest.raises(hdf5.HDF5Error):
         hdf5.H5File(os.path.join(HERE, "golden", "reference_goldens.json"))
