@@ -1,10 +1,11 @@
-"""Loaders feeding the hot path: ``dataset_from_path`` and a dependency-free Zarr v2 codec.
+"""Loaders feeding the hot path: ``dataset_from_path``, a dependency-free Zarr (formats 2 and 3) reader /
+writer, and the streaming routes that put chunked stores (Zarr, netCDF-4) straight into HBM.
 
 The reference opens stores through xarray (`aggfly/dataset/dataset.py:636-740`) and converts
 to time-contiguous Zarr with `dataset_to_zarr` / `zarr_from_path`
 (`aggfly/dataset/zarr_convert.py:50-156`).  Neither xarray nor zarr/netCDF4 is installed here
-or on the GPU box, so this module reads what can be read with numpy + the standard
-library:
+or on the GPU box, so this module reads the containers itself, with numpy, the standard library
+and the native chunk codecs of `csrc/blosc1.c`:
 
 * Zarr directory stores, format 2 and format 3 (``zarr.json``): C-order chunks, ``compressor`` null / zlib / gzip / lz4 / blosc (every
   Blosc-1 codec and shuffle, decoded natively by ``csrc/blosc1.c``) / zstd, ``_ARRAY_DIMENSIONS``
@@ -51,7 +52,7 @@ def _looks_like_zarr(path, storage_options=None) -> bool:
 
 
 # --------------------------------------------------------------------------------------
-# Zarr v2
+# Zarr (formats 2 and 3)
 # --------------------------------------------------------------------------------------
 def _decompress(buf: bytes, comp, nbytes: Optional[int] = None):
     """Decoded bytes of one chunk.  ``nbytes`` = decoded size when known (needed for zstd frames)."""
