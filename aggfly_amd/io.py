@@ -1047,7 +1047,7 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             da = DataArray(data, za.dims, coords, name=var, attrs=za.attrs)
             return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                            preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
-    if device is not None and len(paths) == 1 and engine is None and _is_hdf5(paths[0]):
+    if device is not None and len(paths) == 1 and engine in (None, "netcdf4", "h5netcdf") and _is_hdf5(paths[0]):
         got = _hdf5_to_device(paths[0], var, xycoords, timecoord, time_sel, georegions, lon_is_360, device)
         if got is not None:
             data, src, coords = got
