@@ -12,7 +12,10 @@ shards here is the path itself:
   ``all_reduce(SUM)`` of ``(K+1)·R·P`` doubles finishes the job, then ``res = num / den``.
 
 The exchange helpers (`gather_panel`, `reduce_num_den`) work on any backend and are covered by
-world_size-2 gloo tests; only `aggregate_dataset_sharded` touches the GPU.
+world_size-2 gloo tests; only `aggregate_dataset_sharded` / `aggregate_store_sharded` touch the GPU.
+`aggregate_store_sharded` is the north_star's "zarr chunks streamed per GPU": every rank opens the same
+store, works out its own run of output periods from the time coordinate, and streams ONLY those time steps
+into its GPU (`io.dataset_from_path(..., device=, time window)`) before the panel is gathered.
 """
 from __future__ import annotations
 
@@ -161,5 +164,39 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
         _, _, full = reduce_num_den(pr[0].panel["num"], pr[0].panel["den"], group)
     else:
         raise ValueError("shard must be 'time' or 'cells'")
+    df = agg._assemble_frame(full, names, region_ids, labels, weights)
+    return agg._merge_regions(df, weights)
+
+
+def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto", group=None, **open_kwargs):
+    """Time-sharded `aggregate_dataset` straight from a store on disk.
+
+    ``weights_of(dataset) -> GridWeights`` builds the weights for the rank's (possibly region-clipped) dataset
+    (e.g. ``lambda ds: af.weights_from_objects(ds, regions, table=table)``).  Every rank reads the store's
+    time coordinate, takes the output periods `split_even` gives it, streams only those steps into HBM, reduces
+    them, and one all_gather assembles the region x period panel; the frame is returned on every rank.
+    ``open_kwargs`` go to `dataset_from_path` (``xycoords``, ``lon_is_360``, ``georegions``, ``preprocess`` ...)."""
+    import torch
+    from . import aggregate as agg, io as afio
+    rank, ws = world(group)
+    timecoord = open_kwargs.get("timecoord", "time")
+    tindex = afio.read_time_coordinate(path, var, timecoord)
+    freq = output_freq(aggregator_dict)
+    bounds, labels = resample_groups(tindex, freq)
+    P = len(labels)
+    counts = [split_even(P, r, ws)[1] - split_even(P, r, ws)[0] for r in range(ws)]
+    p_lo, p_hi = split_even(P, rank, ws)
+    k_lo, k_hi = int(bounds[p_lo]), int(bounds[p_hi])
+    names = agg._lower_all(aggregator_dict)[3]
+    # an empty window still opens the store (coordinates, grid) so that every rank builds the same weights
+    local = afio.dataset_from_path(path, var, device="cuda", time_window=(k_lo, max(k_hi, k_lo)), **open_kwargs)
+    weights = weights_of(local)
+    if k_hi > k_lo:
+        res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
+    else:
+        from . import engine as eng
+        _, region_ids = eng.get_csr(weights, local)
+        res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
+    full = gather_panel(res, counts, group)
     df = agg._assemble_frame(full, names, region_ids, labels, weights)
     return agg._merge_regions(df, weights)

@@ -886,6 +886,22 @@ def _open_netcdf3(path, var):
     return DataArray(data, dims, coords, name=var, attrs=attrs)
 
 
+def read_time_coordinate(path, var, timecoord="time"):
+    """The decoded time coordinate of a Zarr store (or of the dimension ``timecoord`` of a netCDF-4 file) without
+    touching the data variable."""
+    if _looks_like_zarr(path):
+        c = ZarrArray(os.path.join(path, timecoord))
+        v = c.read(threads=1)
+        return _decode_time(v, c.attrs) if " since " in str(c.attrs.get("units", "")) else pd.DatetimeIndex(v)
+    if _is_hdf5(path):
+        from . import hdf5
+        with hdf5.H5File(path) as f:
+            c = f.datasets[timecoord]
+            cattrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in c.attrs.items()}
+            return _decode_time(c.read(threads=1), cattrs)
+    raise ValueError(f"cannot read a time coordinate from {path}")
+
+
 def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
     """(y0, y1, x0, x1) on the STORED axes when the clip to the regions' extent (`grid.py:150-217`) keeps one
     contiguous run along both spatial axes, else None (the clip then happens after the load)."""
@@ -913,7 +929,7 @@ def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
     return (ry + rx) if dims[1] == yname else (rx + ry)
 
 
-def _hdf5_to_device(path, var, xycoords, timecoord, time_sel, georegions, lon_is_360, device):
+def _hdf5_to_device(path, var, xycoords, timecoord, time_sel, georegions, lon_is_360, device, time_window=None):
     """A chunked netCDF-4 variable through the streaming route (native inflate + unshuffle, GPU-side placement);
     None when the variable does not qualify (contiguous, not time-leading, ...): the host route then reads it."""
     from . import hdf5
@@ -930,7 +946,10 @@ def _hdf5_to_device(path, var, xycoords, timecoord, time_sel, georegions, lon_is
                 cattrs = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in c.attrs.items()}
                 vals = c.read(threads=1)
                 coords[d] = _decode_time(vals, cattrs) if " since " in str(cattrs.get("units", "")) else vals
-        window = _time_window(coords[timecoord], time_sel) if time_sel is not None and timecoord in coords else None
+        if time_window is not None:
+            window = (int(time_window[0]), int(time_window[1]))
+        else:
+            window = _time_window(coords[timecoord], time_sel) if time_sel is not None and timecoord in coords else None
         box = _clip_box(src.dims, coords, xycoords, georegions, lon_is_360) if georegions is not None else None
         try:
             data, _ = array_to_device(src, device=device, t_range=window, yx_box=box)
@@ -984,11 +1003,13 @@ def _time_window(tindex, time_sel):
 
 def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="time", time_sel=None,
                       georegions=None, lon_is_360=True, time_fix=False, preprocess=None, name=None,
-                      chunks=None, preprocess_at_load=False, parallel=True, device=None, **kwargs) -> Dataset:
+                      chunks=None, preprocess_at_load=False, parallel=True, device=None, time_window=None, **kwargs) -> Dataset:
     """`dataset_from_path` (`dataset.py:636-740`), same signature.  ``chunks`` / ``parallel``
     are accepted and ignored (there is no dask graph); a list / glob of paths is concatenated
     along time like ``open_mfdataset``.  ``device="cuda"`` (extension) streams a single float
-    Zarr array straight into HBM (``zarr_to_device``) and applies ``preprocess`` there."""
+    Zarr array straight into HBM (``zarr_to_device``) and applies ``preprocess`` there; ``time_window=(k0, k1)``
+    (extension, streaming route only) restricts the read to those time steps — what a rank of a time-sharded
+    job asks for (`distributed.aggregate_store_sharded`)."""
     import glob
     if isinstance(path, str) and "://" in path:
         raise ImportError(f"remote stores ({path.split('://')[0]}://) need fsspec backends that are not available here")
@@ -1010,7 +1031,11 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             # a time selection on a time-leading store: only the chunks that hold the selected steps are
             # read and decoded (a decade out of a 40-year store reads a quarter of it)
             window = None
-            if time_sel is not None and za.dims and za.dims[0] == timecoord and timecoord in coords:
+            if time_window is not None:
+                if not (za.dims and za.dims[0] == timecoord):
+                    raise ValueError("time_window needs a time-leading array")
+                window = (int(time_window[0]), int(time_window[1]))
+            elif time_sel is not None and za.dims and za.dims[0] == timecoord and timecoord in coords:
                 window = _time_window(coords[timecoord], time_sel)
             # a clip to the regions' extent (`dataset.py:150-175`): only the chunks that touch the box are read,
             # and only the box reaches HBM; `Dataset` repeats the clip on the clipped grid (a no-op)
@@ -1048,7 +1073,7 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                            preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
     if device is not None and len(paths) == 1 and engine in (None, "netcdf4", "h5netcdf") and _is_hdf5(paths[0]):
-        got = _hdf5_to_device(paths[0], var, xycoords, timecoord, time_sel, georegions, lon_is_360, device)
+        got = _hdf5_to_device(paths[0], var, xycoords, timecoord, time_sel, georegions, lon_is_360, device, time_window)
         if got is not None:
             data, src, coords = got
             da = DataArray(data, src.dims, coords, name=var, attrs=src.attrs)
@@ -1084,6 +1109,8 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
         da = parts[0]
         if preprocess_at_load:
             preprocess = None
+    if time_window is not None:                                     # the streaming route was not taken: cut on the host
+        da = da.isel(**{timecoord: slice(int(time_window[0]), int(time_window[1]))})
     ds = Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                  preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
     return ds.to_device(device) if device is not None else ds      # containers without a streaming route: one upload

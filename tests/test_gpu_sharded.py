@@ -63,3 +63,64 @@ def test_sharded_equals_single(torch_cuda, tmp_path, mode):
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, rtol=1e-12 if mode == "cells" else 0, atol=0, check_exact=(mode == "time"))
+
+
+STORE_SCRIPT = r'''
+import os, sys
+import numpy as np, pandas as pd, torch, torch.distributed as dist
+import aggfly_amd as af
+from aggfly_amd import synth, distributed as D
+
+store, out = sys.argv[1], sys.argv[2]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    dist.init_process_group("gloo")
+ny, nx = 10, 12
+tab = synth.weights_table(ny, nx, 6, seed=62, secondary=True)
+gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "month"})],
+            t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+               ("aggregate", {"calc": "sum", "groupby": "month"})])
+weights_of = lambda ds: af.weights_from_objects(ds, gr, table=tab)
+if dist.is_initialized():
+    from aggfly_amd import codec
+    seen = []
+    real = codec.decode_ranges
+    codec.decode_ranges = lambda kind, locs, outs, threads=8: seen.append(len(locs)) or real(kind, locs, outs, threads)
+    df = D.aggregate_store_sharded(weights_of, store, "t2m", spec, lon_is_360=True, preprocess=lambda x: x - 273.15)
+    assert 0 < sum(seen) < 20, seen          # each rank decoded about half of the store's 28 chunks, not all of them
+else:
+    ds = af.dataset_from_path(store, "t2m", lon_is_360=True, preprocess=lambda x: x - 273.15, device="cuda")
+    df = af.aggregate_dataset(dataset=ds, weights=weights_of(ds), aggregator_dict=spec)
+if D.world()[0] == 0:
+    df.to_csv(out, index=False)
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def test_store_sharded_streams_each_ranks_window(torch_cuda, tmp_path):
+    """`aggregate_store_sharded`: two ranks open the same Zarr store, each streams only the time steps of its own
+    output periods into the GPU, and the gathered panel equals the single-process run."""
+    import numpy as np
+    import aggfly_amd as af
+    from aggfly_amd import synth
+    T, ny, nx = 24 * 400, 10, 12
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=61, ocean_frac=0.1, scattered_nan=30) + np.float32(273.15)
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": pd.date_range("2003-03-01", periods=T, freq="h"), "latitude": 30 + 0.25 * np.arange(ny),
+                                  "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+    store = str(tmp_path / "era.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 350, "latitude": ny, "longitude": nx})
+    script = tmp_path / "store_job.py"
+    script.write_text(STORE_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, AGGFLY_HIP_EXACT_ORDER="1")
+    one, two = str(tmp_path / "one.csv"), str(tmp_path / "two.csv")
+    r = subprocess.run([sys.executable, str(script), store, one], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script), store, two], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = pd.read_csv(one), pd.read_csv(two)
+    assert len(a) == len(b) > 0
+    pd.testing.assert_frame_equal(a, b, check_exact=True)
