@@ -123,6 +123,49 @@ class DataArray:
                 coords.pop(d, None)
         return DataArray(data, dims, coords, self.name, self.attrs)
 
+    def sel(self, indexers=None, **kw):
+        """Label-based selection (the part of ``xarray.DataArray.sel`` the reference's callers use): a
+        scalar label drops the dimension, a list / array of labels keeps it, a ``slice`` of labels is
+        inclusive on both ends; an absent label raises ``KeyError``."""
+        import pandas as pd
+        out = self
+        for d, lab in dict(indexers or {}, **kw).items():
+            c = out.coords[d]
+            index = c if isinstance(c, (CFTimeIndex, pd.Index)) else pd.Index(np.asarray(c))
+            if isinstance(lab, slice):
+                if isinstance(index, CFTimeIndex):
+                    raise NotImplementedError("slice selection on a CF-calendar index: use Dataset(time_sel=...)")
+                lo, hi = index.slice_locs(lab.start, lab.stop)
+                out = out.isel(**{d: slice(lo, hi)})
+                continue
+            scalar = np.ndim(lab) == 0
+            labs = [lab] if scalar else list(lab)
+            if isinstance(index, CFTimeIndex):
+                vals = list(index)
+                pos = []
+                for x in labs:
+                    if x not in vals:
+                        raise KeyError(x)
+                    pos.append(vals.index(x))
+                pos = np.asarray(pos)
+            else:
+                if isinstance(index, pd.DatetimeIndex):
+                    labs = list(pd.DatetimeIndex(labs))
+                pos = index.get_indexer(labs)
+                if (pos < 0).any():
+                    raise KeyError(labs[int(np.nonzero(pos < 0)[0][0])])
+            out = out.isel(**{d: pos[0] if scalar else pos})
+        return out
+
+    def expand_dims(self, dim, axis=0):
+        """A length-1 dimension ``dim`` (re-)inserted at ``axis``; its coordinate is left out."""
+        if dim in self.dims:
+            return self
+        data = self.data.unsqueeze(axis) if _is_torch(self.data) else np.expand_dims(self.data, axis)
+        dims = list(self.dims)
+        dims.insert(axis, dim)
+        return DataArray(data, dims, dict(self.coords), self.name, self.attrs)
+
     def sortby(self, dim):
         c = self.coords[dim]
         order = c.argsort() if isinstance(c, CFTimeIndex) else np.argsort(np.asarray(c), kind="stable")

@@ -193,6 +193,29 @@ class Dataset:
                 raise ValueError("update(): bare arrays must keep the current shape")
             self.da = self.da._replace(data=array)
 
+    def sel(self, **kwargs):
+        """`dataset.py:401-417`: select by label along the named dimensions, keeping every dimension
+        (a scalar label leaves a length-1 axis, as the reference's ``expand_dims`` does)."""
+        da = self.da
+        for k, v in kwargs.items():
+            da = da.sel(**{k: [v] if np.ndim(v) == 0 and not isinstance(v, slice) else v})
+        self.da = da
+        self.grid = Grid(self.longitude, self.latitude, self.name, self.lon_is_360)
+
+    def rechunk(self, chunks="auto"):
+        """`dataset.py:120-130`.  There is no chunk graph here (the cube is one resident array): accepted, no effect."""
+        return None
+
+    def compute(self, dask_array=True, chunks=None):
+        """`dataset.py:196-211`.  Data are always materialised: accepted, no effect."""
+        return None
+
+    def interior_cells(self, georegions, buffer=None, dtype="georegions", maxsize=None):
+        """`dataset.py:315-399` builds cell polygons with geopandas / shapely — part of the CPU-side weights
+        pipeline that stays with the reference."""
+        raise ImportError("Dataset.interior_cells belongs to aggfly's CPU-side geometry pipeline (geopandas / shapely), "
+                          "which this engine does not re-implement; run it with aggfly and pass the table to weights_from_objects(table=...)")
+
     def clip_data_to_grid(self, inlat, inlon):
         self.da = self.da.isel(latitude=np.nonzero(inlat)[0], longitude=np.nonzero(inlon)[0])
 

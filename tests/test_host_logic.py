@@ -158,6 +158,26 @@ def test_dataset_normalisation_and_lon_resort():
         af.weights_from_objects(ds, af.GeoRegions(pd.DataFrame({"geoid": ["r"]})), zero_weight="bogus")
 
 
+def test_dataset_sel_keeps_every_dimension():
+    """`Dataset.sel` (`dataset.py:401-417`): label selection that keeps the selected axis; rechunk / compute are
+    accepted no-ops; interior_cells points at the CPU-side pipeline."""
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=True)
+    one = ds.deepcopy(); one.sel(time=time[2])
+    assert one.da.dims == ("latitude", "longitude", "time") and one.cube().shape == (1, 2, 2)
+    assert np.array_equal(one.cube()[0], arr[2]) and one.time.equals(time[2:3])
+    two = ds.deepcopy(); two.sel(latitude=[lat[1]], time=[time[0], time[3]])
+    assert two.cube().shape == (2, 1, 2) and np.array_equal(two.cube()[:, 0], arr[[0, 3], 1])
+    assert two.grid.latitude.tolist() == [lat[1]]
+    rng = ds.deepcopy(); rng.sel(time=slice(time[1], time[2]))
+    assert rng.time.equals(time[1:3])                                            # label slices are inclusive
+    with pytest.raises(KeyError):
+        ds.deepcopy().sel(latitude=12.345)
+    assert ds.rechunk("auto") is None and ds.compute() is None and ds.cube().shape == (4, 2, 2)
+    with pytest.raises(ImportError, match="geopandas"):
+        ds.interior_cells(None)
+
+
 def test_preprocess_and_unsorted_time():
     arr, time, lat, lon = gi.dataset_360_inputs()
     perm = [2, 0, 3, 1]
