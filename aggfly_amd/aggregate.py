@@ -203,6 +203,28 @@ def _lower_all(aggregator_dict):
     return order, fused_cols, staged, order_keys
 
 
+def transform_dataset(dataset: Dataset, key: str, **kwargs):
+    """`transform_dataset` (`aggregate.py:36-78`), the eager form: ``(datasets, keys)`` for one 'transform' step.
+    ``exp`` fans out to ``key_{e}`` over ``exp[0]`` (the reference indexes the wrapped list), ``inter`` keeps the
+    key, ``transform='spline'`` gives ``key_spline1`` / ``key_spline2``.  `aggregate_dataset` does not call this —
+    `engine.lower_spec` lowers the same steps into the fused plan — it is here for callers that use it directly."""
+    if "exp" in kwargs:
+        exps = kwargs["exp"] if isinstance(kwargs["exp"], list) else [kwargs["exp"]]
+        out = {f"{key}_{e}": dataset.power(e) for e in exps[0]}
+    elif "inter" in kwargs:
+        out = {key: dataset.interact(kwargs["inter"])}
+    elif "spline" in kwargs.get("transform", ""):
+        out = dict(zip([f"{key}_spline1", f"{key}_spline2"], dataset.spline()))
+    else:
+        raise ValueError("No valid transform argument provided.")
+    return out.values(), out.keys()
+
+
+def multi_dd_to_dict(data, key, ddargs):
+    """`multi_dd_to_dict` (`aggregate.py:285-303`): ``(data, [key_{lo}_{hi} ...])`` for a multi-threshold step."""
+    return data, [f"{key}_{x[0]}_{x[1]}" for x in ddargs]
+
+
 def aggregate_time(dataset: Dataset, weights=None, aggregator_dict=None, engine: str = "auto", **kwargs) -> Dict[str, Dataset]:
     """`aggregate_time` (`aggregate.py:101-162`): {output name: Dataset on the output time axis}."""
     resolve_engine(engine)

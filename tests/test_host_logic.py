@@ -178,6 +178,27 @@ def test_dataset_sel_keeps_every_dimension():
         ds.interior_cells(None)
 
 
+def test_transform_dataset_and_multi_dd_keys():
+    """`transform_dataset` / `multi_dd_to_dict` (`aggregate.py:36-78,285-303`): the eager helpers name their outputs
+    exactly as the DSL lowering does (`key_{e}`, `key_spline1/2`, `key_{lo}_{hi}`)."""
+    from aggfly_amd.aggregate import multi_dd_to_dict, transform_dataset
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}))
+    vals, keys = transform_dataset(ds, "tavg", transform="power", exp=[np.arange(1, 4)])
+    assert list(keys) == ["tavg_1", "tavg_2", "tavg_3"]
+    for e, v in zip((1, 2, 3), vals):
+        np.testing.assert_array_equal(v.cube(), np.power(ds.cube(), np.int64(e)))
+    vals, keys = transform_dataset(ds, "t", transform="spline")
+    assert list(keys) == ["t_spline1", "t_spline2"]
+    a, b = list(vals)
+    np.testing.assert_array_equal(b.cube(), (ds.cube() > 20) * (ds.cube() - 20))
+    vals, keys = transform_dataset(ds, "t", transform="interact", inter=ds)
+    assert list(keys) == ["t"] and np.array_equal(list(vals)[0].cube(), ds.cube() * ds.cube())
+    with pytest.raises(ValueError, match="No valid transform"):
+        transform_dataset(ds, "t", transform="log")
+    assert multi_dd_to_dict(["a", "b"], "dd", [[10, 30, 0], [0, 5, 1]]) == (["a", "b"], ["dd_10_30", "dd_0_5"])
+
+
 def test_preprocess_and_unsorted_time():
     arr, time, lat, lon = gi.dataset_360_inputs()
     perm = [2, 0, 3, 1]
