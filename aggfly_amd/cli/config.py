@@ -300,3 +300,62 @@ def load_config(path) -> RunConfig:
     except yaml.YAMLError as e:
         raise ConfigError([f"could not parse YAML: {e}"])
     return parse_config(raw)
+
+
+# --------------------------------------------------------------------------------------
+# what `aggfly validate` prints (`cli/config.py:406-466` in the reference)
+# --------------------------------------------------------------------------------------
+def _is_remote(path) -> bool:
+    return isinstance(path, str) and "://" in path
+
+
+def check_paths(config: RunConfig) -> List[str]:
+    """Messages for local inputs that do not exist (remote URLs are never fetched)."""
+    import glob
+    import os
+    missing = []
+    if not _is_remote(config.regions_path) and not os.path.exists(config.regions_path):
+        missing.append(f"regions.path does not exist: {config.regions_path}")
+    missing += [f"dataset.path does not resolve: {p}" for p in config.resolved_paths()
+                if not _is_remote(p) and not glob.glob(p) and not os.path.exists(p)]
+    sec = config.secondary
+    if sec is not None and not _is_remote(sec.path) and not os.path.exists(sec.path):
+        missing.append(f"weights.secondary.path does not exist: {sec.path}")
+    if config.weights_table and not _is_remote(config.weights_table) and not os.path.exists(config.weights_table):
+        missing.append(f"weights.table does not exist: {config.weights_table}")
+    return missing
+
+
+def describe(config: RunConfig) -> str:
+    """The normalised plan of a config, one fact per line."""
+    def step(kind, params):
+        what = params.get("calc") or params.get("transform") or "?"
+        return f"{kind}:{what}" + (f"@{params['groupby']}" if params.get("groupby") else "")
+
+    rows = [("regions", f"{config.regions_path}  (id column: {config.regionid})"),
+            ("dataset", f"{config.dataset_path}  var={config.var}"),
+            ("", f"lon_is_360={config.lon_is_360} timecoord={config.timecoord} xycoords={list(config.xycoords)}")]
+    if config.reader_engine:
+        rows.append(("", f"reader engine: {config.reader_engine}"))
+    if config.storage_options:      # keys only: the values carry credentials
+        rows.append(("", "storage_options: {" + ", ".join(sorted(config.storage_options)) + "} (values hidden)"))
+    if config.preprocess:
+        rows.append(("", f"preprocess: {config.preprocess}"))
+    elif config.preprocess_from:
+        rows.append(("", f"preprocess_from: {config.preprocess_from}"))
+    if config.templated:
+        yrs = config.years or []
+        rows.append(("years", f"{yrs[0]}..{yrs[-1]} ({len(yrs)} files)" if yrs else "(none)"))
+    if config.secondary is not None:
+        rows.append(("weights", f"{config.secondary.type} secondary ({config.secondary.path})"))
+    else:
+        rows.append(("weights", "area-only"))
+    if config.weights_table:
+        rows.append(("", f"precomputed table: {config.weights_table}"))
+    rows += [("zero wt", config.zero_weight),
+             ("engine", f"{config.engine}   backend: {config.backend}"),
+             ("output", f"{config.output_path}  ({config.output_format})"),
+             ("variables", str(len(config.variables)))]
+    lines = ["Normalized plan"] + [(f"  {k:<10}: {v}" if k else f"              {v}") for k, v in rows]
+    lines += [f"    - {name}: " + " -> ".join(step(k, p) for k, p in steps) for name, steps in config.variables.items()]
+    return "\n".join(lines)

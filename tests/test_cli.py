@@ -92,7 +92,23 @@ def test_validate_command(tmp_path):
     bad = tmp_path / "bad.yaml"
     bad.write_text(yaml.safe_dump({"regions": {}}))
     r = CliRunner().invoke(cli, ["validate", str(bad)])
-    assert r.exit_code == 1
+    assert r.exit_code == 1 and "Config is invalid:" in r.output
+    # the reference's report (`cli/main.py:89-125`): normalised plan, unresolved local paths as warnings, --strict -> errors
+    r = CliRunner().invoke(cli, ["validate", str(good)])
+    assert "Normalized plan" in r.output and "Config OK." in r.output and "area-only" in r.output
+    assert "Warnings:" in r.output and "regions.path does not exist" in r.output and "dataset.path does not resolve" in r.output
+    r = CliRunner().invoke(cli, ["validate", str(good), "--strict"])
+    assert r.exit_code == 1 and "Errors:" in r.output and "Config OK." not in r.output
+    for name, steps in _minimal()["aggregate"]["variables"].items():
+        assert f"- {name}: " in CliRunner().invoke(cli, ["validate", str(good)]).output
+    # every flag of the reference's `run` exists (values checked by click before anything is read)
+    r = CliRunner().invoke(cli, ["run", "--help"])
+    for flag in ("-o, --output", "--engine", "--years", "--project-dir", "--backend", "--n-workers", "-v, --verbose"):
+        assert flag in r.output, flag
+    r = CliRunner().invoke(cli, ["weights", "--help"])
+    assert "--project-dir" in r.output and "--verbose" in r.output
+    r = CliRunner().invoke(cli, ["regions", "--help"])
+    assert "--rows" in r.output and "--uniqueness" in r.output
 
 
 def _write_run_inputs(tmp_path, years=(2000,)):
