@@ -19,6 +19,8 @@ into its GPU (`io.dataset_from_path(..., device=, time window)`) before the pane
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .timegroups import resample_groups
@@ -168,13 +170,55 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
     return agg._merge_regions(df, weights)
 
 
-def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto", group=None, **open_kwargs):
+def _step_bytes(path, var):
+    """Bytes one time step of ``var`` takes in HBM (full stored grid: a clipped read takes less), or None when
+    the container's shape cannot be told without reading it."""
+    import numpy as np
+    from . import io as afio
+    try:
+        if afio._looks_like_zarr(path):
+            za = afio.ZarrArray(os.path.join(path, var))
+            shape, dt = za.shape, np.dtype(za.dtype)
+        elif afio._is_hdf5(path):
+            from . import hdf5
+            with hdf5.H5File(path) as f:
+                shape, dt = f.datasets[var].shape, np.dtype(f.datasets[var].dtype)
+        else:
+            return None
+        item = dt.itemsize if dt.kind == "f" else 4           # packed integers are unpacked to float32 in HBM
+        return int(np.prod(shape[1:], dtype=np.int64)) * item
+    except Exception:
+        return None
+
+
+def plan_windows(bounds, p_lo, p_hi, step_bytes, budget_bytes):
+    """Cut the output periods ``[p_lo, p_hi)`` into consecutive runs whose time steps fit ``budget_bytes`` in HBM
+    (a run always holds at least one period).  -> [(q_lo, q_hi), ...]"""
+    if p_hi <= p_lo:
+        return []
+    if not step_bytes or not budget_bytes:
+        return [(p_lo, p_hi)]
+    runs, q = [], p_lo
+    while q < p_hi:
+        e = q + 1
+        while e < p_hi and (int(bounds[e + 1]) - int(bounds[q])) * step_bytes <= budget_bytes:
+            e += 1
+        runs.append((q, e))
+        q = e
+    return runs
+
+
+def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto", group=None, max_window_bytes=None,
+                            **open_kwargs):
     """Time-sharded `aggregate_dataset` straight from a store on disk.
 
     ``weights_of(dataset) -> GridWeights`` builds the weights for the rank's (possibly region-clipped) dataset
     (e.g. ``lambda ds: af.weights_from_objects(ds, regions, table=table)``).  Every rank reads the store's
     time coordinate, takes the output periods `split_even` gives it, streams only those steps into HBM, reduces
     them, and one all_gather assembles the region x period panel; the frame is returned on every rank.
+    A rank's share that does not fit in HBM is taken in consecutive windows of whole output periods
+    (``max_window_bytes``; default: 60 % of the free HBM), each streamed, reduced and released before the next:
+    a store of any length runs on one GPU.
     ``open_kwargs`` go to `dataset_from_path` (``xycoords``, ``lon_is_360``, ``georegions``, ``preprocess`` ...)."""
     import torch
     from . import aggregate as agg, io as afio
@@ -186,16 +230,27 @@ def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto
     P = len(labels)
     counts = [split_even(P, r, ws)[1] - split_even(P, r, ws)[0] for r in range(ws)]
     p_lo, p_hi = split_even(P, rank, ws)
-    k_lo, k_hi = int(bounds[p_lo]), int(bounds[p_hi])
     names = agg._lower_all(aggregator_dict)[3]
-    # an empty window still opens the store (coordinates, grid) so that every rank builds the same weights
-    local = afio.dataset_from_path(path, var, device="cuda", time_window=(k_lo, max(k_hi, k_lo)), **open_kwargs)
-    weights = weights_of(local)
-    if k_hi > k_lo:
-        res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
+    if max_window_bytes is None and torch.cuda.is_available():
+        max_window_bytes = int(0.6 * torch.cuda.mem_get_info()[0])
+    windows = plan_windows(bounds, p_lo, p_hi, _step_bytes(path, var), max_window_bytes)
+    weights, parts, region_ids = None, [], None
+    # an empty share still opens the store (coordinates, grid) so that every rank builds the same weights
+    for q_lo, q_hi in (windows or [(p_lo, p_lo)]):
+        k_lo, k_hi = int(bounds[q_lo]), int(bounds[q_hi])
+        local = afio.dataset_from_path(path, var, device="cuda", time_window=(k_lo, k_hi), **open_kwargs)
+        if weights is None:
+            weights = weights_of(local)
+        if k_hi > k_lo:
+            res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
+            parts.append(res)
+        else:
+            from . import engine as eng
+            _, region_ids = eng.get_csr(weights, local)
+        del local                                                      # the window's cube is released before the next is read
+    if parts:
+        res = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
     else:
-        from . import engine as eng
-        _, region_ids = eng.get_csr(weights, local)
         res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
     full = gather_panel(res, counts, group)
     df = agg._assemble_frame(full, names, region_ids, labels, weights)

@@ -108,3 +108,20 @@ def test_shard_maths_single_process():
     spans = [D.time_shard_bounds(t, "YE", r, 3) for r in range(3)]
     assert spans[0][0] == 0 and spans[-1][1] == len(t) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert D.world() == (0, 1)
+
+
+def test_plan_windows_cuts_on_output_periods():
+    """`distributed.plan_windows`: a rank's output periods are taken in consecutive runs whose time steps fit the
+    HBM budget; a period larger than the budget still gets a window of its own."""
+    import numpy as np
+    from aggfly_amd.distributed import plan_windows
+    b = np.array([0, 10, 20, 30, 40, 55])
+    assert plan_windows(b, 0, 5, 8, 160) == [(0, 2), (2, 4), (4, 5)]
+    assert plan_windows(b, 0, 5, 8, 1) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+    assert plan_windows(b, 1, 4, 8, 10 ** 9) == [(1, 4)]
+    assert plan_windows(b, 2, 2, 8, 100) == []
+    assert plan_windows(b, 0, 5, None, 100) == [(0, 5)]
+    for budget in (1, 80, 81, 239, 240, 10 ** 6):
+        runs = plan_windows(b, 0, 5, 8, budget)
+        assert runs[0][0] == 0 and runs[-1][1] == 5 and all(x[1] == y[0] for x, y in zip(runs, runs[1:]))
+        assert all((b[hi] - b[lo]) * 8 <= budget or hi == lo + 1 for lo, hi in runs)

@@ -88,6 +88,19 @@ if dist.is_initialized():
     codec.decode_ranges = lambda kind, locs, outs, threads=8: seen.append(len(locs)) or real(kind, locs, outs, threads)
     df = D.aggregate_store_sharded(weights_of, store, "t2m", spec, lon_is_360=True, preprocess=lambda x: x - 273.15)
     assert 0 < sum(seen) < 20, seen          # each rank decoded about half of the store's 28 chunks, not all of them
+elif os.environ.get("WINDOW_BYTES"):
+    # one GPU, a budget of a few output periods per window: the store goes through HBM window by window
+    from aggfly_amd import io as afio
+    opened = []
+    real_open = afio.dataset_from_path
+    def spy(*a, **k):
+        opened.append(k.get("time_window"))
+        return real_open(*a, **k)
+    afio.dataset_from_path = spy
+    df = D.aggregate_store_sharded(weights_of, store, "t2m", spec, lon_is_360=True, preprocess=lambda x: x - 273.15,
+                                   max_window_bytes=int(os.environ["WINDOW_BYTES"]))
+    assert len(opened) >= 4 and opened[0][0] == 0 and opened[-1][1] == 24 * 400, opened
+    assert all(a[1] == b[0] for a, b in zip(opened, opened[1:])), opened
 else:
     ds = af.dataset_from_path(store, "t2m", lon_is_360=True, preprocess=lambda x: x - 273.15, device="cuda")
     df = af.aggregate_dataset(dataset=ds, weights=weights_of(ds), aggregator_dict=spec)
@@ -124,3 +137,9 @@ def test_store_sharded_streams_each_ranks_window(torch_cuda, tmp_path):
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, check_exact=True)
+    # a store longer than the HBM budget: windows of whole output periods (here 4 months of hourly steps at most)
+    win = str(tmp_path / "win.csv")
+    r = subprocess.run([sys.executable, str(script), store, win], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WINDOW_BYTES=str(4 * 31 * 24 * ny * nx * 4)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    pd.testing.assert_frame_equal(a, pd.read_csv(win), check_exact=True)
