@@ -5,6 +5,9 @@ The reference loops the years sequentially in one process.  Here the loop is the
 time-shard scheduler: launched under ``torch.distributed.run`` each rank takes every
 ``world``-th path (a year is an outer-period-aligned time shard), reduces it on its own GPU,
 and the per-year region x period panels are all-gathered (RCCL over xGMI) to rank 0.
+A config with ONE un-templated store is cut along time inside the store instead (`run_store`):
+ranks take runs of output periods and stream only their own chunks; a share beyond the HBM
+budget (``AGGFLY_HIP_WINDOW_BYTES``, default 60 % of the free HBM) goes through in windows.
 """
 from __future__ import annotations
 
@@ -24,6 +27,60 @@ from . import preprocess as preprocess_mod
 
 def build_regions(config):
     return georegions_from_path(config.regions_path, config.regionid, config.region_list)
+
+
+def _open_kwargs(config, georegions):
+    """What every `dataset_from_path` call of a run shares."""
+    kwargs = {}
+    if config.chunks is not None:
+        kwargs["chunks"] = config.chunks
+    if config.storage_options is not None:
+        kwargs["storage_options"] = config.storage_options
+    if config.reader_engine is not None:
+        kwargs["engine"] = config.reader_engine
+    clip = georegions if config.clip_to_regions and _has_bounds(georegions) else None
+    kwargs.update(xycoords=config.xycoords, timecoord=config.timecoord, georegions=clip, lon_is_360=config.lon_is_360,
+                  preprocess=preprocess_mod.resolve_from_config(config), name=config.var)
+    return kwargs
+
+
+def store_route_ok(config, paths) -> bool:
+    """One un-templated Zarr store / netCDF-4 file whose outputs share a nestable output frequency can be cut along
+    time INSIDE the store: ranks (and, beyond the HBM budget, windows) take runs of output periods
+    (`distributed.aggregate_store_sharded`)."""
+    from .. import hip, io as afio
+    if len(paths) != 1 or config.time_sel is not None or hip.device_count() == 0:
+        return False
+    p = paths[0]
+    if not isinstance(p, str) or any(ch in p for ch in "*?[") or "://" in p:
+        return False
+    if not (afio._looks_like_zarr(p) or (os.path.isfile(p) and afio._is_hdf5(p))):
+        return False
+    try:
+        D.output_freq(config.to_aggregator_dict())
+    except ValueError:
+        return False
+    return True
+
+
+def run_store(config, path, log=lambda m: None):
+    """The single-store route: no sample load; every rank streams only its own output periods."""
+    log(f"Loading regions: {config.regions_path}")
+    georegions = build_regions(config)
+    tpath = find_weights_table(config)
+    log(f"Loading weights table: {tpath}")
+    table = _read_table(tpath)
+
+    def weights_of(ds):
+        w = af.weights_from_objects(ds, georegions, table=table, project_dir=config.project_dir, zero_weight=config.zero_weight)
+        w.calculate_weights()
+        return w
+
+    rank, world = D.world()
+    log(f"Aggregating {path}: output periods split over {world} rank(s), streamed through HBM in windows")
+    budget = os.environ.get("AGGFLY_HIP_WINDOW_BYTES")
+    return D.aggregate_store_sharded(weights_of, path, config.var, config.to_aggregator_dict(), engine=config.engine,
+                                     max_window_bytes=int(budget) if budget else None, **_open_kwargs(config, georegions))
 
 
 def load_dataset(config, path, georegions):
@@ -85,8 +142,10 @@ def compute_weights(config, log=lambda m: None):
 
 def run_pipeline(config, log=lambda m: None):
     """-> the panel DataFrame (on every rank when distributed)."""
-    weights, georegions, sample = compute_weights(config, log)
     paths = config.resolved_paths()
+    if store_route_ok(config, paths):
+        return run_store(config, paths[0], log)
+    weights, georegions, sample = compute_weights(config, log)
     aggregator_dict = config.to_aggregator_dict()
     rank, world = D.world()
     mine = list(range(len(paths)))[rank::world]

@@ -3,6 +3,8 @@ CLI == hand-written-API parity of `aggfly/tests/test_cli.py:426-458` (GPU), and 
 world_size-2 gloo gather of per-year panels."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pandas as pd
@@ -189,6 +191,45 @@ def test_run_matches_direct_api(torch_cuda, tmp_path):
     want = ra.aggregate_dataset(ow, ra.ODataset(ds.cube(), ds.time, ds.latitude, ds.longitude, False), engine="numba",
                                 **cfg.parse_config(yaml.safe_load(cpath.read_text())).to_aggregator_dict())
     np.testing.assert_allclose(actual[["tavg_1", "tavg_2"]].values[:1], want[["tavg_1", "tavg_2"]].values, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_run_single_store_is_cut_inside_the_store(torch_cuda, tmp_path):
+    """A config with ONE un-templated store takes the single-store route: ranks (and HBM-budget windows) take runs of
+    output periods of the same store.  One process, one process under a tiny HBM budget, and two ranks all write the
+    frame the hand-written API call gives."""
+    _, rpath, wpath = _write_run_inputs(tmp_path)
+    lon, lat = np.arange(-100.0, -60.0, 5.0), np.arange(20.0, 60.0, 5.0)
+    time = pd.date_range("2001-11-15", periods=300, freq="12h")                     # Nov 2001 .. Apr 2002: 6 monthly periods
+    arr = np.random.default_rng(11).normal(20, 15, (len(time), len(lat), len(lon))) + 273.15
+    arr[37, 3, 4] = np.nan
+    store = str(tmp_path / "long.zarr")
+    af.dataset_to_zarr(af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}),
+                                  lon_is_360=False), store, var="t2m", chunks={"time": 40, "latitude": 8, "longitude": 8})
+    gr = af.weights.georegions_from_path(rpath, "geoid")
+    ds = af.dataset_from_path(store, var="t2m", lon_is_360=False, georegions=gr, name="t2m", preprocess=lambda x: x - 273.15)
+    w = af.weights_from_objects(ds, gr, table=pd.read_parquet(wpath))
+    expected = af.aggregate_dataset(dataset=ds, weights=w, tavg=[("aggregate", {"calc": "mean", "groupby": "date"}),
+                                                                 ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                                                                 ("aggregate", {"calc": "sum", "groupby": "month"})])
+    assert len(expected) == 6                                                        # the NaN cell only leaves its month's average
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = [sys.executable, "-m", "aggfly_amd.cli.main"]
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "aggfly_amd.cli.main"]
+    step = 8 * 8 * 8                                                                 # bytes of one stored time step
+    for tag, cmd, extra in (("one", one, {}), ("windows", one, {"AGGFLY_HIP_WINDOW_BYTES": str(70 * step)}),
+                            ("ranks", two, {"AGGFLY_DIST_BACKEND": "gloo"})):
+        out = str(tmp_path / f"panel_{tag}.csv")
+        cpath = tmp_path / f"config_{tag}.yaml"
+        cpath.write_text(yaml.safe_dump(_run_config(store, rpath, wpath, out)))
+        r = subprocess.run(cmd + ["run", str(cpath), "-v"], capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "streamed through HBM in windows" in r.stdout, r.stdout
+        got = pd.read_csv(out, parse_dates=["time"])
+        assert list(got.columns) == list(expected.columns) and got["geoid"].tolist() == expected["geoid"].tolist(), tag
+        assert got["time"].tolist() == pd.DatetimeIndex(expected["time"]).tolist(), tag
+        np.testing.assert_allclose(got[["tavg_1", "tavg_2"]].values, expected[["tavg_1", "tavg_2"]].values, rtol=1e-13, err_msg=tag)
 
 
 def _free_port():
