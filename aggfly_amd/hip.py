@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaggfly_hip.so")
+LIB_PATH = os.environ.get("AGGFLY_HIP_LIB") or os.path.join(_HERE, "libaggfly_hip.so")     # override: A/B of two builds
 
 # codes (include/aggfly_hip.h)
 F32, F64 = 0, 1
