@@ -12,7 +12,8 @@ fp64, synthetic), ~3.1k regions with area weights, and the fused plan
 
 A "step" is one whole pass of the hot path over one resident year: fused temporal kernel,
 slot merge + shared validity, CSR weighted sums, divide (and, for N > 1, the RCCL
-all-gather of the region x period panel).  Inputs are resident in HBM before the timed
+all-gather of the region x period panel, which runs on the collective's stream beside the
+next step's kernels; every gather completes inside the timed region).  Inputs are resident in HBM before the timed
 region.  With N > 1 every rank owns a different year (time-axis sharding on outer-period
 boundaries, weak scaling): value = N * T * cells / max-over-ranks time.
 
@@ -214,29 +215,60 @@ def main():
     out = {"num": torch.empty((K, R, 1), dtype=torch.float64, device="cuda"),
            "den": torch.empty((R, 1), dtype=torch.float64, device="cuda"),
            "res": torch.empty((K, R, 1), dtype=torch.float64, device="cuda")}
-    gathered = [torch.empty_like(out["res"]) for _ in range(world)] if world > 1 else None
+    # N > 1: the region x period panel of every step is all-gathered (RCCL over xGMI).  Two result buffers, so that
+    # the gather of step i (on the collective's own stream) overlaps the kernels of step i + 1; a buffer is reused
+    # only after its gather has finished, and every gather is waited for inside the timed region.
+    pipelined = world > 1 and os.environ.get("AGGFLY_BENCH_PIPELINE", "1") != "0"
+    outs = [out] + ([{k: torch.empty_like(v) for k, v in out.items()}] if pipelined else [])
+    use_flat = world > 1 and dist.get_backend() == "nccl"
+    if use_flat:        # one RCCL call straight into [world, K, R, 1]
+        gathered = [torch.empty((world,) + tuple(out["res"].shape), dtype=torch.float64, device="cuda") for _ in outs]
+    else:
+        gathered = [[torch.empty_like(out["res"]) for _ in range(world)] for _ in outs] if world > 1 else None
+    pending = [None] * len(outs)
 
-    def step():
-        plan.run(cube, csr, out=out)
+    def step(i):
+        b = i % len(outs)
+        if pending[b] is not None:
+            pending[b].wait()                                 # the gather that last read this buffer
+            pending[b] = None
+        plan.run(cube, csr, out=outs[b])
         if world > 1:
-            dist.all_gather(gathered, out["res"])            # RCCL over xGMI: the region x period panel
+            if use_flat:
+                w = dist.all_gather_into_tensor(gathered[b], outs[b]["res"], async_op=pipelined)
+            else:
+                w = dist.all_gather(gathered[b], outs[b]["res"], async_op=pipelined)
+            pending[b] = w if pipelined else None
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for b in range(len(outs)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     plan.profile_begin(args.steps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms = plan.profile_end()
+    if world > 1:       # outside the timed region: the gathered panel really holds this rank's result of the last step
+        b = (args.steps - 1) % len(outs)
+        mine = gathered[b][rank]
+        if not torch.equal(torch.nan_to_num(mine), torch.nan_to_num(outs[b]["res"])):
+            raise SystemExit(f"rank {rank}: gathered panel differs from the local result")
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -262,7 +294,8 @@ def main():
                                    f"{ny}x{nx} cells, {R} regions area weights, fused dd[10,30]@date->sum@year + "
                                    "mean@date->power[1..4]->sum@year, %s, K=5" % ("fp64" if args.dtype == "f64" else "fp32 storage / fp64 accumulation"),
                        "T": T, "cells": C, "regions": R, "columns": K, "nnz": int(csr.nnz),
-                       "sharding": "time axis, one year per GPU; RCCL all-gather of the panel" if world > 1 else "single GPU",
+                       "sharding": ("time axis, one year per GPU; RCCL all-gather of the panel"
+                                    + (", overlapped with the next step's kernels" if pipelined else "")) if world > 1 else "single GPU",
                        "plan": plan.describe()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
