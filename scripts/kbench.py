@@ -30,15 +30,25 @@ def main():
     ap.add_argument("--spd", type=int, default=24, help="steps per inner group (24 hourly, 1 daily, 2 tmin/tmax)")
     ap.add_argument("--periods", type=int, default=1, help="outer periods (years)")
     ap.add_argument("--regions", type=int, default=3100)
+    ap.add_argument("--data", default="iid", choices=["iid", "era5"],
+                    help="iid: 15 + N(0, 12) per element (every wave meets every branch); era5: seasonal + diurnal cycle + N(0, 3), "
+                         "the synthetic field of SURVEY.md 8(d) (neighbouring cells and days resemble each other, as in real data)")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     C = a.ny * a.nx
     g = torch.Generator(device="cuda").manual_seed(1)
     cube = torch.empty((a.T, a.ny, a.nx), dtype=dt, device="cuda")
     # filled on device in slabs: 15 + N(0, 12)
+    lat = torch.linspace(0.6, 1.4, a.ny, device="cuda", dtype=torch.float32)[None, :, None]
     for k0 in range(0, a.T, 512):
         k1 = min(a.T, k0 + 512)
-        cube[k0:k1] = (15 + 12 * torch.randn((k1 - k0, a.ny, a.nx), generator=g, device="cuda", dtype=torch.float32)).to(dt)
+        noise = torch.randn((k1 - k0, a.ny, a.nx), generator=g, device="cuda", dtype=torch.float32)
+        if a.data == "iid":
+            cube[k0:k1] = (15 + 12 * noise).to(dt)
+        else:
+            k = torch.arange(k0, k1, device="cuda", dtype=torch.float32)
+            base = 15.0 + 12.0 * torch.sin(2 * np.pi * torch.floor(k / a.spd) / 365.0) + 6.0 * torch.sin(2 * np.pi * (k % a.spd) / a.spd - np.pi / 2)
+            cube[k0:k1] = (base[:, None, None] * lat + 3.0 * noise).to(dt)
     ib = synth.hourly_bounds(a.T, a.spd)
     G1 = len(ib) - 1
     ob = np.round(np.linspace(0, G1, a.periods + 1)).astype(np.int64)
@@ -92,7 +102,7 @@ def main():
                      "cell_steps_per_s": a.T * C / (float(np.median(tot[t])) / 1e3)})
         print(json.dumps(rows[-1]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/kbench_{a.plan}_{a.dtype}_{a.ny}x{a.nx}.json", "w") as f:
+    with open(f"gpurun_out/kbench_{a.plan}_{a.dtype}_{a.ny}x{a.nx}{'' if a.data == 'iid' else '_' + a.data}.json", "w") as f:
         json.dump({"args": vars(a), "bytes": bytes_alg, "rows": rows}, f, indent=1)
 
 
