@@ -416,6 +416,8 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
     and uploaded while the next slab decodes.  Returns (tensor, source)."""
     if len(za.shape) != 3:
         raise ValueError("zarr_to_device expects a (time, y, x) array")
+    if os.environ.get("AGGFLY_HIP_SLAB_MB"):                       # tuning knob (scripts/e2e_bench.py sweeps it)
+        slab_bytes = int(float(os.environ["AGGFLY_HIP_SLAB_MB"]) * (1 << 20))
     sf, ao = za.attrs.get("scale_factor"), za.attrs.get("add_offset")
     packed = za.dtype.kind in "iu" or sf is not None or ao is not None
     if za.dtype.kind not in "fiu":
