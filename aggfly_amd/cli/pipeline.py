@@ -77,6 +77,18 @@ def run_store(config, path, log=lambda m: None):
         return w
 
     rank, world = D.world()
+    if world > 1:
+        # fewer output periods than ranks (one year, annual output): shard the cells instead — latitude bands, one all_reduce
+        from aggfly_amd import io as afio
+        from aggfly_amd.timegroups import resample_groups
+        aggd = config.to_aggregator_dict()
+        P = len(resample_groups(afio.read_time_coordinate(path, config.var, config.timecoord), D.output_freq(aggd))[1])
+        if P < world:
+            try:
+                log(f"Aggregating {path}: {P} output period(s) < {world} ranks -> latitude bands, one all_reduce")
+                return D.aggregate_store_cells(weights_of, path, config.var, aggd, **_open_kwargs(config, georegions))
+            except ValueError as e:           # staged specs, mixed frequencies, fewer rows than ranks: time route
+                log(f"cell sharding not applicable ({e}); falling back to time sharding")
     log(f"Aggregating {path}: output periods split over {world} rank(s), streamed through HBM in windows")
     budget = os.environ.get("AGGFLY_HIP_WINDOW_BYTES")
     return D.aggregate_store_sharded(weights_of, path, config.var, config.to_aggregator_dict(), engine=config.engine,

@@ -12,7 +12,7 @@ shards here is the path itself:
   ``all_reduce(SUM)`` of ``(K+1)·R·P`` doubles finishes the job, then ``res = num / den``.
 
 The exchange helpers (`gather_panel`, `reduce_num_den`) work on any backend and are covered by
-world_size-2 gloo tests; only `aggregate_dataset_sharded` / `aggregate_store_sharded` touch the GPU.
+world_size-2 gloo tests; only `aggregate_dataset_sharded` / `aggregate_store_sharded` / `aggregate_store_cells` touch the GPU.
 `aggregate_store_sharded` is the north_star's "zarr chunks streamed per GPU": every rank opens the same
 store, works out its own run of output periods from the time coordinate, and streams ONLY those time steps
 into its GPU (`io.dataset_from_path(..., device=, time window)`) before the panel is gathered.
@@ -116,6 +116,33 @@ def band_csr_triplets(rows, cols, w, ny, nx, y0, y1):
     return rows[keep], cols[keep] - y0 * nx, w[keep]
 
 
+def _cells_band_panel(weights, grid_ds, cube_band, y0, y1, tindex, aggregator_dict, group=None):
+    """One rank's latitude band ``[y0, y1)`` of a cell-sharded job: the band's cube (time, y1 - y0, nx) is reduced
+    against the weights restricted to the band, and ONE all_reduce(SUM) of the numerators and denominators
+    finishes the panel (`reduce_num_den`).  ``grid_ds`` carries the full grid (its longitude order is folded into
+    the CSR columns as in `engine.get_csr`).  -> (res[K, R, P] on every rank, names, region_ids, labels)"""
+    from . import aggregate as agg, engine as eng, hip
+    ny, nx = len(grid_ds.latitude), len(grid_ds.longitude)
+    _, fused_cols, staged, names = agg._lower_all(aggregator_dict)
+    if staged:
+        raise ValueError("cell sharding supports fused (two-level) specs only")
+    groups = eng.plan_groups(tindex, fused_cols)
+    if len(groups) != 1:
+        raise ValueError("cell sharding needs all outputs to share their group frequencies")
+    cols, ib, ob, labels = groups[0]
+    wrows, wcols, wv, region_ids = eng.weight_triplets(weights.weights, np.asarray(weights.grid.cell_id))
+    lon_order, _ = grid_ds.lon_order_to_180()
+    iy, ixs = np.divmod(wcols, nx)
+    wcols_mem = iy * nx + lon_order[ixs]
+    br, bc, bw = band_csr_triplets(wrows, wcols_mem, wv, ny, nx, y0, y1)
+    csr = hip.CSR(br, bc, bw, len(region_ids), (y1 - y0) * nx)
+    pr = eng.run_fused_pass(cube_band, cols, ib, ob, csr=csr, want_cells=False)
+    if len(pr) != 1:
+        raise hip.HipUnsupported("cell sharding needs the spec to fit one fused pass")
+    _, _, full = reduce_num_den(pr[0].panel["num"], pr[0].panel["den"], group)
+    return full, names, region_ids, labels
+
+
 def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engine="auto", shard="time",
                               group=None, **kwargs):
     """`aggregate_dataset` across the GPUs of the process group.  Every rank passes the same
@@ -144,26 +171,10 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
             res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
         full = gather_panel(res, counts, group)
     elif shard == "cells":
-        ny, nx = len(dataset.latitude), len(dataset.longitude)
+        ny = len(dataset.latitude)
         y0, y1 = split_even(ny, rank, ws)
-        _, fused_cols, staged, names = agg._lower_all(aggregator_dict)
-        if staged:
-            raise ValueError("cell sharding supports fused (two-level) specs only")
-        groups = eng.plan_groups(tindex, fused_cols)
-        if len(groups) != 1:
-            raise ValueError("cell sharding needs all outputs to share their group frequencies")
-        cols, ib, ob, labels = groups[0]
-        wrows, wcols, wv, region_ids = eng.weight_triplets(weights.weights, np.asarray(weights.grid.cell_id))
-        lon_order, _ = dataset.lon_order_to_180()
-        iy, ixs = np.divmod(wcols, nx)
-        wcols_mem = iy * nx + lon_order[ixs]
-        br, bc, bw = band_csr_triplets(wrows, wcols_mem, wv, ny, nx, y0, y1)
         cube = eng.device_cube(dataset)[:, y0:y1, :].contiguous()
-        csr = hip.CSR(br, bc, bw, len(region_ids), (y1 - y0) * nx)
-        pr = eng.run_fused_pass(cube, cols, ib, ob, csr=csr, want_cells=False)
-        if len(pr) != 1:
-            raise hip.HipUnsupported("cell sharding needs the spec to fit one fused pass")
-        _, _, full = reduce_num_den(pr[0].panel["num"], pr[0].panel["den"], group)
+        full, names, region_ids, labels = _cells_band_panel(weights, dataset, cube, y0, y1, tindex, aggregator_dict, group)
     else:
         raise ValueError("shard must be 'time' or 'cells'")
     df = agg._assemble_frame(full, names, region_ids, labels, weights)
@@ -206,6 +217,27 @@ def plan_windows(bounds, p_lo, p_hi, step_bytes, budget_bytes):
         runs.append((q, e))
         q = e
     return runs
+
+
+def aggregate_store_cells(weights_of, path, var, aggregator_dict, group=None, **open_kwargs):
+    """Cell-sharded `aggregate_dataset` straight from a store: for jobs with fewer output periods than GPUs (one
+    annual period: BASELINE configs[0], [1], [4]).  Every rank opens the store's coordinates (no data), takes a band of
+    latitude rows, streams ONLY the chunks that touch its band into HBM, reduces it against the weights of the band,
+    and one all_reduce(SUM) of ``(K+1) x R x P`` doubles assembles the panel on every rank."""
+    from . import aggregate as agg, engine as eng, io as afio
+    rank, ws = world(group)
+    head = afio.dataset_from_path(path, var, device="cuda", time_window=(0, 0), **open_kwargs)      # grid and coordinates only
+    weights = weights_of(head)
+    if len(head.latitude) < ws:
+        raise ValueError(f"{ws} ranks for {len(head.latitude)} latitude rows: use fewer ranks or time sharding")
+    y0, y1 = split_even(len(head.latitude), rank, ws)
+    band = afio.dataset_from_path(path, var, device="cuda", lat_window=(y0, y1), **open_kwargs)
+    if len(band.latitude) != y1 - y0 or len(band.longitude) != len(head.longitude):
+        raise RuntimeError("the band read does not match the grid the weights were laid on")
+    tindex = band.da.coords["time"]
+    full, names, region_ids, labels = _cells_band_panel(weights, head, eng.device_cube(band), y0, y1, tindex, aggregator_dict, group)
+    df = agg._assemble_frame(full, names, region_ids, labels, weights)
+    return agg._merge_regions(df, weights)
 
 
 def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto", group=None, max_window_bytes=None,

@@ -33,7 +33,7 @@ import pandas as pd
 
 from .cfcalendar import STANDARD_CALENDARS, CFTimeIndex, decode_cf_time
 from .dataarray import DataArray
-from .dataset import Dataset
+from .dataset import Dataset, Grid
 
 _ZARR_MARKERS = ("zarr.json", ".zmetadata", ".zgroup", ".zarray")
 _NON_ZARR_SUFFIXES = (".nc", ".nc4", ".netcdf", ".cdf", ".h5", ".hdf5", ".grib", ".grb", ".grib2", ".tif", ".tiff")
@@ -931,6 +931,18 @@ def _clip_box(dims, coords, xycoords, georegions, lon_is_360):
     return (ry + rx) if dims[1] == yname else (rx + ry)
 
 
+def _band_of_box(dims, shape, xycoords, box, lat_window):
+    """The stored-axes box (a0, a1, b0, b1) of latitude rows ``lat_window`` inside ``box`` (None = the whole grid)."""
+    full = tuple(box) if box is not None else (0, int(shape[1]), 0, int(shape[2]))
+    j0, j1 = int(lat_window[0]), int(lat_window[1])
+    out = list(full)
+    k = 0 if dims[1] == xycoords[1] else 2                          # where the latitude range sits in the box
+    if not (0 <= j0 <= j1 <= full[k + 1] - full[k]):
+        raise ValueError(f"lat_window {lat_window} outside the {full[k + 1] - full[k]} latitude rows of the grid")
+    out[k], out[k + 1] = full[k] + j0, full[k] + j1
+    return tuple(out)
+
+
 def _hdf5_to_device(path, var, xycoords, timecoord, time_sel, georegions, lon_is_360, device, time_window=None):
     """A chunked netCDF-4 variable through the streaming route (native inflate + unshuffle, GPU-side placement);
     None when the variable does not qualify (contiguous, not time-leading, ...): the host route then reads it."""
@@ -1005,13 +1017,16 @@ def _time_window(tindex, time_sel):
 
 def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="time", time_sel=None,
                       georegions=None, lon_is_360=True, time_fix=False, preprocess=None, name=None,
-                      chunks=None, preprocess_at_load=False, parallel=True, device=None, time_window=None, **kwargs) -> Dataset:
+                      chunks=None, preprocess_at_load=False, parallel=True, device=None, time_window=None, lat_window=None,
+                      **kwargs) -> Dataset:
     """`dataset_from_path` (`dataset.py:636-740`), same signature.  ``chunks`` / ``parallel``
     are accepted and ignored (there is no dask graph); a list / glob of paths is concatenated
     along time like ``open_mfdataset``.  ``device="cuda"`` (extension) streams a single float
     Zarr array straight into HBM (``zarr_to_device``) and applies ``preprocess`` there; ``time_window=(k0, k1)``
     (extension, streaming route only) restricts the read to those time steps — what a rank of a time-sharded
-    job asks for (`distributed.aggregate_store_sharded`)."""
+    job asks for (`distributed.aggregate_store_sharded`); ``lat_window=(j0, j1)`` (extension) keeps rows ``j0..j1`` of the
+    latitude axis AFTER the clip to the regions' extent — the band of a cell-sharded job
+    (`distributed.aggregate_store_cells`); on the streaming route only the chunks that touch the band are read."""
     import glob
     if isinstance(path, str) and "://" in path:
         raise ImportError(f"remote stores ({path.split('://')[0]}://) need fsspec backends that are not available here")
@@ -1044,6 +1059,10 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             box = None
             if georegions is not None and len(za.dims) == 3:
                 box = _clip_box(za.dims, coords, xycoords, georegions, lon_is_360)
+                if box is None and lat_window is not None:
+                    raise ValueError("lat_window on a non-contiguous clip goes through the host route")
+            if lat_window is not None:
+                box = _band_of_box(za.dims, za.shape, xycoords, box, lat_window)
             data, za = zarr_to_device(path1, var, device=device, t_range=window, yx_box=box)
             if window is not None:
                 coords[timecoord] = coords[timecoord][window[0]:window[1]]
@@ -1072,9 +1091,10 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
             data = None
         if data is not None:
             da = DataArray(data, za.dims, coords, name=var, attrs=za.attrs)
+            # a band was cut out of the already clipped box: the clip is not repeated on the band's own grid
             return Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
-                           preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
-    if device is not None and len(paths) == 1 and engine in (None, "netcdf4", "h5netcdf") and _is_hdf5(paths[0]):
+                           preprocess=preprocess, georegions=None if lat_window is not None else georegions, time_fix=time_fix, name=name)
+    if device is not None and lat_window is None and len(paths) == 1 and engine in (None, "netcdf4", "h5netcdf") and _is_hdf5(paths[0]):
         got = _hdf5_to_device(paths[0], var, xycoords, timecoord, time_sel, georegions, lon_is_360, device, time_window)
         if got is not None:
             data, src, coords = got
@@ -1115,4 +1135,7 @@ def dataset_from_path(path, var, xycoords=("longitude", "latitude"), timecoord="
         da = da.isel(**{timecoord: slice(int(time_window[0]), int(time_window[1]))})
     ds = Dataset(da, xycoords=xycoords, timecoord=timecoord, time_sel=time_sel, lon_is_360=lon_is_360,
                  preprocess=preprocess, georegions=georegions, time_fix=time_fix, name=name)
+    if lat_window is not None:                                      # the streaming route was not taken: cut on the host
+        ds.da = ds.da.isel(latitude=slice(int(lat_window[0]), int(lat_window[1])))
+        ds.grid = Grid(ds.longitude, ds.latitude, ds.name, ds.lon_is_360)
     return ds.to_device(device) if device is not None else ds      # containers without a streaming route: one upload

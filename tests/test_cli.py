@@ -230,6 +230,25 @@ def test_run_single_store_is_cut_inside_the_store(torch_cuda, tmp_path):
         assert list(got.columns) == list(expected.columns) and got["geoid"].tolist() == expected["geoid"].tolist(), tag
         assert got["time"].tolist() == pd.DatetimeIndex(expected["time"]).tolist(), tag
         np.testing.assert_allclose(got[["tavg_1", "tavg_2"]].values, expected[["tavg_1", "tavg_2"]].values, rtol=1e-13, err_msg=tag)
+    # ONE output period (a single year, annual sums) and two ranks: the cells are sharded instead (latitude bands, one all_reduce)
+    short = str(tmp_path / "one_year.zarr")
+    sel = slice(100, 300)                                                            # all of it inside 2002
+    af.dataset_to_zarr(af.Dataset(af.DataArray(arr[sel], ["time", "latitude", "longitude"], {"time": time[sel], "latitude": lat, "longitude": lon}),
+                                  lon_is_360=False), short, var="t2m", chunks={"time": 200, "latitude": 4, "longitude": 4})
+    annual = {"engine": "auto", "variables": {"tavg": [["aggregate", {"calc": "mean", "groupby": "date"}],
+                                                       ["transform", {"transform": "power", "exp": [1, 2]}],
+                                                       ["aggregate", {"calc": "sum", "groupby": "year"}]]}}
+    outs = {}
+    for tag, cmd, extra in (("y1", one, {}), ("y2", two[:8] + [str(_free_port())] + two[9:], {"AGGFLY_DIST_BACKEND": "gloo"})):
+        out = str(tmp_path / f"panel_{tag}.csv")
+        cpath = tmp_path / f"config_{tag}.yaml"
+        cpath.write_text(yaml.safe_dump(_run_config(short, rpath, wpath, out, aggregate=annual)))
+        r = subprocess.run(cmd + ["run", str(cpath), "-v"], capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("latitude bands" in r.stdout) == (tag == "y2"), r.stdout
+        outs[tag] = pd.read_csv(out)
+    assert len(outs["y1"]) == 1
+    pd.testing.assert_frame_equal(outs["y1"], outs["y2"], rtol=1e-12, atol=0)
 
 
 def _free_port():

@@ -81,7 +81,15 @@ spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 3
             t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
                ("aggregate", {"calc": "sum", "groupby": "month"})])
 weights_of = lambda ds: af.weights_from_objects(ds, gr, table=tab)
-if dist.is_initialized():
+if dist.is_initialized() and os.environ.get("SHARD") == "cells":
+    # latitude bands: each rank decodes only the chunks that touch its band, one all_reduce finishes the panel
+    from aggfly_amd import codec
+    seen = []
+    real = codec.decode_ranges
+    codec.decode_ranges = lambda kind, locs, outs, threads=8: seen.append(len(locs)) or real(kind, locs, outs, threads)
+    df = D.aggregate_store_cells(weights_of, store, "t2m", spec, lon_is_360=True, preprocess=lambda x: x - 273.15)
+    assert 0 < sum(seen) <= int(os.environ["CHUNKS_PER_RANK"]), seen
+elif dist.is_initialized():
     from aggfly_amd import codec
     seen = []
     real = codec.decode_ranges
@@ -143,3 +151,33 @@ def test_store_sharded_streams_each_ranks_window(torch_cuda, tmp_path):
                        env=dict(env, WINDOW_BYTES=str(4 * 31 * 24 * ny * nx * 4)))
     assert r.returncode == 0, r.stderr[-2000:]
     pd.testing.assert_frame_equal(a, pd.read_csv(win), check_exact=True)
+
+
+def test_store_cell_sharding_reads_only_its_band(torch_cuda, tmp_path):
+    """`aggregate_store_cells`: two ranks take latitude bands of the same store (space-tiled chunks: each rank decodes
+    only the tiles of its band), the numerators / denominators are all-reduced, and the frame equals the
+    single-process run to rounding (band sums are added in a different order)."""
+    import numpy as np
+    import aggfly_amd as af
+    from aggfly_amd import synth
+    T, ny, nx = 24 * 90, 10, 12
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=63, ocean_frac=0.1, scattered_nan=30) + np.float32(273.15)
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": pd.date_range("2003-03-01", periods=T, freq="h"), "latitude": 30 + 0.25 * np.arange(ny),
+                                  "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+    store = str(tmp_path / "era.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 720, "latitude": 5, "longitude": 6})      # 3 x 2 x 2 tiles
+    script = tmp_path / "store_job.py"
+    script.write_text(STORE_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    one, two = str(tmp_path / "one.csv"), str(tmp_path / "two.csv")
+    r = subprocess.run([sys.executable, str(script), store, one], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script), store, two], capture_output=True, text=True, timeout=300,
+                       env=dict(env, SHARD="cells", CHUNKS_PER_RANK="6"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = pd.read_csv(one), pd.read_csv(two)
+    assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
+    pd.testing.assert_frame_equal(a, b, rtol=1e-12, atol=0)
