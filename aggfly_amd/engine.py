@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import threading
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -340,8 +341,21 @@ def plan_groups(time_index, cols):
     return out
 
 
+# Plans (and their scratch in HBM) are cached per process and a handle must not be used by two calls at once
+# (include/aggfly_hip.h): calls from several host threads — the reference runs its kernels from a dask thread pool,
+# `nb_kernels.py:271-305` — enqueue their kernel sequences one after the other.  The sequences stay in order on the
+# stream they share, so no device synchronisation is needed; threads that use DIFFERENT streams must not share a
+# process-wide cache entry (give them `exact_order` / `tuning` variants or separate processes).
+_RUN_LOCK = threading.RLock()
+
+
 def run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=None):
     """Run one fused pass; splits it if the library says the pass is too wide."""
+    with _RUN_LOCK:
+        return _run_fused_pass(cube, cols, ib, ob, csr, want_cells, exact_order)
+
+
+def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=None):
     T = int(cube.shape[0])
     n_cells = int(cube[0].numel()) if T else int(np.prod(cube.shape[1:]))
     code = hip._dtype_code(cube)
@@ -353,8 +367,8 @@ def run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=No
         if len(cols) == 1:
             raise
         h = len(cols) // 2
-        return run_fused_pass(cube, cols[:h], ib, ob, None, True, exact_order) + \
-            run_fused_pass(cube, cols[h:], ib, ob, None, True, exact_order)
+        return _run_fused_pass(cube, cols[:h], ib, ob, None, True, exact_order) + \
+            _run_fused_pass(cube, cols[h:], ib, ob, None, True, exact_order)
     if csr is not None:
         out = plan.run(cube, csr, want_cells=want_cells)
         return [PassResult([c.key for c in cols], None, plan, out.get("cells"), out)]

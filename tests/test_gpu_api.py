@@ -537,3 +537,32 @@ def test_float32_reference_rounding_mode(torch_cuda):
     # the default (all-float64) results sit ~1e-7 from the float32 reference run, as documented
     rel = np.nanmax(np.abs(plain[cols].values - want32[cols].values) / np.maximum(np.abs(want32[cols].values), 1e-30))
     assert 1e-12 < rel < 1e-4
+
+
+def test_concurrent_host_threads_share_cached_plans(torch_cuda):
+    """The reference's kernels are called from a thread pool (`nb_kernels.py:271-305`); here eight host threads run the
+    same spec on different cubes at once.  They share ONE cached plan (and its scratch in HBM): every result must equal
+    the result of the same call made alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    from aggfly_amd import synth
+    T, ny, nx = 24 * 60, 20, 24
+    time = pd.date_range("2001-01-01", periods=T, freq="h")
+    lat, lon = 30 + 0.25 * np.arange(ny), 250 + 0.25 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, 7, seed=9)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "month"})],
+                t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 4)}),
+                   ("aggregate", {"calc": "sum", "groupby": "month"})])
+    dss = []
+    for i in range(8):
+        cube = synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=100 + i, ocean_frac=0.1, scattered_nan=5)
+        dss.append(af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}),
+                              lon_is_360=True).to_device())
+    w = af.weights_from_objects(dss[0], gr, table=tab)
+    alone = [af.aggregate_dataset(dataset=d, weights=w, **spec) for d in dss]
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            together = list(ex.map(lambda d: af.aggregate_dataset(dataset=d, weights=w, **spec), dss))
+        for a, b in zip(alone, together):
+            pd.testing.assert_frame_equal(a, b, check_exact=True)
+    assert not alone[0].drop(columns=["geoid", "time"]).equals(alone[1].drop(columns=["geoid", "time"]))     # the cubes do differ
