@@ -183,6 +183,7 @@ def run(config, output, engine, years, project_dir, backend, n_workers, verbose,
 
 def _maybe_init_distributed():
     import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on some hosts
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
         import torch.distributed as dist

@@ -34,6 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes: this pool's driver only supports dmabuf IPC
 
 HBM_PEAK_GBPS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy rate
 
