@@ -101,6 +101,8 @@ struct afhip_plan {
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
+    bool hb_arith = false; double hb_w = 0, hb_lo0 = 0, hb_gl = 0, hb_gh = 0;   // ... with exactly representable edges
+    bool packed = false;      // single-level, all columns plain bin counts: partial is [slot][C][16] u16 (FusedArgs::packed)
     int hb_bin_of_slot[MAX_THR] = {0};
     double hb_edge[MAX_THR + 1] = {0};
     // device tables
@@ -524,14 +526,40 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
                 pl->hb_edge[b] = pl->thr[(size_t)order[(size_t)b]].t0;
             }
             pl->hb_edge[pl->nthr] = pl->thr[(size_t)order[(size_t)pl->nthr - 1]].t1;
+            // arithmetic edges: E[g] = lo0 + g * w must come out EXACTLY, in the input precision and by the very fma the
+            // kernel executes, for every bin of the guarded partition; the clamp points must lie inside the guard bins
+            const int n = pl->nthr;
+            const double lo0 = e0 - w, gl = e0 - 0.5 * w, gh = pl->hb_edge[n] + 0.5 * w;
+            bool ex = true;
+            if (desc->dtype == AFHIP_F32) {
+                const float wf = (float)w, lo0f = (float)lo0, e0f = (float)e0, glf = (float)gl, ghf = (float)gh;
+                ex = (double)wf == w && (double)lo0f == lo0 && (double)e0f == e0 && lo0f + wf == e0f;
+                for (int g = 0; ex && g <= n + 1; ++g) {
+                    const double lo_want = g == 0 ? lo0 : pl->hb_edge[g - 1];
+                    const double hi_want = g == n + 1 ? pl->hb_edge[n] + w : pl->hb_edge[g];
+                    ex = (double)fmaf((float)g, wf, lo0f) == lo_want && (double)fmaf((float)g, wf, e0f) == hi_want;
+                }
+                ex = ex && (double)glf > lo0 && (double)glf < e0 && (double)ghf > pl->hb_edge[n] && (double)ghf < pl->hb_edge[n] + w;
+            } else {
+                ex = lo0 + w == e0;
+                for (int g = 0; ex && g <= n + 1; ++g) {
+                    const double lo_want = g == 0 ? lo0 : pl->hb_edge[g - 1];
+                    const double hi_want = g == n + 1 ? pl->hb_edge[n] + w : pl->hb_edge[g];
+                    ex = fma((double)g, w, lo0) == lo_want && fma((double)g, w, e0) == hi_want;
+                }
+                ex = ex && gl > lo0 && gl < e0 && gh > pl->hb_edge[n] && gh < pl->hb_edge[n] + w;
+            }
+            if (getenv("AFHIP_NO_ARITH_EDGES")) ex = false;       // experiment knob: force the table form
+            pl->hb_arith = ex; pl->hb_w = w; pl->hb_lo0 = lo0; pl->hb_gl = gl; pl->hb_gh = gh;
         }
     }
     if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
     const bool partition = pl->hb_n > 0 && want_pipe == 0;
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition);
+    const bool arith = partition && pl->hb_arith;
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
-        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition);
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0);
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
@@ -555,7 +583,15 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     }
     const int64_t C = desc->n_cells, K = desc->K, P = desc->P;
     auto a256 = [](int64_t b) { return (b + 255) / 256 * 256; };
-    pl->ws_partial = a256(std::max<int64_t>(pl->n_slots, 1) * K * C * 8);
+    // packed counts: integer-bin single-level variant, every column a plain bin count, no period longer than a
+    // 16-bit counter holds (0xFFFF is the NaN mark)
+    pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
+    for (const ColOp& c : pl->cols)
+        pl->packed = pl->packed && c.src == SRC_THR && c.tf == TF_NONE && c.rounding == 0 && c.outer == OUT_FIRST;
+    for (int64_t g = 0; pl->packed && g < desc->G1; ++g)
+        pl->packed = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] < 65535;
+    pl->ws_partial = pl->packed ? a256(std::max<int64_t>(pl->n_slots, 1) * C * 32)
+                                : a256(std::max<int64_t>(pl->n_slots, 1) * K * C * 8);
     pl->ws_panel = a256(C * (K + 1) * std::max<int64_t>(P, 1) * 8);
     *out = pl;
     return AFHIP_OK;
@@ -575,11 +611,12 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     char tmp[1024];
     int n = snprintf(tmp, sizeof tmp,
                      "variant=%s pipe=%d vec=%d stat=%d slots=%d kmax=%d depth=%d | T=%lld cells=%lld K=%d G1=%lld P=%lld | "
-                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld | workspace=%.1f MiB",
+                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld%s | workspace=%.1f MiB",
                      plan->variant->name, plan->variant->pipe, plan->variant->vec, plan->variant->stat, plan->variant->nthr,
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
                      plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
+                     plan->packed ? " packed-counts" : "",
                      (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
     return n + 1;
@@ -601,6 +638,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         fa.thr[i].t0f = INFINITY; fa.thr[i].t1f = -INFINITY;
     }
     for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
+    fa.packed = pl->packed ? 1 : 0;
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
@@ -616,6 +654,8 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
             fa.hb_dn[k] = (double)f > t ? std::nextafterf(f, -INFINITY) : f;     // largest float <= t
             fa.hb_up[k] = (double)f < t ? std::nextafterf(f, INFINITY) : f;      // smallest float >= t
         }
+        fa.hb_w = pl->hb_w; fa.hb_lo0 = pl->hb_lo0; fa.hb_gl = pl->hb_gl; fa.hb_gh = pl->hb_gh;
+        fa.hb_wf = (float)pl->hb_w; fa.hb_lo0f = (float)pl->hb_lo0; fa.hb_glf = (float)pl->hb_gl; fa.hb_ghf = (float)pl->hb_gh;
         lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
     }
     HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
@@ -628,6 +668,7 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
     CombineArgs ca{};
     ca.partial = partial; ca.slot_ptr = pl->d_slot_ptr.p; ca.outer_bounds = pl->d_ob.p;
     ca.cells_out = cells; ca.panel = panel; ca.C = C; ca.P = P; ca.K = pl->K;
+    ca.packed = pl->packed ? 1 : 0;
     for (int j = 0; j < pl->K; ++j) {
         ca.outer[j] = pl->cols[(size_t)j].outer;
         ca.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
@@ -773,9 +814,9 @@ static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells
     if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
     dim3 grid((unsigned)((n_cells + WG - 1) / WG), (unsigned)std::min<int64_t>(G, 65535));
     if (dtype == AFHIP_F32)
-        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D);
+        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D, pl->packed ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D);
+        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D, pl->packed ? 1 : 0);
     hipError_t e = hipGetLastError();
     // the plan owns the scratch the kernels are still reading: drain before freeing it
     hipError_t e2 = hipStreamSynchronize(st);

@@ -85,6 +85,16 @@ struct FusedArgs {
     int32_t hb_bin_of_slot[MAX_THR];
     double hb_edge[MAX_THR + 1];
     float hb_dn[MAX_THR + 1], hb_up[MAX_THR + 1];
+    // arithmetic edges (FEAT bit 6): every edge is EXACTLY hb_lo0 + g * hb_w in the input precision (host-checked with
+    // the same fma), so the two edges around a guess are two fmas instead of an LDS table read; hb_gl / hb_gh sit
+    // inside the lower / upper guard bin: values (and NaN) are clamped onto them first.
+    // packed != 0 (single-level plans whose columns are all bin counts): the period's K counts leave as 16-bit
+    // integers, cell-major, 32 B per (slot, cell) — [slot][C][16] u16, 0xFFFF = NaN (empty period) — instead of
+    // K doubles per cell in K planes: a quarter of the bytes in 2 stores instead of K (the f64 stores of the
+    // 13-bin CMIP6 plan cost its streaming kernel 18 %)
+    int32_t packed;
+    double hb_w, hb_lo0, hb_gl, hb_gh;
+    float hb_wf, hb_lo0f, hb_glf, hb_ghf;
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
 };
@@ -385,6 +395,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     constexpr bool TKI = (FEAT & 8) != 0;
     constexpr bool SL = (FEAT & 16) != 0;
     constexpr bool HB = (FEAT & 32) != 0;
+    // FEAT bit 6: histogram with arithmetic edges — exactly representable equal-width edges (5 degC bins from -20 ...):
+    //             the edge pair of the guessed bin is computed (2 fma) instead of read from the LDS table, which takes an
+    //             LDS round trip out of every element's dependent chain; a value on an edge is recognised by equality.
+    constexpr bool HA = (FEAT & 64) != 0;
+    static_assert(!HA || HB, "arithmetic edges are a mode of the LDS histogram");
     static_assert(!HB || (TKI && PIPE == 0), "the LDS histogram replaces the integer bin counters of the direct-load path");
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
     const int64_t C = a.C;
@@ -442,6 +457,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     const int bd = blockDim.x, tid = threadIdx.x;
     const int hb_bins = a.hb_n + 2;
     TIn hb_c1 = 0, hb_c0 = 0, hb_top = 0;
+    TIn ha_w = 0, ha_lo0 = 0, ha_e0 = 0, ha_gl = 0, ha_gh = 0;
     int hb_sh = 0, hb_lane[VEC] = {0};
     if constexpr (HB) {
         if (tid < hb_bins) {
@@ -460,6 +476,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         if constexpr (sizeof(TIn) == 4) { hb_c1 = a.hb_c1f; hb_c0 = a.hb_c0f; }
         else { hb_c1 = a.hb_c1; hb_c0 = a.hb_c0; }
         hb_top = (TIn)(a.hb_n + 1);
+        if constexpr (HA) {
+            if constexpr (sizeof(TIn) == 4) { ha_w = a.hb_wf; ha_lo0 = a.hb_lo0f; ha_gl = a.hb_glf; ha_gh = a.hb_ghf; }
+            else { ha_w = a.hb_w; ha_lo0 = a.hb_lo0; ha_gl = a.hb_gl; ha_gh = a.hb_gh; }
+            ha_e0 = ha_lo0 + ha_w;                                  // exact (host-checked)
+            // VOP3 takes one scalar operand: keep the second operand of the clamp and the fma addends in VGPRs
+            asm volatile("" : "+v"(ha_gh), "+v"(ha_lo0), "+v"(ha_e0));
+        }
         asm volatile("" : "+v"(hb_c0));      // keep the addend in a VGPR: v_fma takes one scalar operand only
         hb_sh = a.hb_shift + 2 + (VEC == 4 ? 2 : (VEC == 2 ? 1 : 0));     // byte stride between bins = VEC * blockDim * 4
 #pragma unroll
@@ -504,13 +527,43 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         if (count)
             __hip_atomic_fetch_add((int*)((char*)hcnt + (b << hb_sh) + hb_lane[i]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
+    // arithmetic-edge form of hb_guess + hb_count: no table read
+    auto ha_update = [&](TIn vr, int i) {
+        TIn vc;                                                     // clamped into the guarded range; NaN -> lower guard bin
+        if constexpr (sizeof(TIn) == 4) vc = __builtin_amdgcn_fmed3f(vr, ha_gl, ha_gh);
+        else vc = fmin(fmax(vr, ha_gl), ha_gh);
+        TIn tf, lo, hi;
+        if constexpr (sizeof(TIn) == 4) {
+            tf = __builtin_floorf(__fmaf_rn(vc, hb_c1, hb_c0));
+            lo = __fmaf_rn(tf, ha_w, ha_lo0);                       // E[b] and E[b + 1], exactly
+            hi = __fmaf_rn(tf, ha_w, ha_e0);
+        } else {
+            tf = __builtin_floor(__fma_rn(vc, hb_c1, hb_c0));
+            lo = __fma_rn(tf, ha_w, ha_lo0);
+            hi = __fma_rn(tf, ha_w, ha_e0);
+        }
+        // branch-free repair of a guess that is off by one (carry-in adds), and a value ON an edge is in no bin
+        int b = (int)tf;
+        b += (vc >= hi) ? 1 : 0;
+        b -= (vc <= lo) ? 1 : 0;
+        const bool on_edge = (vc == hi) | (vc == lo);
+        if (!on_edge) {
+            int* p = (int*)((char*)hcnt + (b << hb_sh) + hb_lane[i]);
+#ifdef HA_PLAIN_RMW
+            *p = *p + 1;                                              // the counter is private to this lane
+#else
+            __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+        }
+    };
     auto consume = [&](const RawVec<TIn, VEC>& rv, bool hb_inline = true) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const TIn vr = rv.v[i];
             const double v = (double)vr;
             const bool isn = vr != vr;
-            nanmask[i] |= __builtin_amdgcn_ballot_w64(isn);
+            // integer-bin plans without an inner statistic never look at the NaN mask (a NaN is simply in no bin)
+            if constexpr (!(TKI && STAT == 0)) nanmask[i] |= __builtin_amdgcn_ballot_w64(isn);
             if (STAT == 1) {
                 s[i] += v;                          // a NaN poisons s; the group is NaN anyway
             } else if (STAT == 2) {
@@ -524,7 +577,8 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 mx[i] = __builtin_fmax(mx[i], v);
             }
             if constexpr (HB) {
-                if (hb_inline) { int b; EdgeT ea; hb_guess(vr, b, ea); hb_count(vr, i, b, ea); }
+                if constexpr (HA) { if (hb_inline) ha_update(vr, i); }
+                else if (hb_inline) { int b; EdgeT ea; hb_guess(vr, b, ea); hb_count(vr, i, b, ea); }
             }
 #pragma unroll
             for (int j = 0; j < (HB ? 0 : NTHR); ++j) {
@@ -553,6 +607,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
             mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
             inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_fast(mx[i] - mn[i]) : 0.0;
+        }
+        uint32_t pk[VEC][8];
+        if constexpr (SL && TKI) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pk[i][u] = 0u;
         }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
@@ -623,6 +684,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) x[i] = pow(x[i], co.tf_arg);
                 }
+                if constexpr (SL && TKI) {
+                    if (a.packed) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const uint32_t u = (x[i] != x[i]) ? 0xFFFFu : (uint32_t)x[i];
+                            pk[i][j >> 1] |= u << (16 * (j & 1));
+                        }
+                        continue;
+                    }
+                }
                 if constexpr (SL) {
                     if (active) {
 #pragma unroll
@@ -652,6 +723,17 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         }
                     }
                     os[j][i] = o;
+                }
+            }
+        }
+        if constexpr (SL && TKI) {
+            if (a.packed && active) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    u4* dst = (u4*)((char*)a.partial + ((int64_t)slot * C + c0 + i) * 32);
+                    dst[0] = u4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
+                    dst[1] = u4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
                 }
             }
         }
@@ -707,7 +789,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 p += (int64_t)DEPTH * C;
             };
             auto use_block = [&](const RawVec<TIn, VEC> (&r)[DEPTH]) {
-                if constexpr (HB) {
+                if constexpr (HA) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) consume(r[d]);
+                } else if constexpr (HB) {
                     int hb_b[DEPTH][VEC];
                     EdgeT hb_e[DEPTH][VEC];
 #pragma unroll
