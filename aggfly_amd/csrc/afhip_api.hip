@@ -738,8 +738,19 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
     if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
-    if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
-    if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
+    if (plan->packed && !cells_dev && plan->n_slots <= P && !getenv("AFHIP_NO_COUNTS_SPMM")) {
+        // bin-count plan, no per-cell output wanted: the weighted sums gather the packed counts directly
+        // (every period has at most one slot: single-level plans are never split)
+        const int64_t nq = csr->R * P;
+        if (nq) {
+            hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st, csr->indptr.p, csr->cols.p,
+                               csr->w.p, (const uint16_t*)partial, plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)K, plan->desc.n_cells);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
+        if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
+    }
     const int64_t n = K > 0 ? csr->R * P : 0;                 // one thread per (region, period)
     if (n) {
         hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, plan->sums, num_dev,

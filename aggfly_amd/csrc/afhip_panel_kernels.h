@@ -180,6 +180,66 @@ __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, co
 }
 
 // ---------------------------------------------------------------------------------------
+// k_csr_spmm_counts: the weighted sums of a bin-count plan straight from the packed counts
+// (FusedArgs::packed: [slot][C][16] u16, 0xFFFF = NaN), without the cell-major panel in between.
+// One thread per (region r, period p): per table entry it reads the cell's 32-byte record once (two 16-byte loads,
+// four entries in flight) and feeds its K + 1 running sums; the thread's K + 1 results are contiguous in out.
+// Column K is the validity weight sum (den).  Same products, same order, same rounding as k_combine_slots +
+// k_csr_spmm: x = where(valid, count, 0), valid = no NaN among the K columns; a count plan's columns are NaN
+// together (empty period) or not at all, so column 0 tells.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                        const double* __restrict__ w, const uint16_t* __restrict__ packed,
+                                                        const int32_t* __restrict__ slot_ptr, double* __restrict__ out,
+                                                        int64_t R, int64_t P, int K, int64_t C) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;       // = r * P + p: a wave walks the periods of one region
+    if (tid >= R * P) return;
+    const int64_t r = tid / P, p = tid - r * P;
+    double* dst = out + tid * (K + 1);
+    const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
+    double acc[MAX_COLS + 1];
+#pragma unroll
+    for (int k = 0; k <= MAX_COLS; ++k) acc[k] = 0.0;
+    if (s1 != s0) {                                                    // else: empty resample bin, every cell invalid
+        const char* plane = (const char*)packed + (int64_t)s0 * C * 32;
+        const int64_t j0 = indptr[r], j1 = indptr[r + 1];
+        auto feed = [&](double wj, const u4& lo, const u4& hi) {
+            const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const bool valid = (q[0] & 0xFFFFu) != 0xFFFFu;
+#pragma unroll
+            for (int k = 0; k < MAX_COLS; ++k) {
+                if (k < K) {
+                    const double x = valid ? (double)((q[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : 0.0;
+                    acc[k] = __dadd_rn(acc[k], __dmul_rn(wj, x));
+                }
+            }
+            acc[MAX_COLS] = __dadd_rn(acc[MAX_COLS], __dmul_rn(wj, valid ? 1.0 : 0.0));
+        };
+        int64_t j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            u4 lo[4], hi[4];
+            double wj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u4* rec = (const u4*)(plane + (int64_t)cols[j + u] * 32);
+                lo[u] = rec[0]; hi[u] = rec[1]; wj[u] = w[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) feed(wj[u], lo[u], hi[u]);
+        }
+        for (; j < j1; ++j) {
+            const u4* rec = (const u4*)(plane + (int64_t)cols[j] * 32);
+            feed(w[j], rec[0], rec[1]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_COLS; ++k)
+        if (k < K) dst[k] = acc[k];
+    dst[K] = acc[MAX_COLS];
+}
+
+// ---------------------------------------------------------------------------------------
 // k_csr_spmm: out[r][q] = sum_j w[j] * X[col[j]][q], j over the row in table order.
 // One thread per (r, q), q fastest, so a wave reads whole rows of X contiguously.  The
 // product is rounded before the add (no FMA): np.add.at adds the already-rounded

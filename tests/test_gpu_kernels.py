@@ -360,6 +360,28 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     assert "_hist" in plan.describe(), plan.describe()
     got = plan.run_temporal(d).cpu().numpy()                             # [D, G, cells]
     np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want.reshape(3, -1, 13))
+    # the whole pass: count plans leave the streaming kernel as packed 16-bit counts; without a per-cell output the
+    # weighted sums gather them directly, with one the cell-major panel is built first — same numbers either way,
+    # and both equal the reference's scatter of where(valid, x, 0) (empty middle group -> NaN panel column)
+    assert "packed-counts" in plan.describe(), plan.describe()
+    nreg = 7
+    wr = rng.integers(0, nreg, 150); wc = rng.integers(0, ny * nx, 150); ww = rng.uniform(0.1, 2.0, 150)
+    order = np.argsort(wr, kind="stable")
+    csr = hip.CSR(wr[order], wc[order], ww[order], nreg, ny * nx)
+    direct = plan.run(d, csr, want_cells=False)
+    via_panel = plan.run(d, csr, want_cells=True)
+    for key in ("num", "den", "res"):
+        np.testing.assert_array_equal(direct[key].cpu().numpy(), via_panel[key].cpu().numpy(), err_msg=key)
+    cells = np.transpose(got, (1, 2, 0))                                 # [G, cells, D], exact counts (NaN for the empty group)
+    for g in range(3):
+        valid = ~np.isnan(cells[g]).any(axis=1)
+        den = np.zeros(nreg); num = np.zeros((13, nreg))
+        for r_, c_, w_ in zip(wr[order], wc[order], ww[order]):
+            den[r_] += w_ * valid[c_]
+            for k in range(13):
+                num[k, r_] += w_ * (cells[g, c_, k] if valid[c_] else 0.0)
+        np.testing.assert_array_equal(direct["den"].cpu().numpy()[:, g], den)
+        np.testing.assert_array_equal(direct["num"].cpu().numpy()[:, :, g], num)
     # shuffled slot order and a two-level use (daily mean + annual bins on raw hourly-like groups)
     perm = rng.permutation(13)
     plan2 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [cols[i] for i in perm] + [dict(inner="mean")])
