@@ -102,7 +102,8 @@ struct afhip_plan {
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
     bool hb_arith = false; double hb_w = 0, hb_lo0 = 0, hb_gl = 0, hb_gh = 0;   // ... with exactly representable edges
-    bool packed = false;      // single-level, all columns plain bin counts: partial is [slot][C][16] u16 (FusedArgs::packed)
+    bool packed = false;      // single-level, all columns plain bin counts: partial holds packed records (FusedArgs::packed)
+    PackFmt pk{};             // their format; pk_bw = bits per count
     int hb_bin_of_slot[MAX_THR] = {0};
     double hb_edge[MAX_THR + 1] = {0};
     // device tables
@@ -588,9 +589,21 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
     for (const ColOp& c : pl->cols)
         pl->packed = pl->packed && c.src == SRC_THR && c.tf == TF_NONE && c.rounding == 0 && c.outer == OUT_FIRST;
-    for (int64_t g = 0; pl->packed && g < desc->G1; ++g)
-        pl->packed = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] < 65535;
-    pl->ws_partial = pl->packed ? a256(std::max<int64_t>(pl->n_slots, 1) * C * 32)
+    int64_t maxlen = 0;
+    for (int64_t g = 0; g < desc->G1; ++g) maxlen = std::max(maxlen, pl->ib[(size_t)g + 1] - pl->ib[(size_t)g]);
+    pl->packed = pl->packed && maxlen < 65535;
+    if (pl->packed) {
+        // the narrowest field that holds the longest period's count and keeps all ones free for NaN; 16-byte records when
+        // K such fields fit two words (daily data, annual bins: 13 x 9 bits), else 16-bit fields in 32 bytes
+        int bw = 1;
+        while (((int64_t)1 << bw) - 1 <= maxlen) ++bw;
+        int f = 64 / bw;
+        pl->pk.nw = 2;
+        if (K > 2 * f || getenv("AFHIP_PACK32")) { bw = 16; f = 4; pl->pk.nw = 4; }
+        pl->pk.mask = (uint32_t)(((uint64_t)1 << bw) - 1);
+        for (int j = 0; j < MAX_COLS; ++j) { pl->pk.word[j] = (uint8_t)(j / f); pl->pk.shift[j] = (uint8_t)((j % f) * bw); }
+    }
+    pl->ws_partial = pl->packed ? a256(std::max<int64_t>(pl->n_slots, 1) * C * pl->pk.nw * 8)
                                 : a256(std::max<int64_t>(pl->n_slots, 1) * K * C * 8);
     pl->ws_panel = a256(C * (K + 1) * std::max<int64_t>(P, 1) * 8);
     *out = pl;
@@ -616,7 +629,7 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
                      plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
-                     plan->packed ? " packed-counts" : "",
+                     plan->packed ? (plan->pk.nw == 2 ? " packed-counts16" : " packed-counts32") : "",
                      (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
     return n + 1;
@@ -639,6 +652,8 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     }
     for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
     fa.packed = pl->packed ? 1 : 0;
+    fa.pk_nw = pl->pk.nw; fa.pk_mask = pl->pk.mask;
+    for (int j = 0; j < MAX_COLS; ++j) { fa.pk_word[j] = pl->pk.word[j]; fa.pk_shift[j] = pl->pk.shift[j]; }
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
@@ -668,7 +683,7 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
     CombineArgs ca{};
     ca.partial = partial; ca.slot_ptr = pl->d_slot_ptr.p; ca.outer_bounds = pl->d_ob.p;
     ca.cells_out = cells; ca.panel = panel; ca.C = C; ca.P = P; ca.K = pl->K;
-    ca.packed = pl->packed ? 1 : 0;
+    ca.pk = pl->packed ? pl->pk : PackFmt{};
     for (int j = 0; j < pl->K; ++j) {
         ca.outer[j] = pl->cols[(size_t)j].outer;
         ca.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
@@ -744,7 +759,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         const int64_t nq = csr->R * P;
         if (nq) {
             hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st, csr->indptr.p, csr->cols.p,
-                               csr->w.p, (const uint16_t*)partial, plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)K, plan->desc.n_cells);
+                               csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)K, plan->desc.n_cells, plan->pk);
             HIP_TRY(hipGetLastError());
         }
     } else {
@@ -825,9 +840,9 @@ static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells
     if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
     dim3 grid((unsigned)((n_cells + WG - 1) / WG), (unsigned)std::min<int64_t>(G, 65535));
     if (dtype == AFHIP_F32)
-        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D, pl->packed ? 1 : 0);
+        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D, pl->packed ? pl->pk : PackFmt{});
     else
-        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D, pl->packed ? 1 : 0);
+        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D, pl->packed ? pl->pk : PackFmt{});
     hipError_t e = hipGetLastError();
     // the plan owns the scratch the kernels are still reading: drain before freeing it
     hipError_t e2 = hipStreamSynchronize(st);

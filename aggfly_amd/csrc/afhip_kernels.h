@@ -43,6 +43,13 @@ enum : int { OUT_FIRST = 0, OUT_SUM = 1, OUT_MEAN = 2, OUT_MIN = 3, OUT_MAX = 4,
 // (nb_kernels.py:169-177) and c += 1.0 (nb_kernels.py:190-196).
 // t0f / t1f are t0 rounded down / t1 rounded up to float: for a float v,
 // (double)v > t0  <=>  v > t0f  and  (double)v < t1  <=>  v < t1f, so f32 cubes compare in f32.
+// packed-count record format (FusedArgs::packed): nw = 0 -> not packed
+struct PackFmt {
+    int32_t nw;                      // 64-bit words per (slot, cell): 2 or 4
+    uint32_t mask;                   // all ones of a field = NaN
+    uint8_t word[MAX_COLS], shift[MAX_COLS];
+};
+
 struct ThrSlot {
     double t0, t1, A, B;
     float t0f, t1f;
@@ -88,11 +95,16 @@ struct FusedArgs {
     // arithmetic edges (FEAT bit 6): every edge is EXACTLY hb_lo0 + g * hb_w in the input precision (host-checked with
     // the same fma), so the two edges around a guess are two fmas instead of an LDS table read; hb_gl / hb_gh sit
     // inside the lower / upper guard bin: values (and NaN) are clamped onto them first.
-    // packed != 0 (single-level plans whose columns are all bin counts): the period's K counts leave as 16-bit
-    // integers, cell-major, 32 B per (slot, cell) — [slot][C][16] u16, 0xFFFF = NaN (empty period) — instead of
-    // K doubles per cell in K planes: a quarter of the bytes in 2 stores instead of K (the f64 stores of the
-    // 13-bin CMIP6 plan cost its streaming kernel 18 %)
+    // packed != 0 (single-level plans whose columns are all bin counts): the period's K counts leave as small
+    // integers, cell-major, one 16- or 32-byte record per (slot, cell), all ones = NaN (empty period) — instead of
+    // K doubles per cell in K planes: an eighth / a quarter of the bytes in 1 / 2 stores instead of K (the f64 stores
+    // of the 13-bin CMIP6 plan cost its streaming kernel 18 %)
     int32_t packed;
+    // record format: pk_nw 64-bit words per (slot, cell) — 2 (16 B) when K counts of pk_bw bits fit, else 4 with 16-bit
+    // fields; column j sits in word pk_word[j] at bit pk_shift[j]; all ones (pk_mask) = NaN
+    int32_t pk_nw;
+    uint32_t pk_mask;
+    uint8_t pk_word[MAX_COLS], pk_shift[MAX_COLS];
     double hb_w, hb_lo0, hb_gl, hb_gh;
     float hb_wf, hb_lo0f, hb_glf, hb_ghf;
     ThrSlot thr[MAX_THR];
@@ -608,12 +620,12 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
             inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_fast(mx[i] - mn[i]) : 0.0;
         }
-        uint32_t pk[VEC][8];
+        uint64_t pk[VEC][4];
         if constexpr (SL && TKI) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) pk[i][u] = 0u;
+                for (int u = 0; u < 4; ++u) pk[i][u] = 0ull;
         }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
@@ -688,8 +700,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if (a.packed) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
-                            const uint32_t u = (x[i] != x[i]) ? 0xFFFFu : (uint32_t)x[i];
-                            pk[i][j >> 1] |= u << (16 * (j & 1));
+                            const uint64_t u = (x[i] != x[i]) ? (uint64_t)a.pk_mask : (uint64_t)(uint32_t)x[i];
+                            const int wi = a.pk_word[j];
+                            const uint64_t f = u << a.pk_shift[j];
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) pk[i][w] |= (wi == w) ? f : 0ull;
                         }
                         continue;
                     }
@@ -731,9 +746,14 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    u4* dst = (u4*)((char*)a.partial + ((int64_t)slot * C + c0 + i) * 32);
-                    dst[0] = u4{pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
-                    dst[1] = u4{pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+                    const u4 lo = u4{(uint32_t)pk[i][0], (uint32_t)(pk[i][0] >> 32), (uint32_t)pk[i][1], (uint32_t)(pk[i][1] >> 32)};
+                    if (a.pk_nw == 2) {
+                        *(u4*)((char*)a.partial + ((int64_t)slot * C + c0 + i) * 16) = lo;
+                    } else {
+                        u4* dst = (u4*)((char*)a.partial + ((int64_t)slot * C + c0 + i) * 32);
+                        dst[0] = lo;
+                        dst[1] = u4{(uint32_t)pk[i][2], (uint32_t)(pk[i][2] >> 32), (uint32_t)pk[i][3], (uint32_t)(pk[i][3] >> 32)};
+                    }
                 }
             }
         }

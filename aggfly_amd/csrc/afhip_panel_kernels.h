@@ -26,16 +26,35 @@ struct CombineArgs {
     int32_t K;
     int32_t outer[MAX_COLS];
     int32_t round_final[MAX_COLS];   // 1: round the merged value to float32 (reference dtype rule)
-    int32_t packed;                  // partial is [slot][C][16] u16 counts (0xFFFF = NaN), see FusedArgs::packed
+    PackFmt pk;                      // pk.nw != 0: partial holds packed counts, see FusedArgs::packed
 };
 
 // partial value of (slot s, column j, cell c) in either layout
-__device__ __forceinline__ double ld_partial(const double* partial, int packed, int64_t s, int j, int K, int64_t C, int64_t c) {
-    if (packed) {
-        const uint16_t u = ((const uint16_t*)partial)[(s * C + c) * 16 + j];
-        return u == 0xFFFFu ? nan64() : (double)u;
+__device__ __forceinline__ double ld_partial(const double* partial, const PackFmt& pk, int64_t s, int j, int K, int64_t C, int64_t c) {
+    if (pk.nw) {
+        const uint64_t q = ((const uint64_t*)partial)[(s * C + c) * pk.nw + pk.word[j]];
+        const uint32_t u = (uint32_t)(q >> pk.shift[j]) & pk.mask;
+        return u == pk.mask ? nan64() : (double)u;
     }
     return partial[(s * K + j) * C + c];
+}
+
+// one packed record (2 or 4 words) of (slot s, cell c) in registers, and a field of it
+__device__ __forceinline__ void ld_record(const void* partial, const PackFmt& pk, int64_t s, int64_t C, int64_t c, uint64_t (&q)[4]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const char* rec = (const char*)partial + (s * C + c) * (int64_t)(pk.nw * 8);
+    const u4 lo = *(const u4*)rec;
+    q[0] = (uint64_t)lo.x | ((uint64_t)lo.y << 32); q[1] = (uint64_t)lo.z | ((uint64_t)lo.w << 32);
+    q[2] = 0ull; q[3] = 0ull;
+    if (pk.nw == 4) {
+        const u4 hi = *(const u4*)(rec + 16);
+        q[2] = (uint64_t)hi.x | ((uint64_t)hi.y << 32); q[3] = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
+    }
+}
+__device__ __forceinline__ uint32_t record_field(const uint64_t (&q)[4], const PackFmt& pk, int j) {
+    const int wi = pk.word[j];
+    const uint64_t w = wi == 0 ? q[0] : (wi == 1 ? q[1] : (wi == 2 ? q[2] : q[3]));
+    return (uint32_t)(w >> pk.shift[j]) & pk.mask;
 }
 
 __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
@@ -52,10 +71,10 @@ __global__ __launch_bounds__(WG) void k_combine_slots(const CombineArgs a) {
             if (s1 == s0) {
                 v = nan64();
             } else {
-                v = ld_partial(a.partial, a.packed, s0, j, K, a.C, c);
+                v = ld_partial(a.partial, a.pk, s0, j, K, a.C, c);
                 const int o = a.outer[j];
                 for (int s = s0 + 1; s < s1; ++s) {
-                    const double x = ld_partial(a.partial, a.packed, s, j, K, a.C, c);
+                    const double x = ld_partial(a.partial, a.pk, s, j, K, a.C, c);
                     if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
                     else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
                     else if (o == OUT_FIRST) { /* a period is never split for OUT_FIRST */ }
@@ -97,16 +116,18 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
         const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
         bool valid = true;
         double vals[MAX_COLS];
-        if (a.packed && s1 == s0 + 1) {
-            // packed counts: the cell's 16 u16 in two 16-byte loads
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            const u4* q = (const u4*)((const char*)a.partial + ((int64_t)s0 * a.C + c) * 32);
-            const u4 lo = q[0], hi = q[1];
-            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (a.pk.nw && s1 == s0 + 1) {
+            // packed counts: the cell's record in one or two 16-byte loads
+            uint64_t q[4];
+            ld_record(a.partial, a.pk, s0, a.C, c, q);
 #pragma unroll
             for (int j = 0; j < MAX_COLS; ++j) {
-                const uint32_t u = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                vals[j] = (j < K) ? (u == 0xFFFFu ? nan64() : (double)u) : 0.0;
+                if (j < K) {
+                    const uint32_t u = record_field(q, a.pk, j);
+                    vals[j] = (u == a.pk.mask) ? nan64() : (double)u;
+                } else {
+                    vals[j] = 0.0;
+                }
             }
         } else if (s1 == s0 + 1) {
             // one slot per period (single-level plans, packed periods): K independent loads in flight
@@ -124,10 +145,10 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
                 if (s1 == s0) {
                     v = nan64();
                 } else {
-                    v = ld_partial(a.partial, a.packed, s0, j, K, a.C, c);
+                    v = ld_partial(a.partial, a.pk, s0, j, K, a.C, c);
                     const int o = a.outer[j];
                     for (int s = s0 + 1; s < s1; ++s) {
-                        const double x = ld_partial(a.partial, a.packed, s, j, K, a.C, c);
+                        const double x = ld_partial(a.partial, a.pk, s, j, K, a.C, c);
                         if (o == OUT_MIN) { double t = (x < v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
                         else if (o == OUT_MAX) { double t = (x > v) ? x : v; v = (x != x || v != v) ? nan64() : t; }
                         else if (o == OUT_FIRST) { }
@@ -167,13 +188,13 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
 // (nb_kernels.py:257-268: float64 accumulate, store in the input dtype).
 template <typename TOut>
 __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, const int32_t* slot_ptr,
-                                                       TOut* out, int64_t C, int64_t G, int D, int packed) {
+                                                       TOut* out, int64_t C, int64_t G, int D, const PackFmt pk) {
     const int64_t c = (int64_t)blockIdx.x * WG + threadIdx.x;   // grid = (cell tiles, group lanes)
     if (c >= C) return;
     for (int64_t g = blockIdx.y; g < G; g += gridDim.y) {
         const int s0 = slot_ptr[g], s1 = slot_ptr[g + 1];
         for (int d = 0; d < D; ++d) {
-            const double v = (s1 == s0) ? nan64() : ld_partial(partial, packed, s0, d, D, C, c);
+            const double v = (s1 == s0) ? nan64() : ld_partial(partial, pk, s0, d, D, C, c);
             out[(g * C + c) * D + d] = (TOut)v;
         }
     }
@@ -181,18 +202,17 @@ __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, co
 
 // ---------------------------------------------------------------------------------------
 // k_csr_spmm_counts: the weighted sums of a bin-count plan straight from the packed counts
-// (FusedArgs::packed: [slot][C][16] u16, 0xFFFF = NaN), without the cell-major panel in between.
-// One thread per (region r, period p): per table entry it reads the cell's 32-byte record once (two 16-byte loads,
-// four entries in flight) and feeds its K + 1 running sums; the thread's K + 1 results are contiguous in out.
+// (FusedArgs::packed: one 16- or 32-byte record per (slot, cell), all ones = NaN), without the cell-major panel in
+// between.  One thread per (region r, period p): per table entry it reads the cell's record once (one or two 16-byte
+// loads, four entries in flight) and feeds its K + 1 running sums; the thread's K + 1 results are contiguous in out.
 // Column K is the validity weight sum (den).  Same products, same order, same rounding as k_combine_slots +
 // k_csr_spmm: x = where(valid, count, 0), valid = no NaN among the K columns; a count plan's columns are NaN
 // together (empty period) or not at all, so column 0 tells.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
-                                                        const double* __restrict__ w, const uint16_t* __restrict__ packed,
+                                                        const double* __restrict__ w, const void* __restrict__ packed,
                                                         const int32_t* __restrict__ slot_ptr, double* __restrict__ out,
-                                                        int64_t R, int64_t P, int K, int64_t C) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                                                        int64_t R, int64_t P, int K, int64_t C, const PackFmt pk) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;       // = r * P + p: a wave walks the periods of one region
     if (tid >= R * P) return;
     const int64_t r = tid / P, p = tid - r * P;
@@ -202,15 +222,13 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
 #pragma unroll
     for (int k = 0; k <= MAX_COLS; ++k) acc[k] = 0.0;
     if (s1 != s0) {                                                    // else: empty resample bin, every cell invalid
-        const char* plane = (const char*)packed + (int64_t)s0 * C * 32;
         const int64_t j0 = indptr[r], j1 = indptr[r + 1];
-        auto feed = [&](double wj, const u4& lo, const u4& hi) {
-            const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const bool valid = (q[0] & 0xFFFFu) != 0xFFFFu;
+        auto feed = [&](double wj, const uint64_t (&q)[4]) {
+            const bool valid = record_field(q, pk, 0) != pk.mask;
 #pragma unroll
             for (int k = 0; k < MAX_COLS; ++k) {
                 if (k < K) {
-                    const double x = valid ? (double)((q[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : 0.0;
+                    const double x = valid ? (double)record_field(q, pk, k) : 0.0;
                     acc[k] = __dadd_rn(acc[k], __dmul_rn(wj, x));
                 }
             }
@@ -218,19 +236,17 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
         };
         int64_t j = j0;
         for (; j + 4 <= j1; j += 4) {
-            u4 lo[4], hi[4];
+            uint64_t q[4][4];
             double wj[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const u4* rec = (const u4*)(plane + (int64_t)cols[j + u] * 32);
-                lo[u] = rec[0]; hi[u] = rec[1]; wj[u] = w[j + u];
-            }
+            for (int u = 0; u < 4; ++u) { ld_record(packed, pk, s0, C, cols[j + u], q[u]); wj[u] = w[j + u]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) feed(wj[u], lo[u], hi[u]);
+            for (int u = 0; u < 4; ++u) feed(wj[u], q[u]);
         }
         for (; j < j1; ++j) {
-            const u4* rec = (const u4*)(plane + (int64_t)cols[j] * 32);
-            feed(w[j], rec[0], rec[1]);
+            uint64_t q[4];
+            ld_record(packed, pk, s0, C, cols[j], q);
+            feed(w[j], q);
         }
     }
 #pragma unroll

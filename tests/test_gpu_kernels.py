@@ -382,6 +382,17 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
                 num[k, r_] += w_ * (cells[g, c_, k] if valid[c_] else 0.0)
         np.testing.assert_array_equal(direct["den"].cpu().numpy()[:, g], den)
         np.testing.assert_array_equal(direct["num"].cpu().numpy()[:, :, g], num)
+    # 13 counts of up to 365 fit a 16-byte record (9-bit fields); one 730-step period needs 10 bits -> 16-bit fields, 32 bytes
+    assert "packed-counts16" in plan.describe(), plan.describe()
+    whole = np.array([0, T], dtype=np.int64)
+    plan_w = hip.FusedPlan(T, ny * nx, code, whole, np.arange(2), cols)
+    assert "packed-counts32" in plan_w.describe(), plan_w.describe()
+    want_w = cport.block_bins(cube, whole, dda).reshape(1, -1, 13)
+    np.testing.assert_array_equal(np.transpose(plan_w.run_temporal(d).cpu().numpy(), (1, 2, 0)), want_w)
+    dw, pw = plan_w.run(d, csr, want_cells=False), plan_w.run(d, csr, want_cells=True)
+    for key in ("num", "den", "res"):
+        np.testing.assert_array_equal(dw[key].cpu().numpy(), pw[key].cpu().numpy(), err_msg=key)
+    np.testing.assert_array_equal(np.transpose(pw["cells"].cpu().numpy(), (1, 2, 0)), want_w)
     # shuffled slot order and a two-level use (daily mean + annual bins on raw hourly-like groups)
     perm = rng.permutation(13)
     plan2 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [cols[i] for i in perm] + [dict(inner="mean")])
