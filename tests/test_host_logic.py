@@ -199,6 +199,27 @@ def test_transform_dataset_and_multi_dd_keys():
     assert multi_dd_to_dict(["a", "b"], "dd", [[10, 30, 0], [0, 5, 1]]) == (["a", "b"], ["dd_10_30", "dd_0_5"])
 
 
+def test_lat_and_time_windows_on_the_host_route(tmp_path):
+    """`dataset_from_path(lat_window=, time_window=)` without a device: the windows are cut after the host read, on the
+    grid the regions' clip left — the same rows and steps the streaming route would have read."""
+    from aggfly_amd.io import _band_of_box
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    big = np.tile(arr, (3, 3, 2))[:10]                                               # (10, 6, 4)
+    t = pd.date_range("2000-01-01", periods=10, freq="D")
+    la, lo = 10.0 + np.arange(6), 100.0 + np.arange(4)
+    ds = af.Dataset(af.DataArray(big, ["time", "latitude", "longitude"], {"time": t, "latitude": la, "longitude": lo}), lon_is_360=True)
+    store = str(tmp_path / "w.zarr")
+    af.dataset_to_zarr(ds, store, var="v", chunks={"time": 4, "latitude": 3, "longitude": 4})
+    band = af.dataset_from_path(store, "v", lon_is_360=True, lat_window=(2, 5), time_window=(3, 9))
+    assert band.cube().shape == (6, 3, 4) and np.array_equal(band.cube(), big[3:9, 2:5])
+    assert band.latitude.tolist() == la[2:5].tolist() and band.grid.latitude.tolist() == la[2:5].tolist() and band.time.equals(t[3:9])
+    # the stored-axes box of a band inside a clip box, either dimension order
+    assert _band_of_box(("time", "latitude", "longitude"), (10, 6, 4), ("longitude", "latitude"), (1, 5, 0, 4), (1, 3)) == (2, 4, 0, 4)
+    assert _band_of_box(("time", "longitude", "latitude"), (10, 4, 6), ("longitude", "latitude"), None, (2, 6)) == (0, 4, 2, 6)
+    with pytest.raises(ValueError, match="outside"):
+        _band_of_box(("time", "latitude", "longitude"), (10, 6, 4), ("longitude", "latitude"), (1, 5, 0, 4), (0, 5))
+
+
 def test_preprocess_and_unsorted_time():
     arr, time, lat, lon = gi.dataset_360_inputs()
     perm = [2, 0, 3, 1]
