@@ -60,6 +60,7 @@ class Grid:
         self.lon_array, self.lat_array = np.meshgrid(self.longitude, self.latitude)
         self.index = np.arange(self.lon_array.size).reshape(self.lon_array.shape)
         self.cell_id = self.index.flatten()
+        self._cell_key = (id(self.cell_id), "arange", int(self.cell_id.size))     # cheap cache key while cell_id is this very array
 
     @property
     def resolution(self):

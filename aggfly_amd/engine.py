@@ -244,7 +244,9 @@ def get_csr(weights, dataset: Dataset):
     order, _ = dataset.lon_order_to_180()
     # keyed on the table object's identity; a finalizer evicts the entry when the table dies,
     # so a recycled id() can never serve a stale CSR
-    ckey = (id(wdf), len(wdf), ny, nx, _hash(order, np.asarray(weights.grid.cell_id)))
+    ck = getattr(weights.grid, "_cell_key", None)
+    cell_key = ck[1:] if ck is not None and ck[0] == id(weights.grid.cell_id) else _hash(np.asarray(weights.grid.cell_id))
+    ckey = (id(wdf), len(wdf), ny, nx, _hash(order), cell_key)
     hit = _CSR_CACHE.get(ckey)
     if hit is not None:
         return hit
