@@ -332,6 +332,25 @@ def test_info_regions_weights_commands_need_no_gpu(tmp_path):
     assert r.exit_code == 1 and "no precomputed weights found" in r.output
 
 
+def test_single_store_route_needs_a_gpu_and_a_plain_store(tmp_path):
+    """`pipeline.store_route_ok`: the cut-inside-the-store route is for ONE un-templated local Zarr / netCDF-4 store with
+    nestable output frequencies and no time_sel — and only with a GPU; everything else keeps the per-path scheduler."""
+    from aggfly_amd import hip
+    paths, rpath, wpath = _write_run_inputs(tmp_path)
+    c = cfg.parse_config(_run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv")))
+    assert pipeline.store_route_ok(c, c.resolved_paths()) == (hip.device_count() > 0)
+    assert not pipeline.store_route_ok(c, [paths[0], paths[0]])                       # several paths: the year scheduler
+    glob_cfg = cfg.parse_config(_run_config(str(tmp_path / "ds_*.zarr"), rpath, wpath, str(tmp_path / "o.csv")))
+    assert not pipeline.store_route_ok(glob_cfg, glob_cfg.resolved_paths())
+    sel = cfg.parse_config(_run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv")))
+    sel.time_sel = "2000"
+    assert not pipeline.store_route_ok(sel, sel.resolved_paths())
+    weekly = _run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv"))
+    weekly["aggregate"] = {"variables": {"t": [["aggregate", {"calc": "mean", "groupby": "week"}]]}}
+    wk = cfg.parse_config(weekly)
+    assert not pipeline.store_route_ok(wk, wk.resolved_paths())                       # weeks do not nest: no time sharding
+
+
 def test_weights_table_found_in_project_cache(tmp_path):
     """N3: the reference caches weights as {project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather
     (`aggfly/cache/project_cache.py:46-47`); the CLI picks that file up when weights.table is unset."""
