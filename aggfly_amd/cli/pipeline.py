@@ -49,7 +49,7 @@ def store_route_ok(config, paths) -> bool:
     time INSIDE the store: ranks (and, beyond the HBM budget, windows) take runs of output periods
     (`distributed.aggregate_store_sharded`)."""
     from .. import hip, io as afio
-    if len(paths) != 1 or config.time_sel is not None or hip.device_count() == 0:
+    if len(paths) != 1 or hip.device_count() == 0:
         return False
     p = paths[0]
     if not isinstance(p, str) or any(ch in p for ch in "*?[") or "://" in p:
@@ -82,17 +82,29 @@ def run_store(config, path, log=lambda m: None):
         from aggfly_amd import io as afio
         from aggfly_amd.timegroups import resample_groups
         aggd = config.to_aggregator_dict()
-        P = len(resample_groups(afio.read_time_coordinate(path, config.var, config.timecoord), D.output_freq(aggd))[1])
+        tindex = afio.read_time_coordinate(path, config.var, config.timecoord)
+        if config.time_sel is not None:
+            win = afio._time_window(tindex, config.time_sel)
+            tindex = tindex[win[0]:win[1]] if win is not None else tindex
+        P = len(resample_groups(tindex, D.output_freq(aggd))[1])
         if P < world:
             try:
                 log(f"Aggregating {path}: {P} output period(s) < {world} ranks -> latitude bands, one all_reduce")
-                return D.aggregate_store_cells(weights_of, path, config.var, aggd, **_open_kwargs(config, georegions))
+                return D.aggregate_store_cells(weights_of, path, config.var, aggd, time_sel=config.time_sel,
+                                               **_open_kwargs(config, georegions))
             except ValueError as e:           # staged specs, mixed frequencies, fewer rows than ranks: time route
                 log(f"cell sharding not applicable ({e}); falling back to time sharding")
     log(f"Aggregating {path}: output periods split over {world} rank(s), streamed through HBM in windows")
     budget = os.environ.get("AGGFLY_HIP_WINDOW_BYTES")
-    return D.aggregate_store_sharded(weights_of, path, config.var, config.to_aggregator_dict(), engine=config.engine,
-                                     max_window_bytes=int(budget) if budget else None, **_open_kwargs(config, georegions))
+    try:
+        return D.aggregate_store_sharded(weights_of, path, config.var, config.to_aggregator_dict(), engine=config.engine,
+                                         max_window_bytes=int(budget) if budget else None, time_sel=config.time_sel,
+                                         **_open_kwargs(config, georegions))
+    except ValueError as e:
+        if "time_sel" not in str(e):
+            raise
+        log(f"{e}; reading the store whole")
+        return None
 
 
 def load_dataset(config, path, georegions):
@@ -156,7 +168,9 @@ def run_pipeline(config, log=lambda m: None):
     """-> the panel DataFrame (on every rank when distributed)."""
     paths = config.resolved_paths()
     if store_route_ok(config, paths):
-        return run_store(config, paths[0], log)
+        df = run_store(config, paths[0], log)
+        if df is not None:
+            return df
     weights, georegions, sample = compute_weights(config, log)
     aggregator_dict = config.to_aggregator_dict()
     rank, world = D.world()

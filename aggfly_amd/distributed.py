@@ -226,7 +226,8 @@ def aggregate_store_cells(weights_of, path, var, aggregator_dict, group=None, **
     and one all_reduce(SUM) of ``(K+1) x R x P`` doubles assembles the panel on every rank."""
     from . import aggregate as agg, engine as eng, io as afio
     rank, ws = world(group)
-    head = afio.dataset_from_path(path, var, device="cuda", time_window=(0, 0), **open_kwargs)      # grid and coordinates only
+    head_kwargs = {k: v for k, v in open_kwargs.items() if k != "time_sel"}                            # (no steps to select from)
+    head = afio.dataset_from_path(path, var, device="cuda", time_window=(0, 0), **head_kwargs)       # grid and coordinates only
     weights = weights_of(head)
     if len(head.latitude) < ws:
         raise ValueError(f"{ws} ranks for {len(head.latitude)} latitude rows: use fewer ranks or time sharding")
@@ -251,12 +252,20 @@ def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto
     A rank's share that does not fit in HBM is taken in consecutive windows of whole output periods
     (``max_window_bytes``; default: 60 % of the free HBM), each streamed, reduced and released before the next:
     a store of any length runs on one GPU.
-    ``open_kwargs`` go to `dataset_from_path` (``xycoords``, ``lon_is_360``, ``georegions``, ``preprocess`` ...)."""
+    ``open_kwargs`` go to `dataset_from_path` (``xycoords``, ``lon_is_360``, ``georegions``, ``preprocess`` ...);
+    ``time_sel`` among them restricts the job to the selected years before the periods are dealt out."""
     import torch
     from . import aggregate as agg, io as afio
     rank, ws = world(group)
     timecoord = open_kwargs.get("timecoord", "time")
     tindex = afio.read_time_coordinate(path, var, timecoord)
+    # a time selection (`Dataset(time_sel=...)`, `dataset.py:88-92`) narrows the job to one contiguous run of steps first
+    k_off, time_sel = 0, open_kwargs.pop("time_sel", None)
+    if time_sel is not None:
+        win = afio._time_window(tindex, time_sel)
+        if win is None:
+            raise ValueError("time_sel does not pick one contiguous run of this store's time axis")
+        k_off, tindex = int(win[0]), tindex[int(win[0]):int(win[1])]
     freq = output_freq(aggregator_dict)
     bounds, labels = resample_groups(tindex, freq)
     P = len(labels)
@@ -269,7 +278,7 @@ def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto
     weights, parts, region_ids = None, [], None
     # an empty share still opens the store (coordinates, grid) so that every rank builds the same weights
     for q_lo, q_hi in (windows or [(p_lo, p_lo)]):
-        k_lo, k_hi = int(bounds[q_lo]), int(bounds[q_hi])
+        k_lo, k_hi = k_off + int(bounds[q_lo]), k_off + int(bounds[q_hi])
         local = afio.dataset_from_path(path, var, device="cuda", time_window=(k_lo, k_hi), **open_kwargs)
         if weights is None:
             weights = weights_of(local)

@@ -249,6 +249,26 @@ def test_run_single_store_is_cut_inside_the_store(torch_cuda, tmp_path):
         outs[tag] = pd.read_csv(out)
     assert len(outs["y1"]) == 1
     pd.testing.assert_frame_equal(outs["y1"], outs["y2"], rtol=1e-12, atol=0)
+    # dataset.time_sel on the single-store routes: the long store restricted to 2002 — monthly periods over two ranks
+    # (time route) and one annual period over two ranks (latitude bands) — equals the API call on Dataset(time_sel="2002")
+    ds_sel = af.dataset_from_path(store, var="t2m", lon_is_360=False, georegions=gr, name="t2m", preprocess=lambda x: x - 273.15, time_sel="2002")
+    for tag, agg_cfg, groupby in (("selm", None, "month"), ("sely", annual, "year")):
+        want = af.aggregate_dataset(dataset=ds_sel, weights=w, tavg=[("aggregate", {"calc": "mean", "groupby": "date"}),
+                                                                      ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                                                                      ("aggregate", {"calc": "sum", "groupby": groupby})])
+        out = str(tmp_path / f"panel_{tag}.csv")
+        cpath = tmp_path / f"config_{tag}.yaml"
+        raw = _run_config(store, rpath, wpath, out) if agg_cfg is None else _run_config(store, rpath, wpath, out, aggregate=agg_cfg)
+        raw["dataset"]["time_sel"] = "2002"
+        cpath.write_text(yaml.safe_dump(raw))
+        cmd = two[:8] + [str(_free_port())] + two[9:]
+        r = subprocess.run(cmd + ["run", str(cpath), "-v"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PYTHONPATH=root, AGGFLY_DIST_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("latitude bands" in r.stdout) == (tag == "sely"), r.stdout
+        got = pd.read_csv(out, parse_dates=["time"])
+        assert len(got) == len(want) and got["time"].tolist() == pd.DatetimeIndex(want["time"]).tolist(), tag
+        np.testing.assert_allclose(got[["tavg_1", "tavg_2"]].values, want[["tavg_1", "tavg_2"]].values, rtol=1e-12, err_msg=tag)
 
 
 def _free_port():
@@ -334,7 +354,7 @@ def test_info_regions_weights_commands_need_no_gpu(tmp_path):
 
 def test_single_store_route_needs_a_gpu_and_a_plain_store(tmp_path):
     """`pipeline.store_route_ok`: the cut-inside-the-store route is for ONE un-templated local Zarr / netCDF-4 store with
-    nestable output frequencies and no time_sel — and only with a GPU; everything else keeps the per-path scheduler."""
+    nestable output frequencies — and only with a GPU; everything else keeps the per-path scheduler."""
     from aggfly_amd import hip
     paths, rpath, wpath = _write_run_inputs(tmp_path)
     c = cfg.parse_config(_run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv")))
@@ -342,9 +362,6 @@ def test_single_store_route_needs_a_gpu_and_a_plain_store(tmp_path):
     assert not pipeline.store_route_ok(c, [paths[0], paths[0]])                       # several paths: the year scheduler
     glob_cfg = cfg.parse_config(_run_config(str(tmp_path / "ds_*.zarr"), rpath, wpath, str(tmp_path / "o.csv")))
     assert not pipeline.store_route_ok(glob_cfg, glob_cfg.resolved_paths())
-    sel = cfg.parse_config(_run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv")))
-    sel.time_sel = "2000"
-    assert not pipeline.store_route_ok(sel, sel.resolved_paths())
     weekly = _run_config(paths[0], rpath, wpath, str(tmp_path / "o.csv"))
     weekly["aggregate"] = {"variables": {"t": [["aggregate", {"calc": "mean", "groupby": "week"}]]}}
     wk = cfg.parse_config(weekly)
