@@ -393,6 +393,19 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     for key in ("num", "den", "res"):
         np.testing.assert_array_equal(dw[key].cpu().numpy(), pw[key].cpu().numpy(), err_msg=key)
     np.testing.assert_array_equal(np.transpose(pw["cells"].cpu().numpy(), (1, 2, 0)), want_w)
+    # 32-byte records through the TILED panel kernel (>= 4 periods) and the direct gather: four periods of 1,200 steps
+    T4 = 4800
+    cube4 = rng.normal(14, 12, (T4, ny, nx)).astype(dtype)
+    cube4[rng.integers(0, T4, 40), rng.integers(0, ny, 40), rng.integers(0, nx, 40)] = np.nan
+    b4 = np.arange(0, T4 + 1, 1200, dtype=np.int64)
+    d4 = torch_cuda.from_numpy(cube4).cuda()
+    plan4 = hip.FusedPlan(T4, ny * nx, code, b4, np.arange(5), cols)
+    assert "packed-counts32" in plan4.describe(), plan4.describe()
+    want4 = cport.block_bins(cube4, b4, dda).reshape(4, -1, 13)
+    d_, p_ = plan4.run(d4, csr, want_cells=False), plan4.run(d4, csr, want_cells=True)
+    np.testing.assert_array_equal(np.transpose(p_["cells"].cpu().numpy(), (1, 2, 0)), want4)
+    for key in ("num", "den", "res"):
+        np.testing.assert_array_equal(d_[key].cpu().numpy(), p_[key].cpu().numpy(), err_msg=key)
     # shuffled slot order and a two-level use (daily mean + annual bins on raw hourly-like groups)
     perm = rng.permutation(13)
     plan2 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [cols[i] for i in perm] + [dict(inner="mean")])
