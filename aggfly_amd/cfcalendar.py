@@ -134,6 +134,53 @@ class CFTimeIndex:
     def argsort(self):
         return np.argsort(self.seconds, kind="stable")
 
+    # ---- label selection (what ``da.sel(time=...)`` does on an xarray CFTimeIndex) ----
+    def _partial_span(self, label):
+        """[lo, hi) in seconds for a partial date string ('2000', '2000-06', '2000-06-15', '2000-06-15T12', ...) — the
+        whole year / month / day / hour it names — or the single instant of a `CFDatetime`."""
+        if isinstance(label, CFDatetime):
+            if label.calendar != self.calendar:
+                raise ValueError(f"time_sel is on calendar {label.calendar!r}, the index on {self.calendar!r}")
+            t = CFTimeIndex.from_fields([label.year], [label.month], [label.day], [label.hour], [label.minute], [label.second],
+                                        calendar=self.calendar).seconds[0]
+            return int(t), int(t) + 1
+        m = re.fullmatch(r"\s*(-?\d{1,4})(?:-(\d{1,2})(?:-(\d{1,2})(?:[ T](\d{1,2})(?::(\d{1,2})(?::(\d{1,2}))?)?)?)?)?\s*", str(label))
+        if not m:
+            raise ValueError(f"cannot parse time selection {label!r} on a CF calendar")
+        f = [int(g) if g is not None else None for g in m.groups()]
+        md = month_days(self.calendar)
+        y = f[0]
+        mo, d, hh, mi, ss = (f[1] or 1), (f[2] or 1), (f[3] or 0), (f[4] or 0), (f[5] or 0)
+        lo = int(CFTimeIndex.from_fields([y], [mo], [d], [hh], [mi], [ss], calendar=self.calendar).seconds[0])
+        if f[1] is None:
+            width = year_days(self.calendar) * 86400
+        elif f[2] is None:
+            width = md[mo - 1] * 86400
+        elif f[3] is None:
+            width = 86400
+        elif f[4] is None:
+            width = 3600
+        elif f[5] is None:
+            width = 60
+        else:
+            width = 1
+        return lo, lo + width
+
+    def sel_positions(self, time_sel):
+        """Positions selected by ``time_sel``: a partial date string selects everything inside the year / month / day it
+        names; a slice of two such labels is inclusive at both ends (xarray's partial-datetime-string indexing)."""
+        if isinstance(time_sel, slice):
+            lo = self._partial_span(time_sel.start)[0] if time_sel.start is not None else None
+            hi = self._partial_span(time_sel.stop)[1] if time_sel.stop is not None else None
+        else:
+            lo, hi = self._partial_span(time_sel)
+        keep = np.ones(len(self), dtype=bool)
+        if lo is not None:
+            keep &= self.seconds >= lo
+        if hi is not None:
+            keep &= self.seconds < hi
+        return np.nonzero(keep)[0]
+
     def to_list(self):
         return list(self)
 

@@ -192,8 +192,11 @@ def _maybe_init_distributed():
             ndev = torch.cuda.device_count()
             if ndev:
                 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
-            # RCCL needs one GPU per rank; fewer GPUs than ranks (a rehearsal box) falls back to gloo
-            backend = os.environ.get("AGGFLY_DIST_BACKEND", "nccl" if ndev >= int(os.environ["WORLD_SIZE"]) else "gloo")
+            from aggfly_amd.distributed import choose_backend
+            backend = choose_backend(ndev, os.environ.get("AGGFLY_DIST_BACKEND"))
+            if int(os.environ.get("RANK", "0")) == 0:
+                click.echo(f"torch.distributed backend: {backend} ({ndev} GPU(s) visible on this node, "
+                           f"{os.environ.get('LOCAL_WORLD_SIZE', os.environ['WORLD_SIZE'])} local rank(s))", err=True)
             dist.init_process_group(backend)
 
 

@@ -131,10 +131,21 @@ def blosc_decode_many(bufs, outs, threads: int = 8):
 KIND = {"raw": 0, "blosc": 1, "zstd": 2, "zlib": 3, "gzip": 3, "lz4": 4}
 
 
-def decode_files(kind: str, paths, outs, threads: int = 8):
+def _require_full(what, names, outs, res):
+    """A present chunk must fill its destination exactly: a Blosc header announcing fewer bytes, a truncated raw file or
+    a zstd / zlib frame that decodes short would otherwise leave the rest of a (re-used, page-locked) staging slot to
+    travel to HBM as data.  zarr / numcodecs raise on such chunks (`aggfly/dataset/dataset.py:697-728` reads through them)."""
+    short = [(names[i], int(res[i]), outs[i].nbytes) for i in range(len(outs)) if res[i] != -100 and int(res[i]) != outs[i].nbytes]
+    if short:
+        nm, got, want = short[0]
+        raise CodecError(f"{what}: chunk {nm} decoded to {got} bytes, expected {want}"
+                         + (f" (and {len(short) - 1} more)" if len(short) > 1 else ""))
+
+
+def decode_files(kind: str, paths, outs, threads: int = 8, exact: bool = True):
     """Read and decode the chunk files ``paths[i]`` (all of codec ``kind``: raw / blosc / zstd / zlib /
     gzip) into ``outs[i]`` on an OpenMP team.  -> list of decoded sizes; -100 marks a missing file (the
-    caller applies the fill value)."""
+    caller applies the fill value).  ``exact``: a present chunk must decode to exactly ``outs[i].nbytes``."""
     lib = load()
     n = len(paths)
     pp = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
@@ -144,13 +155,15 @@ def decode_files(kind: str, paths, outs, threads: int = 8):
     if lib.afcodec_decode_files(KIND[kind], n, pp, dp, ds, int(threads), res):
         bad = [paths[i] for i in range(n) if res[i] < 0 and res[i] != -100]
         raise CodecError(f"decode_files({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+    if exact:
+        _require_full(f"decode_files({kind})", paths, outs, res)
     return [int(res[i]) for i in range(n)]
 
 
-def decode_ranges(kind: str, locators, outs, threads: int = 8):
+def decode_ranges(kind: str, locators, outs, threads: int = 8, exact: bool = True):
     """Like `decode_files` for ``locators[i] = (path, offset, nbytes)`` — nbytes < 0 = the whole file, None =
     an absent chunk (reported as -100 without touching the disk).  ``kind`` may be a pair ``(codec, element_size)``:
-    the codec's output is then byte-unshuffled (HDF5 shuffle + deflate chunks)."""
+    the codec's output is then byte-unshuffled (HDF5 shuffle + deflate chunks).  ``exact`` as in `decode_files`."""
     lib = load()
     n = len(locators)
     pp = (C.c_char_p * n)(*[os.fsencode(l[0]) if l is not None else b"" for l in locators])
@@ -163,6 +176,8 @@ def decode_ranges(kind: str, locators, outs, threads: int = 8):
     if lib.afcodec_decode_ranges(code, n, pp, offs, lens, dp, ds, int(threads), res):
         bad = [locators[i] for i in range(n) if res[i] < 0 and res[i] != -100]
         raise CodecError(f"decode_ranges({kind}): {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+    if exact:
+        _require_full(f"decode_ranges({kind})", locators, outs, res)
     return [int(res[i]) for i in range(n)]
 
 

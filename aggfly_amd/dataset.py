@@ -146,12 +146,7 @@ class Dataset:
             if isinstance(loc, (int, np.integer)):
                 loc = slice(loc, loc + 1)
             return da.isel(time=loc if isinstance(loc, slice) else np.asarray(loc))
-        y = np.asarray(t.fields()[0])
-        if isinstance(time_sel, slice):
-            lo = int(str(time_sel.start)[:4]) if time_sel.start is not None else y.min()
-            hi = int(str(time_sel.stop)[:4]) if time_sel.stop is not None else y.max()
-            return da.isel(time=np.nonzero((y >= lo) & (y <= hi))[0])
-        return da.isel(time=np.nonzero(y == int(str(time_sel)[:4]))[0])
+        return da.isel(time=t.sel_positions(time_sel))       # CF calendar: year / month / day granular, like xarray
 
     # ---- the engine's view ----
     def cube(self):

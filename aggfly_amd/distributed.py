@@ -38,6 +38,17 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def choose_backend(n_devices: int, override=None) -> str:
+    """"nccl" (RCCL over xGMI) when this NODE has one GPU per local rank, else "gloo" (a rehearsal of N ranks on fewer
+    cards).  The local device count is compared with LOCAL_WORLD_SIZE — the ranks torchrun started on this node — not
+    with the global WORLD_SIZE: 2 nodes x 8 GPUs (WORLD_SIZE 16) is an RCCL job.  ``override`` (an environment
+    switch of the caller) wins."""
+    if override:
+        return override
+    local = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE", "1"))
+    return "nccl" if n_devices >= local else "gloo"
+
+
 def split_even(n: int, rank: int, world_size: int):
     """Contiguous balanced split of range(n): -> (lo, hi)."""
     base, extra = divmod(n, world_size)
@@ -73,8 +84,51 @@ def time_shard_bounds(tindex, freq: str, rank: int, world_size: int):
     return int(bounds[p_lo]), int(bounds[p_hi]), p_lo, p_hi, P
 
 
+def label_positions(local_labels, labels):
+    """Position of every local output label in ``labels`` (exact match; a label that is not there is an error)."""
+    import pandas as pd
+    from .cfcalendar import CFTimeIndex
+    if len(local_labels) == 0:
+        return np.zeros(0, dtype=np.int64)
+    if isinstance(labels, CFTimeIndex) or isinstance(local_labels, CFTimeIndex):
+        if not (isinstance(labels, CFTimeIndex) and isinstance(local_labels, CFTimeIndex) and labels.calendar == local_labels.calendar):
+            raise ValueError("local and global output labels are on different calendars")
+        pos = np.searchsorted(labels.seconds, local_labels.seconds)
+        ok = (pos < len(labels)) & (labels.seconds[np.minimum(pos, len(labels) - 1)] == local_labels.seconds)
+    else:
+        pos = pd.DatetimeIndex(labels).get_indexer(pd.DatetimeIndex(local_labels))
+        ok = pos >= 0
+    if not bool(np.all(ok)):
+        raise ValueError("a shard produced an output period that the whole time axis does not have")
+    return np.asarray(pos, dtype=np.int64)
+
+
+def place_by_label(res_local, local_labels, labels, p_lo: int, p_hi: int):
+    """``res_local[K, R, P_local]`` (periods ``local_labels``) -> a NaN-filled block ``[K, R, p_hi - p_lo]`` whose
+    period axis is ``labels[p_lo:p_hi]``.
+
+    A shard's own time slice runs from its first to its last time stamp, so resample bins of the whole axis that are
+    EMPTY at the start or end of the share (seasonal data: June-August only; gaps on a shard or window boundary) do not
+    exist locally: the local result has fewer periods than the share and must be placed by label, not by position.
+    Periods without data stay NaN — what the unsharded run gives an empty resample bin (`nb_kernels.py:138-141`)."""
+    import torch
+    n = int(p_hi - p_lo)
+    pos = label_positions(local_labels, labels) - int(p_lo)
+    if len(pos) != res_local.shape[2]:
+        raise ValueError(f"shard result has {res_local.shape[2]} periods but {len(pos)} labels")
+    if len(pos) and (pos.min() < 0 or pos.max() >= n):
+        raise ValueError("a shard produced an output period outside its own share of the time axis")
+    if len(pos) == n and bool(np.array_equal(pos, np.arange(n))):
+        return res_local
+    block = torch.full((res_local.shape[0], res_local.shape[1], n), float("nan"), dtype=res_local.dtype, device=res_local.device)
+    if len(pos):
+        block.index_copy_(2, torch.as_tensor(pos, device=res_local.device), res_local)
+    return block
+
+
 def gather_panel(res_local, p_counts, group=None):
-    """all_gather of per-rank ``res[K, R, P_local]`` tensors with different P_local.
+    """all_gather of per-rank ``res[K, R, P_local]`` tensors with different P_local (every rank's block must span
+    exactly its share of the output periods: see `place_by_label`).
 
     Every rank pads to max(P_local), one all_gather moves the padded blocks (RCCL over xGMI
     on GPUs), and the blocks are trimmed and concatenated along the period axis.
@@ -82,6 +136,8 @@ def gather_panel(res_local, p_counts, group=None):
     import torch
     dist = _dist()
     rank, ws = world(group)
+    if res_local.shape[2] != int(p_counts[rank]):
+        raise ValueError(f"rank {rank}: local panel has {res_local.shape[2]} periods, its share has {int(p_counts[rank])}")
     if ws == 1:
         return res_local
     pmax = int(max(p_counts))
@@ -166,10 +222,10 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
         _, fused_cols, _, names = agg._lower_all(aggregator_dict)
         csr, region_ids = eng.get_csr(weights, dataset)
         if k_hi > k_lo:
-            res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
+            res, names, region_ids, local_labels = agg.panel_arrays(weights, local, aggregator_dict, engine)
         else:
-            res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
-        full = gather_panel(res, counts, group)
+            res, local_labels = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda"), labels[:0]
+        full = gather_panel(place_by_label(res, local_labels, labels, p_lo, p_hi), counts, group)
     elif shard == "cells":
         ny = len(dataset.latitude)
         y0, y1 = split_even(ny, rank, ws)
@@ -283,16 +339,18 @@ def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto
         if weights is None:
             weights = weights_of(local)
         if k_hi > k_lo:
-            res, names, region_ids, _ = agg.panel_arrays(weights, local, aggregator_dict, engine)
-            parts.append(res)
+            res, names, region_ids, local_labels = agg.panel_arrays(weights, local, aggregator_dict, engine)
         else:
             from . import engine as eng
             _, region_ids = eng.get_csr(weights, local)
+            res, local_labels = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda"), labels[:0]
+        # by label: a window that starts or ends on empty resample bins has fewer local periods than q_hi - q_lo
+        parts.append(place_by_label(res, local_labels, labels, q_lo, q_hi))
+        # the window's kernels must have finished reading the cube before its block goes back to the allocator:
+        # the next window's copy stream writes into (very likely) the same block
+        torch.cuda.current_stream().synchronize()
         del local                                                      # the window's cube is released before the next is read
-    if parts:
-        res = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
-    else:
-        res = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda")
+    res = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
     full = gather_panel(res, counts, group)
     df = agg._assemble_frame(full, names, region_ids, labels, weights)
     return agg._merge_regions(df, weights)

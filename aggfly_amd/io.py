@@ -385,6 +385,9 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     stage_t = [b[:slab_steps * row].view(tdt).reshape((slab_steps,) + tuple(spatial)) for b in _pinned_stage(slab_steps * row, nstage)]
     stage = [t.numpy() for t in stage_t]
     copy_stream = torch.cuda.Stream(device=device)
+    # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
+    # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
+    copy_stream.wait_stream(torch.cuda.current_stream(device))
     done = [None, None]
     for i, k0 in enumerate(range(0, T, slab_steps)):
         k1 = min(T, k0 + slab_steps)
@@ -537,6 +540,9 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     host = _pinned_stage(per * cb, nstage)
     dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
     copy_stream = torch.cuda.Stream(device=device)
+    # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
+    # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
+    copy_stream.wait_stream(torch.cuda.current_stream(device))
     done = [None, None]
     for b, lo in enumerate(range(0, len(idxs), per)):
         batch = idxs[lo:lo + per]
@@ -999,13 +1005,7 @@ def _time_window(tindex, time_sel):
                 k0, k1, _ = loc.indices(n)
                 return (k0, k1) if k1 > k0 else (0, 0)          # nothing selected in this store: nothing is read
             return None
-        y = np.asarray(tindex.fields()[0])
-        if isinstance(time_sel, slice):
-            lo = int(str(time_sel.start)[:4]) if time_sel.start is not None else y.min()
-            hi = int(str(time_sel.stop)[:4]) if time_sel.stop is not None else y.max()
-            idx = np.nonzero((y >= lo) & (y <= hi))[0]
-        else:
-            idx = np.nonzero(y == int(str(time_sel)[:4]))[0]
+        idx = tindex.sel_positions(time_sel)             # the exact selection `Dataset(time_sel=)` applies on a CF calendar
         if len(idx) == 0:
             return 0, 0
         if idx[-1] - idx[0] + 1 == len(idx):

@@ -248,3 +248,41 @@ def test_zarr_format_3_sharded_store(tmp_path, compress):
     got = afio.ZarrArray(os.path.join(store, "t2m")).read()
     assert np.isnan(got[24:48]).all()
     np.testing.assert_array_equal(got[:24], cube[:24])
+
+
+def test_short_chunks_are_refused(tmp_path):
+    """A present chunk must decode to exactly the chunk size: a truncated raw file, a zstd frame of fewer bytes or a Blosc
+    chunk whose header announces less than the array's chunk would otherwise leave stale staging bytes to travel on as
+    data (zarr / numcodecs raise on such chunks too)."""
+    import pyarrow as pa
+    rng = np.random.default_rng(9)
+    data = rng.normal(size=(48, 6, 8))
+    cb = 24 * 6 * 8 * 8
+    # raw store, second chunk file cut short
+    files = {"0.0.0": data[:24].tobytes(), "1.0.0": data[24:].tobytes()[:cb - 64]}
+    _zarr_v2_from_chunks(str(tmp_path), "r", data.shape, (24, 6, 8), "<f8", None, files, ("time", "latitude", "longitude"))
+    za = afio.ZarrArray(os.path.join(str(tmp_path), "r"))
+    assert za.native_kind == "raw"
+    outs = [np.empty((24, 6, 8)), np.empty((24, 6, 8))]
+    locs = [za.chunk_locator((0, 0, 0)), za.chunk_locator((1, 0, 0))]
+    with pytest.raises(codec.CodecError, match=r"1\.0\.0.*decoded to 9152 bytes, expected 9216"):
+        codec.decode_ranges("raw", locs, outs, threads=2)
+    assert codec.decode_ranges("raw", locs, outs, threads=2, exact=False) == [9216, 9152]      # the old, lenient answer
+    # zstd frame holding 23 of the 24 steps
+    files = {"0.0.0": pa.Codec("zstd").compress(data[:24].tobytes(), asbytes=True),
+             "1.0.0": pa.Codec("zstd").compress(data[24:47].tobytes(), asbytes=True)}
+    _zarr_v2_from_chunks(str(tmp_path), "z", data.shape, (24, 6, 8), "<f8", {"id": "zstd", "level": 1}, files,
+                         ("time", "latitude", "longitude"))
+    zz = afio.ZarrArray(os.path.join(str(tmp_path), "z"))
+    with pytest.raises(codec.CodecError, match="decoded to 8832 bytes, expected 9216"):
+        codec.decode_ranges("zstd", [zz.chunk_locator((0, 0, 0)), zz.chunk_locator((1, 0, 0))], outs, threads=2)
+    # Blosc chunk (written by the in-tree encoder) of fewer elements than the array's chunk
+    files = {"0.0.0": codec.blosc_encode(data[:24].tobytes(), 8), "1.0.0": codec.blosc_encode(data[24:40].tobytes(), 8)}
+    _zarr_v2_from_chunks(str(tmp_path), "b", data.shape, (24, 6, 8), "<f8",
+                         {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}, files, ("time", "latitude", "longitude"))
+    zb = afio.ZarrArray(os.path.join(str(tmp_path), "b"))
+    with pytest.raises(codec.CodecError, match="expected 9216"):
+        codec.decode_files("blosc", [zb.chunk_locator((i, 0, 0))[0] for i in range(2)], outs, threads=2)
+    # an absent chunk is not a short chunk
+    os.remove(za.chunk_locator((1, 0, 0))[0])
+    assert codec.decode_ranges("raw", [za.chunk_locator((0, 0, 0)), za.chunk_locator((1, 0, 0))], outs, threads=2) == [9216, -100]

@@ -46,11 +46,38 @@ def _full_res(cube, time, tab, ncells):
         return np.where(den[None] != 0, num / den[None], np.nan), labels
 
 
+def _seasonal_case():
+    """Daily June-August data of 2000-2002: the months September-May are empty resample bins, and with three ranks the
+    share boundaries (27 monthly periods -> 9 each) fall INSIDE those gaps: rank 1's share runs 2001-03 .. 2001-11 but
+    its data only 2001-06 .. 2001-08."""
+    days = pd.DatetimeIndex(np.concatenate([pd.date_range(f"{y}-06-01", f"{y}-08-31", freq="D") for y in (2000, 2001, 2002)]))
+    ny, nx = 6, 7
+    cube = synth.temperature_cube(len(days), ny, nx, seed=41, ocean_frac=0.1, scattered_nan=12)
+    tab = synth.weights_table(ny, nx, 5, seed=42, secondary=True)
+    return cube, days, tab, ny, nx
+
+
 def _worker(rank, ws, port, mode, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     try:
+        if mode == "time_gaps":
+            cube, time, tab, ny, nx = _seasonal_case()
+            want, labels = _full_res(cube, time, tab, ny * nx)
+            k_lo, k_hi, p_lo, p_hi, P = D.time_shard_bounds(time, "ME", rank, ws)
+            assert P == len(labels) == 27
+            counts = [D.split_even(P, r, ws)[1] - D.split_even(P, r, ws)[0] for r in range(ws)]
+            local, local_labels = _full_res(cube[k_lo:k_hi], time[k_lo:k_hi], tab, ny * nx)
+            assert local.shape[2] < p_hi - p_lo                      # leading / trailing empty bins are not there locally
+            block = D.place_by_label(torch.from_numpy(local), local_labels, labels, p_lo, p_hi)
+            full = D.gather_panel(block, counts).numpy()
+            np.testing.assert_array_equal(full, want)
+            assert np.isnan(want[:, :, 3:12]).all() and not np.isnan(want[:, :, 12:15]).all()      # Sept-May empty, JJA 2001 there
+            with pytest.raises(ValueError, match="periods"):        # the unplaced block is refused, not shifted
+                D.gather_panel(torch.from_numpy(local), counts)
+            q.put((rank, "ok"))
+            return
         cube, time, tab, ny, nx = _case()
         want, labels = _full_res(cube, time, tab, ny * nx)
         if mode == "time":
@@ -94,6 +121,39 @@ def test_world2_exchange(mode):
     for p in procs:
         p.join(30)
     assert sorted(out) == [(0, "ok"), (1, "ok")], out
+
+
+def test_world3_time_shards_with_gaps_on_the_boundaries():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, "time_gaps", q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(out) == [(0, "ok"), (1, "ok"), (2, "ok")], out
+
+
+def test_place_by_label():
+    from aggfly_amd.cfcalendar import cf_range
+    labels = pd.date_range("2001-01-31", periods=12, freq="ME")
+    res = torch.arange(2 * 3 * 3, dtype=torch.float64).reshape(2, 3, 3)
+    blk = D.place_by_label(res, labels[5:8], labels, 2, 11)
+    assert blk.shape == (2, 3, 9) and torch.equal(blk[:, :, 3:6], res)
+    assert torch.isnan(blk[:, :, :3]).all() and torch.isnan(blk[:, :, 6:]).all()
+    assert D.place_by_label(res, labels[2:5], labels, 2, 5) is res               # already in place: no copy
+    empty = D.place_by_label(res[:, :, :0], labels[:0], labels, 4, 6)
+    assert empty.shape == (2, 3, 2) and torch.isnan(empty).all()
+    with pytest.raises(ValueError, match="outside its own share"):
+        D.place_by_label(res, labels[5:8], labels, 6, 11)
+    with pytest.raises(ValueError, match="does not have"):
+        D.place_by_label(res, pd.date_range("2001-01-15", periods=3, freq="D"), labels, 0, 12)
+    _, cf = resample_groups(cf_range("2001-01-01", 720, "D", "360_day"), "ME")
+    blk = D.place_by_label(res, cf[7:10], cf, 6, 12)
+    assert blk.shape == (2, 3, 6) and torch.equal(blk[:, :, 1:4], res)
+    assert list(D.label_positions(cf[3:5], cf)) == [3, 4]
 
 
 def test_shard_maths_single_process():

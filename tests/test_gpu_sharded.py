@@ -181,3 +181,75 @@ def test_store_cell_sharding_reads_only_its_band(torch_cuda, tmp_path):
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, rtol=1e-12, atol=0)
+
+
+SEASONAL_SCRIPT = r'''
+import os, sys
+import numpy as np, pandas as pd, torch, torch.distributed as dist
+import aggfly_amd as af
+from aggfly_amd import synth, distributed as D
+
+store, out = sys.argv[1], sys.argv[2]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    dist.init_process_group("gloo")
+ny, nx = 6, 8
+tab = synth.weights_table(ny, nx, 5, seed=72, secondary=True)
+gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+spec = dict(t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+               ("aggregate", {"calc": "sum", "groupby": "month"})],
+            hot=[("aggregate", {"calc": "bins", "groupby": "month", "ddargs": [25, 99, 0]})])
+weights_of = lambda ds: af.weights_from_objects(ds, gr, table=tab)
+if dist.is_initialized() or os.environ.get("WINDOW_BYTES"):
+    wb = os.environ.get("WINDOW_BYTES")
+    df = D.aggregate_store_sharded(weights_of, store, "t2m", spec, lon_is_360=True, max_window_bytes=int(wb) if wb else None)
+else:
+    ds = af.dataset_from_path(store, "t2m", lon_is_360=True, device="cuda")
+    df = af.aggregate_dataset(dataset=ds, weights=weights_of(ds), aggregator_dict=spec)
+if os.environ.get("RESIDENT_SHARDED"):
+    ds = af.dataset_from_path(store, "t2m", lon_is_360=True, device="cuda")
+    df2 = D.aggregate_dataset_sharded(weights_of(ds), ds, spec, shard="time")
+    pd.testing.assert_frame_equal(df, df2, check_exact=True)
+if D.world()[0] == 0:
+    df.to_csv(out, index=False)
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def test_seasonal_store_gaps_on_shard_and_window_boundaries(torch_cuda, tmp_path):
+    """Daily June-August data of three years: the nine months between the seasons are empty resample bins.  Shares of
+    three ranks and HBM windows then begin or end INSIDE a gap, where the local time slice has fewer periods than the
+    share: results must be placed by label (`distributed.place_by_label`), never by position."""
+    import numpy as np
+    import aggfly_amd as af
+    from aggfly_amd import synth
+    days = pd.DatetimeIndex(np.concatenate([pd.date_range(f"{y}-06-01", f"{y}-08-31", freq="D") for y in (2000, 2001, 2002)]))
+    ny, nx = 6, 8
+    cube = synth.temperature_cube(len(days), ny, nx, dtype=np.float32, seed=71, ocean_frac=0.1, scattered_nan=10)
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": days, "latitude": 30 + 0.25 * np.arange(ny), "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+    store = str(tmp_path / "jja.zarr")
+    af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 40, "latitude": ny, "longitude": nx})
+    script = tmp_path / "seasonal_job.py"
+    script.write_text(SEASONAL_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, AGGFLY_HIP_EXACT_ORDER="1")
+    one, three, win, both = (str(tmp_path / f"{n}.csv") for n in ("one", "three", "win", "both"))
+    r = subprocess.run([sys.executable, str(script), store, one], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = pd.read_csv(one)
+    assert len(a) > 0 and a["time"].nunique() == 9                                   # the 18 empty months are dropped rows
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(launch + ["--master-port", str(_free_port()), str(script), store, three], capture_output=True, text=True,
+                       timeout=300, env=dict(env, RESIDENT_SHARDED="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    pd.testing.assert_frame_equal(a, pd.read_csv(three), check_exact=True)
+    # windows of at most 40 days of steps: (June), (July), (August + the nine empty months), ...
+    wb = str(40 * ny * nx * 4)
+    r = subprocess.run([sys.executable, str(script), store, win], capture_output=True, text=True, timeout=300, env=dict(env, WINDOW_BYTES=wb))
+    assert r.returncode == 0, r.stderr[-2000:]
+    pd.testing.assert_frame_equal(a, pd.read_csv(win), check_exact=True)
+    r = subprocess.run(launch + ["--master-port", str(_free_port()), str(script), store, both], capture_output=True, text=True,
+                       timeout=300, env=dict(env, WINDOW_BYTES=wb))
+    assert r.returncode == 0, r.stderr[-2000:]
+    pd.testing.assert_frame_equal(a, pd.read_csv(both), check_exact=True)
