@@ -483,7 +483,11 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // short inner groups: the direct path keeps DEPTH rows in flight only INSIDE a group, the LDS-DMA ring
     // prefetches across group ends.  Measured (mean plan, 721x1440 / 1801x3600): 2-step groups f64 4.5 vs
     // 6.0 TB/s, f32 3.5 vs 4.3; 4-step groups f32 4.4 vs 5.6, f64 equal; 8 steps and longer: equal.
-    {
+    // every inner group exactly two rows ((tmin, tmax) pairs) and min / max / sine columns: the pair-mode variants of the
+    // direct-load path keep DEPTH / 2 whole groups in flight, so they need no ring either
+    bool pairs = desc->G1 > 0 && desc->T == 2 * desc->G1 && pl->nthr == 0 && pl->stat == 2 && !getenv("AFHIP_NO_PAIR_MODE");
+    for (int64_t g = 0; pairs && g < desc->G1; ++g) pairs = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == 2;
+    if (!pairs) {
         const double avg_group = desc->G1 > 0 ? (double)desc->T / (double)desc->G1 : 0.0;
         const int vec16 = desc->dtype == AFHIP_F64 ? 2 : 4;
         bool sine = false;                          // sine_dd on short windows is fp64-VALU-bound: direct loads measured 4 % faster
@@ -557,10 +561,11 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
     const bool partition = pl->hb_n > 0 && want_pipe == 0;
     const bool arith = partition && pl->hb_arith;
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith);
+    pairs = pairs && want_pipe == 0;
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
-        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith);
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith);
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);

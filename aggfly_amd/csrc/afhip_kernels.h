@@ -209,13 +209,13 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 // half-angle identity asin(x) = pi/2 - 2 asin(sqrt((1-x)/2)).  One sqrt + 11 FMAs instead of
 // the library's ~70-instruction routines: sine_dd needs one of these per threshold per
 // cell-day and was bound by them.  |x| > 1 yields NaN like the library functions.
-// d = a * b + c as ONE three-address v_fma_f64.  For a Horner chain whose coefficients live in
-// registers hipcc otherwise emits v_mov_b64 + v_fmac_f64 per term (the two-address form clobbers
-// the coefficient), doubling the polynomial's VALU cost.
+// d = a * b + c as ONE three-address v_fma_f64 with the (wave-uniform) addend c in a scalar register pair.  For a Horner
+// chain hipcc otherwise emits v_mov_b64 + v_fmac_f64 per term (the two-address form clobbers the coefficient), doubling
+// the polynomial's VALU cost; with a "v" constraint the coefficients pin 2 VGPRs each (30 for the degree-14 asin).
 __device__ __forceinline__ double fma3(double a, double b, double c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 #else
     return __builtin_fma(a, b, c);
@@ -254,35 +254,79 @@ __device__ __forceinline__ double asin_fast(double x) {
     return copysign(small ? r : HALF_PI - 2.0 * r, x);
 }
 
-// Single-sine degree-day "parts" (nb_kernels.py:224-249), with the reference's nested
-// transcendentals folded by identities that hold on the branch's domain:
-//   cooling: a = acos(z), |z| <= 1:  sin(a) = sqrt(1 - z^2)
-//   heating: at = atan(r / sqrt(1 - r^2)) = asin(r),  cos(at) = sqrt(1 - r^2)
-// (|r| > 1 gives NaN in both forms, as in the reference), and the divisions by pi written as
-// multiplications by 1/pi; the quotient uses one shared reciprocal of (tmax - tmin) per window
-// (rcp_fast + div_by_finite) and the square roots skip the library's range scaling.  Results
-// agree with the reference's form to ~1e-15, inside the 1e-10 contract for sine_dd.
-__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg, double inv_rng) {
+// asin(u) for 0 <= u <= 0.7072 (t = u^2 <= 1/2): u + u^3 p(t), p of degree 14 through Chebyshev nodes of [0, 0.7072^2]
+// (scripts/fit/asin_fit.py: max abs error 1.2e-14, evaluated in double).
+__device__ __forceinline__ double asin_core_wide(double u, double t) {
+    double p = 0.3379097149030259;
+    p = fma3(p, t, -0.9032914986427146);
+    p = fma3(p, t, 1.1675177613361616);
+    p = fma3(p, t, -0.890631195996176);
+    p = fma3(p, t, 0.4674407127226085);
+    p = fma3(p, t, -0.15540291391580394);
+    p = fma3(p, t, 0.05097480101568288);
+    p = fma3(p, t, 0.0042099716965424624);
+    p = fma3(p, t, 0.014879304155047953);
+    p = fma3(p, t, 0.0172753040904813);
+    p = fma3(p, t, 0.022376412991636434);
+    p = fma3(p, t, 0.030381804553144803);
+    p = fma3(p, t, 0.0446428595401402);
+    p = fma3(p, t, 0.07499999998385828);
+    p = fma3(p, t, 0.16666666666668462);
+    return __fma_rn(u * t, p, u);
+}
+
+// Single-sine degree days (nb_kernels.py:224-249).  Both of the reference's closed forms are one function,
+//   arc(d, x) = d * acos(x) + alpha * sqrt(1 - x^2),            alpha = (tmax - tmin) / 2:
+//   cooling part, tmin < thr < tmax:  ((tavg - thr) * acos(z) + rng * sin(acos(z)) / 2) / pi,  z = (2 thr - tmax - tmin) / rng
+//                                     = arc(tavg - thr, z) / pi                       since sin(acos z) = sqrt(1 - z^2)
+//   heating part:  ((thr - tavg) * (atan(r / sqrt(1 - r^2)) + pi/2) + alpha * cos(atan(...))) / pi,  r = (thr - tavg) / alpha
+//                                     = arc(thr - tavg, -r) / pi                      since atan(r / sqrt(1 - r^2)) = asin(r),
+//                                       asin(r) + pi/2 = acos(-r) and cos(asin r) = sqrt(1 - r^2)
+// (|x| > 1 gives NaN in both forms, as in the reference).  arc needs ONE square root and ONE polynomial:
+//   g = sqrt((1 - |x|)(1 + |x|));  u = min(|x|, g) <= 0.7072;  asin(|x|) = |x| <= 0.7072 ? asin(u) : pi/2 - asin(u)
+// — where the previous form took a square root for acos's half-angle reduction, a second one for the sine term, and the
+// reciprocal-corrected quotient per threshold: ~40 fp64 VALU instructions per evaluation instead of ~65 (C5 is bound by them).
+// The quotients are products with ONE faithful reciprocal of (tmax - tmin) per window (<= 1.5 ulp from the reference's
+// division); results agree with the reference's acos / sin / atan / cos form to ~1e-14 absolute on values of order 1-30,
+// inside the 1e-10 contract for sine_dd (scripts/sine_accuracy.py).
+__device__ __forceinline__ double sine_arc(double d, double x, double alpha) {
+    const double HALF_PI = 1.57079632679489661923;
+    const double a = fabs(x);
+    const double q = (1.0 - a) * (1.0 + a);                  // 1 - a is exact for a >= 1/2
+    // sqrt(q) for q in {0} U [2^-53, 1]: adding DBL_MIN leaves every q > 0 as it is, keeps q < 0 negative (rsq -> NaN: |x| > 1)
+    // and makes the rsq of q = 0 finite, so that g = q * y = 0 needs no select.  rsq seed, one coupled Goldschmidt step,
+    // one residual correction (the library's second correction only settles the last bit).
+    const double y = __builtin_amdgcn_rsq(q + 2.2250738585072014e-308);
+    double g = q * y, h = 0.5 * y;
+    const double r = __fma_rn(-h, g, 0.5);
+    g = __fma_rn(g, r, g);
+    h = __fma_rn(h, r, h);
+    const double e = __fma_rn(-g, g, q);
+    g = __fma_rn(e, h, g);
+    const bool small = a <= 0.70710678118654752;
+    const double u = small ? a : g;
+    const double as = asin_core_wide(u, u * u);
+    const double v = small ? as : HALF_PI - as;              // asin(|x|)
+    const double ac = HALF_PI - copysign(v, x);              // acos(x)
+    return __fma_rn(d, ac, alpha * g);
+}
+// cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful)
+__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg, double alpha, double inv_rng) {
     const double INV_PI = 0.31830988618379067154;
     if (thr <= tmin) return tavg - thr;
     if (thr < tmax && tmin < thr) {
-        const double rng = tmax - tmin;
-        const double z = div_by_finite(2.0 * thr - tmax - tmin, rng, inv_rng);   // inf / NaN operands give NaN here too
-        const double a = acos_fast(z);
-        const double sa = sqrt_fast((1.0 - z) * (1.0 + z));
-        return ((tavg - thr) * a + (rng * 0.5) * sa) * INV_PI;       // (rng * sa) * 0.5 exactly: halving is exact
+        const double z = (2.0 * thr - tmax - tmin) * inv_rng;    // inf / NaN operands give NaN here too
+        return sine_arc(tavg - thr, z, alpha) * INV_PI;
     }
     return 0.0;
 }
-__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg, double inv_rng) {
-    const double INV_PI = 0.31830988618379067154, HALF_PI = 1.57079632679489661923;
+// heating part (nb_kernels.py:238-249); inv_alpha ~ 2 / rng
+__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg, double alpha, double inv_alpha) {
+    const double INV_PI = 0.31830988618379067154;
     if (thr >= tmax) return thr - tavg;
     if (thr < tmax && tmin < thr) {
-        const double alpha = (tmax - tmin) * 0.5;
-        const double r = div_by_finite(thr - tavg, alpha, 2.0 * inv_rng);
-        const double at = asin_fast(r);
-        const double ca = sqrt_fast((1.0 - r) * (1.0 + r));
-        return INV_PI * ((thr - tavg) * (at + HALF_PI) + alpha * ca);
+        const double d = thr - tavg;
+        return sine_arc(d, -(d * inv_alpha), alpha) * INV_PI;
     }
     return 0.0;
 }
@@ -411,6 +455,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //             the edge pair of the guessed bin is computed (2 fma) instead of read from the LDS table, which takes an
     //             LDS round trip out of every element's dependent chain; a value on an edge is recognised by equality.
     constexpr bool HA = (FEAT & 64) != 0;
+    // FEAT bit 7: every inner group holds exactly TWO rows ((tmin, tmax) pairs per day, configs[4]): a block of DEPTH rows is
+    //             DEPTH / 2 whole groups — all of them in flight at once instead of one group's two rows — and a group's
+    //             statistics are min / max / sum of the pair, taken in the input precision, without the per-row accumulators.
+    constexpr bool PAIR = (FEAT & 128) != 0;
+    static_assert(!PAIR || (PIPE == 0 && STAT == 2 && NTHR == 0 && DEPTH % 2 == 0), "pair mode: direct loads, sum + min + max, no threshold slots");
     static_assert(!HA || HB, "arithmetic edges are a mode of the LDS histogram");
     static_assert(!HB || (TKI && PIPE == 0), "the LDS histogram replaces the integer bin counters of the direct-load path");
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
@@ -613,12 +662,14 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
         bool hasnan[VEC];
-        double mean[VEC], inv_rng[VEC];
+        double mean[VEC], inv_rng[VEC], alpha[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
-            mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
+            if constexpr (PAIR) mean[i] = s[i] * 0.5;                  // == s / 2 bit for bit
+            else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
             inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_fast(mx[i] - mn[i]) : 0.0;
+            alpha[i] = (mx[i] - mn[i]) * 0.5;
         }
         uint64_t pk[VEC][4];
         if constexpr (SL && TKI) {
@@ -665,9 +716,9 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         if (!bad) {
                             const double tavg = mean[i];
                             if (co.skind == 0)
-                                x[i] = sine_cool(co.s0, mn[i], mx[i], tavg, inv_rng[i]) - sine_cool(co.s1, mn[i], mx[i], tavg, inv_rng[i]);
+                                x[i] = sine_cool(co.s0, mn[i], mx[i], tavg, alpha[i], inv_rng[i]) - sine_cool(co.s1, mn[i], mx[i], tavg, alpha[i], inv_rng[i]);
                             else
-                                x[i] = -sine_heat(co.s0, mn[i], mx[i], tavg, inv_rng[i]) + sine_heat(co.s1, mn[i], mx[i], tavg, inv_rng[i]);
+                                x[i] = -sine_heat(co.s0, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]) + sine_heat(co.s1, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]);
                         }
                     }
                 }
@@ -789,7 +840,47 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     int kk = 0;                 // row index relative to the chunk
     int g = g_lo;
 
-    if constexpr (PIPE == 0) {
+    if constexpr (PAIR) {
+        const TIn* p = cube;
+        constexpr int GB = DEPTH / 2;                 // groups per block of rows
+        // the pair's statistics: min / max in the input precision (exact), the sum as min + max — the same two addends
+        // the reference adds in time order; a NaN in either row marks the lane (the group is NaN, nb_kernels.py:145-147)
+        auto pair_stats = [&](const RawVec<TIn, VEC>& r0, const RawVec<TIn, VEC>& r1) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const TIn u = r0.v[i], v = r1.v[i];
+                nanmask[i] = __builtin_amdgcn_ballot_w64(u != u || v != v);
+                TIn lo, hi;
+                if constexpr (sizeof(TIn) == 4) { lo = __builtin_fminf(u, v); hi = __builtin_fmaxf(u, v); }
+                else { lo = __builtin_fmin(u, v); hi = __builtin_fmax(u, v); }
+                mn[i] = (double)lo; mx[i] = (double)hi;
+                s[i] = mn[i] + mx[i];
+            }
+        };
+        // ONE group-end site (rolled loop over the block's groups, the rows shifted down two per group): the sine closed
+        // forms are long, and DEPTH / 2 inlined copies of them (66 KB of code) would not fit the instruction cache.
+        // Rows beyond the chunk's end (last, partial block) re-read its last row; their groups are not evaluated.
+        const int last = rows - 1;
+        while (g < g_hi) {
+            const int ng = (g_hi - g) < GB ? (g_hi - g) : GB;
+            RawVec<TIn, VEC> r[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int row = (kk + d) < last ? (kk + d) : last;
+                r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)row * C);
+            }
+#pragma unroll 1
+            for (int q = 0; q < ng; ++q) {
+                const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
+                pair_stats(r[0], r[1]);
+                group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63));
+#pragma unroll
+                for (int d = 0; d + 2 < DEPTH; ++d) r[d] = r[d + 2];
+            }
+            g += ng;
+            kk += 2 * ng;
+        }
+    } else if constexpr (PIPE == 0) {
         const TIn* p = cube;
         // group table word for g is fetched one group ahead: its scalar-load latency hides behind
         // the previous group's work (matters for 1-2 step groups: daily data, tmin/tmax pairs)
