@@ -91,7 +91,7 @@ struct afhip_plan {
     // lowering
     int stat = 0, nthr = 0, K = 0;
     std::vector<ThrSlot> thr;
-    std::vector<ColOp> cols;
+    std::vector<ColOp> cols;               // cols[j].inter / inter_f32 are set by afhip_plan_bind_inter
     std::vector<ChunkDesc> chunks;
     std::vector<int32_t> emit;
     std::vector<int64_t> gtab;            // {(end step) << 1 | emit, bits of 1.0/len} per inner group, padded by one
@@ -224,6 +224,36 @@ extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_s
     return AFHIP_OK;
 }
 
+extern "C" int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, double arg,
+                               const void* other_dev, int other_dtype, void* out_dev, int out_dtype, void* stream) {
+    if (!x_dev || !out_dev || n < 0) return fail(AFHIP_E_INVALID, "transform: NULL array or negative size");
+    if ((x_dtype != AFHIP_F32 && x_dtype != AFHIP_F64) || (out_dtype != AFHIP_F32 && out_dtype != AFHIP_F64))
+        return fail(AFHIP_E_INVALID, "transform: dtypes must be AFHIP_F32 or AFHIP_F64");
+    TransformArgs ta{};
+    ta.x = x_dev; ta.other = nullptr; ta.out = out_dev; ta.n = n;
+    ta.x_f32 = x_dtype == AFHIP_F32; ta.out_f32 = out_dtype == AFHIP_F32; ta.other_f32 = 0;
+    switch (transform) {
+        case AFHIP_TF_POW:
+            if (arg == std::floor(arg) && std::fabs(arg) <= 64.0) { ta.tf = TF_POWI; ta.iarg = (int)arg; }
+            else { ta.tf = TF_POW; ta.arg = arg; }
+            break;
+        case AFHIP_TF_HINGE: ta.tf = TF_HINGE; ta.arg = arg; break;
+        case AFHIP_TF_INTER:
+            if (!other_dev || (other_dtype != AFHIP_F32 && other_dtype != AFHIP_F64))
+                return fail(AFHIP_E_INVALID, "transform: AFHIP_TF_INTER needs the second array and its dtype");
+            ta.tf = TF_INTER; ta.other = other_dev; ta.other_f32 = other_dtype == AFHIP_F32;
+            break;
+        default: return fail(AFHIP_E_INVALID, "transform: unknown transform %d", transform);
+    }
+    if (n == 0) return AFHIP_OK;
+    const int64_t per_block = (int64_t)WG * TRANSFORM_PER_THREAD;
+    const int64_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > 0x7fffffff) return fail(AFHIP_E_INVALID, "transform: array too large for one launch");
+    hipLaunchKernelGGL(k_transform, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)stream, ta);
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
 extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int64_t K, int64_t nt,
                                   double* num_dev, double* den_dev, double* res_dev, void* stream) {
     if (!csr || !x_dev || !res_dev || K <= 0 || nt < 0) return fail(AFHIP_E_INVALID, "spatial_wavg: bad arguments");
@@ -293,6 +323,7 @@ static int lower_columns(afhip_plan* pl) {
             case AFHIP_SINE_DD:
                 co.src = SRC_SINE; stat = std::max(stat, 2);
                 co.s0 = c.inner_args[0]; co.s1 = c.inner_args[1];
+                co.s0x2 = 2.0 * co.s0; co.s1x2 = 2.0 * co.s1;
                 if (c.inner_args[2] != 0.0 && c.inner_args[2] != 1.0)
                     return fail(AFHIP_E_INVALID, "column %d: sine_dd flag must be 0 or 1 (temporal.py:324)", j);
                 co.skind = (int)c.inner_args[2];
@@ -308,8 +339,11 @@ static int lower_columns(afhip_plan* pl) {
                 break;
             }
             case AFHIP_TF_HINGE: co.tf = TF_HINGE; co.tf_arg = c.transform_arg; break;
+            case AFHIP_TF_INTER: co.tf = TF_INTER; break;
             default: return fail(AFHIP_E_INVALID, "column %d: unknown transform %d", j, c.transform);
         }
+        // pow() and `inter` are compiled into the all-purpose (STAT 3) variants only (FEAT bit 1)
+        if (co.tf == TF_POW || co.tf == TF_INTER) stat = 3;
         switch (c.outer) {
             case AFHIP_IDENTITY: co.outer = OUT_FIRST; break;
             case AFHIP_SUM: co.outer = OUT_SUM; break;
@@ -617,6 +651,15 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
 
 extern "C" void afhip_plan_destroy(afhip_plan* plan) { delete plan; }
 
+extern "C" int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* inter_dev, int dtype) {
+    if (!plan || column < 0 || column >= plan->K) return fail(AFHIP_E_INVALID, "plan_bind_inter: no such column");
+    if (plan->cols[(size_t)column].tf != TF_INTER) return fail(AFHIP_E_INVALID, "plan_bind_inter: column %d has no inter transform", column);
+    if (!inter_dev || (dtype != AFHIP_F32 && dtype != AFHIP_F64)) return fail(AFHIP_E_INVALID, "plan_bind_inter: NULL array or bad dtype");
+    plan->cols[(size_t)column].inter = inter_dev;
+    plan->cols[(size_t)column].inter_f32 = dtype == AFHIP_F32 ? 1 : 0;
+    return AFHIP_OK;
+}
+
 extern "C" int64_t afhip_plan_workspace_bytes(const afhip_plan* plan) {
     if (!plan) return 0;
     return plan->ws_partial + plan->ws_panel;
@@ -642,6 +685,9 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
 
 static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st) {
     if (pl->chunks.empty()) return AFHIP_OK;
+    for (int j = 0; j < pl->K; ++j)
+        if (pl->cols[(size_t)j].tf == TF_INTER && !pl->cols[(size_t)j].inter)
+            return fail(AFHIP_E_INVALID, "column %d multiplies by a second array (AFHIP_TF_INTER) that was never bound: call afhip_plan_bind_inter first", j);
     FusedArgs fa{};
     fa.cube = cube; fa.C = pl->desc.n_cells;
     fa.gtab = pl->d_gtab.p; fa.chunks = pl->d_chunks.p;

@@ -32,7 +32,7 @@ constexpr int HB_TABLE_BYTES = 2 * (MAX_THR + 2) * 16;    // LDS edge tables of 
 
 // inner-source kinds (what a column reads at the end of an inner group)
 enum : int { SRC_MEAN = 0, SRC_SUM = 1, SRC_MIN = 2, SRC_MAX = 3, SRC_NANMEAN = 4, SRC_THR = 5, SRC_SINE = 6 };
-enum : int { TF_NONE = 0, TF_POWI = 1, TF_POW = 2, TF_HINGE = 3 };
+enum : int { TF_NONE = 0, TF_POWI = 1, TF_POW = 2, TF_HINGE = 3, TF_INTER = 4 };
 enum : int { OUT_FIRST = 0, OUT_SUM = 1, OUT_MEAN = 2, OUT_MIN = 3, OUT_MAX = 4, OUT_DD = 5, OUT_BINS = 6 };
 
 // One threshold slot on raw data: contribution = (t0 < v && v < t1) ? fma(A, v, B) : 0.
@@ -61,8 +61,10 @@ struct ColOp {
     int32_t src, src_idx;      // SRC_*; slot index for SRC_THR
     int32_t tf, tf_iarg;       // TF_*; integer exponent for TF_POWI
     int32_t outer, skind;      // OUT_*; sine_dd kind flag (0 cooling, 1 heating)
-    int32_t rounding, pad;     // AFHIP_ROUND_* bits (float32 intermediates like the reference)
+    int32_t rounding, inter_f32;   // AFHIP_ROUND_* bits (float32 intermediates like the reference); 1: `inter` holds float32
+    const void* inter;         // TF_INTER: the second cube [G1][C] (one value per inner group and cell), else null
     double s0, s1;             // sine_dd thresholds
+    double s0x2, s1x2;         // 2 * s0, 2 * s1 (exact): the cooling form's 2 thr - tmax - tmin starts from them
     double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
     double o0, o1, obase;      // outer dd/bins thresholds
 };
@@ -168,12 +170,12 @@ __device__ __forceinline__ double powi_dd(double x, int e) {
 }
 
 // ---- f64 division / square root without the library's scaling and special-case code ----
-// 1/x for normal x: v_rcp_f64 (~2^-23) + two Newton steps -> faithful (<= 1 ulp).
-__device__ __forceinline__ double rcp_fast(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __fma_rn(-x, y, 1.0);
-    y = __fma_rn(y, e, y);
-    e = __fma_rn(-x, y, 1.0);
+// 1/x for normal x: v_rcp_f64 (measured 2^-24.4 on gfx950, scripts/probe/rcp_rsq_probe.py) + one Newton step: <= 10 ulp
+// (2.2e-15).  Enough for sine_arc's quotients: their error only matters next to |x| = 1, where the closed forms are
+// ill-conditioned by themselves.
+__device__ __forceinline__ double rcp_newton1(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __fma_rn(-x, y, 1.0);
     return __fma_rn(y, e, y);
 }
 // a / b given y ~ 1/b (Markstein): q0 = a*y, r = a - b*q0 exactly (fma), q = q0 + r*y.  With y the
@@ -189,26 +191,6 @@ __device__ __forceinline__ double div_by_finite(double a, double b, double y) { 
 __device__ __forceinline__ double div_by(double a, double b, double y) {
     return __builtin_amdgcn_div_fixup(div_by_finite(a, b, y), b, a);
 }
-// sqrt(x) for normal x >= 0: v_rsq_f64 seed, Goldschmidt step, two residual corrections (the
-// library's core sequence); x == 0 -> 0, x < 0 or NaN -> NaN.
-__device__ __forceinline__ double sqrt_fast(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = __fma_rn(-h, g, 0.5);
-    g = __fma_rn(g, r, g);
-    h = __fma_rn(h, r, h);
-    double d = __fma_rn(-g, g, x);
-    g = __fma_rn(d, h, g);
-    d = __fma_rn(-g, g, x);
-    g = __fma_rn(d, h, g);
-    return (x == 0.0) ? 0.0 : g;
-}
-
-// asin / acos to ~2e-15 relative (checked against numpy on 2e6 points): on
-// |x| <= 1/2, asin(x) = x + x^3 p(x^2) with a degree-10 Chebyshev-fitted p; beyond, the
-// half-angle identity asin(x) = pi/2 - 2 asin(sqrt((1-x)/2)).  One sqrt + 11 FMAs instead of
-// the library's ~70-instruction routines: sine_dd needs one of these per threshold per
-// cell-day and was bound by them.  |x| > 1 yields NaN like the library functions.
 // d = a * b + c as ONE three-address v_fma_f64 with the (wave-uniform) addend c in a scalar register pair.  For a Horner
 // chain hipcc otherwise emits v_mov_b64 + v_fmac_f64 per term (the two-address form clobbers the coefficient), doubling
 // the polynomial's VALU cost; with a "v" constraint the coefficients pin 2 VGPRs each (30 for the degree-14 asin).
@@ -221,39 +203,6 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
     return __builtin_fma(a, b, c);
 #endif
 }
-__device__ __forceinline__ double asin_core(double s, double t) {
-    double p = 2.78600666767379636e-02;
-    p = fma3(p, t, -6.80823893868847015e-03);
-    p = fma3(p, t, 1.54379220773654957e-02);
-    p = fma3(p, t, 1.02917232813431302e-02);
-    p = fma3(p, t, 1.41405795351722628e-02);
-    p = fma3(p, t, 1.73372313610090298e-02);
-    p = fma3(p, t, 2.23730075566984689e-02);
-    p = fma3(p, t, 3.03819175771733174e-02);
-    p = fma3(p, t, 4.46428575770584091e-02);
-    p = fma3(p, t, 7.49999999972744968e-02);
-    p = fma3(p, t, 1.66666666666669405e-01);
-    return __fma_rn(s * t, p, s);                    // asin(s) for 0 <= s <= 1/2, t = s^2
-}
-__device__ __forceinline__ double acos_fast(double x) {
-    const double HALF_PI = 1.57079632679489661923, PI = 3.14159265358979323846;
-    const double ax = fabs(x);
-    const bool small = ax <= 0.5;
-    const double t = small ? ax * ax : (1.0 - ax) * 0.5;
-    const double s = small ? ax : sqrt_fast(t);
-    const double r = asin_core(s, t);
-    return small ? HALF_PI - copysign(r, x) : (x > 0.0 ? 2.0 * r : PI - 2.0 * r);
-}
-__device__ __forceinline__ double asin_fast(double x) {
-    const double HALF_PI = 1.57079632679489661923;
-    const double ax = fabs(x);
-    const bool small = ax <= 0.5;
-    const double t = small ? ax * ax : (1.0 - ax) * 0.5;
-    const double s = small ? ax : sqrt_fast(t);
-    const double r = asin_core(s, t);
-    return copysign(small ? r : HALF_PI - 2.0 * r, x);
-}
-
 // asin(u) for 0 <= u <= 0.7072 (t = u^2 <= 1/2): u + u^3 p(t), p of degree 14 through Chebyshev nodes of [0, 0.7072^2]
 // (scripts/fit/asin_fit.py: max abs error 1.2e-14, evaluated in double).
 __device__ __forceinline__ double asin_core_wide(double u, double t) {
@@ -286,7 +235,7 @@ __device__ __forceinline__ double asin_core_wide(double u, double t) {
 //   g = sqrt((1 - |x|)(1 + |x|));  u = min(|x|, g) <= 0.7072;  asin(|x|) = |x| <= 0.7072 ? asin(u) : pi/2 - asin(u)
 // — where the previous form took a square root for acos's half-angle reduction, a second one for the sine term, and the
 // reciprocal-corrected quotient per threshold: ~40 fp64 VALU instructions per evaluation instead of ~65 (C5 is bound by them).
-// The quotients are products with ONE faithful reciprocal of (tmax - tmin) per window (<= 1.5 ulp from the reference's
+// The quotients are products with ONE reciprocal of (tmax - tmin) per window (rcp_newton1: within 10 ulp of the reference's
 // division); results agree with the reference's acos / sin / atan / cos form to ~1e-14 absolute on values of order 1-30,
 // inside the 1e-10 contract for sine_dd (scripts/sine_accuracy.py).
 __device__ __forceinline__ double sine_arc(double d, double x, double alpha) {
@@ -311,11 +260,11 @@ __device__ __forceinline__ double sine_arc(double d, double x, double alpha) {
     return __fma_rn(d, ac, alpha * g);
 }
 // cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful)
-__device__ __forceinline__ double sine_cool(double thr, double tmin, double tmax, double tavg, double alpha, double inv_rng) {
+__device__ __forceinline__ double sine_cool(double thr, double thr2, double tmin, double tmax, double tavg, double alpha, double inv_rng) {
     const double INV_PI = 0.31830988618379067154;
     if (thr <= tmin) return tavg - thr;
     if (thr < tmax && tmin < thr) {
-        const double z = (2.0 * thr - tmax - tmin) * inv_rng;    // inf / NaN operands give NaN here too
+        const double z = (thr2 - tmax - tmin) * inv_rng;         // thr2 = 2 thr; inf / NaN operands give NaN here too
         return sine_arc(tavg - thr, z, alpha) * INV_PI;
     }
     return 0.0;
@@ -428,7 +377,8 @@ __device__ __forceinline__ RawVec<TIn, VEC> ld_stream(const TIn* p) {
 //   STAT 0 none | 1 sum | 2 sum+min+max | 3 sum+count+min+max with NaN skipping (nanmean)
 // ---------------------------------------------------------------------------------------
 //   FEAT bit 0: single-sine degree days compiled in (needs STAT >= 2)
-//        bit 1: pow() with a non-integer exponent compiled in
+//        bit 1: the general transforms compiled in: pow() with a non-integer exponent, and `inter` (Dataset.interact,
+//               dataset.py:483-518,547-563: the inner value times the matching element of a second cube)
 // Both are bulky once inlined per column, so only the variants that need them carry them.
 //
 // The workgroup size is a launch parameter (64 or 256 threads): waves never talk to each
@@ -494,6 +444,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     double s[VEC], mn[VEC], mx[VEC];
     int cnt[VEC];
     unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
+    bool pnan[VEC];                                 // pair mode: this lane's pair holds a NaN
     double acc[(NTHR > 0 && !TKI) ? NTHR : 1][VEC];
     int cthr[(NTHR > 0 && TKI && !HB) ? NTHR : 1][VEC];
     double os[SL ? 1 : KMAX][VEC];
@@ -658,17 +609,18 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----
-    auto group_end = [&](bool emit_slot, int nsteps, double inv_n, int zoff) {
+    auto group_end = [&](bool emit_slot, int nsteps, double inv_n, int zoff, int gidx) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
         bool hasnan[VEC];
         double mean[VEC], inv_rng[VEC], alpha[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
+            if constexpr (PAIR) hasnan[i] = pnan[i];
+            else hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
             if constexpr (PAIR) mean[i] = s[i] * 0.5;                  // == s / 2 bit for bit
             else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
-            inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_fast(mx[i] - mn[i]) : 0.0;
+            inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_newton1(mx[i] - mn[i]) : 0.0;
             alpha[i] = (mx[i] - mn[i]) * 0.5;
         }
         uint64_t pk[VEC][4];
@@ -716,7 +668,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         if (!bad) {
                             const double tavg = mean[i];
                             if (co.skind == 0)
-                                x[i] = sine_cool(co.s0, mn[i], mx[i], tavg, alpha[i], inv_rng[i]) - sine_cool(co.s1, mn[i], mx[i], tavg, alpha[i], inv_rng[i]);
+                                x[i] = sine_cool(co.s0, co.s0x2, mn[i], mx[i], tavg, alpha[i], inv_rng[i]) - sine_cool(co.s1, co.s1x2, mn[i], mx[i], tavg, alpha[i], inv_rng[i]);
                             else
                                 x[i] = -sine_heat(co.s0, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]) + sine_heat(co.s1, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]);
                         }
@@ -746,6 +698,22 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 } else if ((FEAT & 2) && tf == TF_POW) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) x[i] = pow(x[i], co.tf_arg);
+                } else if ((FEAT & 2) && tf == TF_INTER) {
+                    // np.multiply(block, other) (dataset.py:563): this group's value times other[g][cell]; lanes beyond the
+                    // grid re-read valid cells (c_ld) and are never stored
+                    KEEP_BRANCH();
+                    const int64_t at = (int64_t)gidx * C + c_ld;
+                    if (co.inter_f32) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) x[i] *= (double)((const float*)co.inter)[at + i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) x[i] *= ((const double*)co.inter)[at + i];
+                    }
+                    if (co.rounding & 2) {                            // float32 times float32 stays float32 in the reference
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) x[i] = (double)(float)x[i];
+                    }
                 }
                 if constexpr (SL && TKI) {
                     if (a.packed) {
@@ -849,10 +817,17 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const TIn u = r0.v[i], v = r1.v[i];
-                nanmask[i] = __builtin_amdgcn_ballot_w64(u != u || v != v);
+                pnan[i] = u != u || v != v;
+                // v_min / v_max straight on the loaded values: the builtins first canonicalise both operands (v_max x, x)
+                // against signalling NaNs; a pair with any NaN is a NaN group anyway
                 TIn lo, hi;
-                if constexpr (sizeof(TIn) == 4) { lo = __builtin_fminf(u, v); hi = __builtin_fmaxf(u, v); }
-                else { lo = __builtin_fmin(u, v); hi = __builtin_fmax(u, v); }
+                if constexpr (sizeof(TIn) == 4) {
+                    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(u), "v"(v));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(u), "v"(v));
+                } else {
+                    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(u), "v"(v));
+                    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(u), "v"(v));
+                }
                 mn[i] = (double)lo; mx[i] = (double)hi;
                 s[i] = mn[i] + mx[i];
             }
@@ -873,7 +848,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             for (int q = 0; q < ng; ++q) {
                 const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
                 pair_stats(r[0], r[1]);
-                group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63));
+                group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63), g + q);
 #pragma unroll
                 for (int d = 0; d + 2 < DEPTH; ++d) r[d] = r[d + 2];
             }
@@ -942,7 +917,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if (d < rem) consume(r[d]);
                 kk = gend;
             }
-            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63));
+            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63), g);
             ++g;
         }
     } else {
@@ -987,7 +962,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 __builtin_memcpy(&rv, &raw, 16);
                 consume(rv);
             }
-            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63));
+            group_end((w & 1) != 0, gend - gbeg, __longlong_as_double(iv), (int)((uint64_t)w >> 63), g);
             ++g;
         }
         // no DMA may still target this workgroup's LDS when the wave retires

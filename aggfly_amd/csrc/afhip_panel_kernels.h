@@ -327,6 +327,63 @@ __global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// k_transform: the element-wise transforms of the staged path on a whole array — Dataset.power (`np.power(block, exp)`,
+// dataset.py:527-543), Dataset.spline's hinge (dataset.py:475-481) and Dataset.interact (`np.multiply`, dataset.py:547-563).
+// A plain stream: read x (and other), write out; a thread handles TRANSFORM_PER_THREAD elements a block apart so that
+// every load of a wave is one contiguous run.  float64 arithmetic with one rounding at the store, except float32 ->
+// float32 hinge / product, which numpy evaluates in float32.
+// ---------------------------------------------------------------------------------------
+constexpr int TRANSFORM_PER_THREAD = 4;
+struct TransformArgs {
+    const void* x;
+    const void* other;
+    void* out;
+    int64_t n;
+    int32_t x_f32, other_f32, out_f32, tf, iarg, pad;
+    double arg;
+};
+
+__global__ __launch_bounds__(WG) void k_transform(const TransformArgs a) {
+    const int64_t base = (int64_t)blockIdx.x * (WG * TRANSFORM_PER_THREAD) + threadIdx.x;
+    double v[TRANSFORM_PER_THREAD], o[TRANSFORM_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) {
+        const int64_t i = base + (int64_t)u * WG;
+        const int64_t ic = i < a.n ? i : a.n - 1;                     // clamped: the tail re-reads the last element
+        v[u] = a.x_f32 ? (double)((const float*)a.x)[ic] : ((const double*)a.x)[ic];
+        o[u] = 1.0;
+        if (a.tf == TF_INTER) o[u] = a.other_f32 ? (double)((const float*)a.other)[ic] : ((const double*)a.other)[ic];
+    }
+    const bool all_f32 = a.x_f32 && a.out_f32;
+    if (a.tf == TF_POWI) {
+        powi_dd_vec<TRANSFORM_PER_THREAD>(v, a.iarg);
+    } else if (a.tf == TF_POW) {
+#pragma unroll
+        for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) v[u] = pow(v[u], a.arg);
+    } else if (a.tf == TF_HINGE) {
+        if (all_f32) {
+            const float kf = (float)a.arg;
+#pragma unroll
+            for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) { const float xf = (float)v[u]; v[u] = (double)(((xf > kf) ? 1.0f : 0.0f) * (xf - kf)); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) v[u] = ((v[u] > a.arg) ? 1.0 : 0.0) * (v[u] - a.arg);
+        }
+    } else {                                                            // TF_INTER: float32 x float32 products are exact in float64
+#pragma unroll
+        for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) v[u] = v[u] * o[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TRANSFORM_PER_THREAD; ++u) {
+        const int64_t i = base + (int64_t)u * WG;
+        if (i < a.n) {
+            if (a.out_f32) ((float*)a.out)[i] = (float)v[u];
+            else ((double*)a.out)[i] = v[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_place_box: a decoded chunk [bt][by][bx] (contiguous) -> its box of the time-major cube
 // [T][NY][NX] at (t0, y0, x0), only the part [st, st+nt) x [sy, sy+ny) x [sx, sx+nx) of the chunk.
 // The ingestion route's scatter (aggfly_amd/io.py): reads are contiguous in x runs, writes are

@@ -10,9 +10,10 @@ far as the aggregation path reads them: dimension normalisation to
 What differs by design: there is no dask graph.  ``Dataset.da`` wraps a plain array (numpy
 on the host, or a torch tensor already resident in HBM after ``to_device()``); the engine
 consumes the time-major ``(time, lat, lon)`` cube directly (``Dataset.cube()``), which is
-the layout climate stores have on disk.  ``power`` / ``interact`` / ``spline`` exist for API
-parity and act on the current array; inside ``aggregate_dataset`` those transforms are fused
-into the GPU kernels instead of materialising new datasets.
+the layout climate stores have on disk.  ``power`` / ``interact`` / ``spline`` run the library's
+element-wise kernel (`afhip_transform`) on the current array in HBM (a host array is uploaded first;
+without a GPU they raise); inside ``aggregate_dataset`` those transforms are fused into the streaming
+kernel instead of materialising new datasets.
 """
 from __future__ import annotations
 
@@ -248,28 +249,58 @@ class Dataset:
         new.history.append(tag)
         return new
 
-    def power(self, exp, update=False):
-        """`dataset.py:442-473` (`np.power` per block, `:527-543`)."""
-        if _is_torch(self.da.data):
-            base = self.da.data
-            if isinstance(exp, np.generic) and str(base.dtype).endswith("float32"):
-                base = base.double()       # NumPy 2 promotion: float32 ** np.int64 -> float64 (np.power, dataset.py:543)
-            data = base ** (exp.item() if isinstance(exp, np.generic) else exp)
-        else:
-            data = np.power(self.da.data, exp)
+    # ---- element-wise transforms: `k_transform` of the HIP library (include/aggfly_hip.h: afhip_transform) ----
+    def _hbm_time_major(self):
+        """The (time, latitude, longitude) cube as a float HBM tensor, uploaded if still on the host.  Raises
+        `HipEngineError` without a GPU: the transforms have no CPU form here."""
+        import torch
+        from . import hip
+        hip.require_gpu()
+        d = self.cube()
+        if not _is_torch(d):
+            if d.dtype not in (np.float32, np.float64):
+                d = d.astype(np.float64)
+            d = torch.from_numpy(d)
+        if not d.is_cuda:
+            d = d.cuda(non_blocking=True)
+        if d.dtype not in (torch.float32, torch.float64):
+            d = d.to(torch.float64)
+        return d.contiguous()
+
+    def _transformed(self, tm, tag, update):
+        """Wrap a time-major HBM result as this dataset's ``da`` (dimension order kept: a permuted view)."""
+        da = DataArray(tm, ("time", "latitude", "longitude"),
+                       {k: self.da.coords[k] for k in ("time", "latitude", "longitude")}, self.da.name, self.da.attrs)
+        da = da.transpose(*self.da.dims) if set(self.da.dims) == {"time", "latitude", "longitude"} else da
         if update:
-            self.da = self.da._replace(data=data)
-            self.history.append(f"power{exp}")
+            self.da = da
+            self.history.append(tag)
             return None
-        return self._with(data, f"power{exp}")
+        new = self.deepcopy()
+        new.da = da
+        new.history.append(tag)
+        return new
+
+    def power(self, exp, update=False):
+        """`dataset.py:442-473` (`np.power` per block, `:527-543`), on the GPU: integer exponents through the kernel's
+        correctly rounded product chain, others through ``pow``."""
+        import torch
+        from . import hip
+        x = self._hbm_time_major()
+        # NumPy 2 promotion: float32 ** np.int64 / np.float64 scalar -> float64; a Python scalar keeps float32
+        out_dtype = torch.float64 if (isinstance(exp, np.generic) and exp.dtype.itemsize == 8) else x.dtype
+        out = hip.transform(x, "pow", float(exp), out_dtype=out_dtype)
+        return self._transformed(out, f"power{exp}", update)
 
     def spline(self):
         """`dataset.py:475-481`: (self, hinge at 20)."""
-        d = self.da.data
-        return self, self._with((d > 20) * (d - 20), "spline")
+        from . import hip
+        return self, self._transformed(hip.transform(self._hbm_time_major(), "hinge", 20.0), "spline", False)
 
     def interact(self, inter, update=False):
-        """`dataset.py:483-518`."""
+        """`dataset.py:483-518`: element-wise product with a second array of the same shape (`_interact`, `:547-563`)."""
+        import torch
+        from . import hip
         if isinstance(inter, Dataset):
             inter = inter.da
         if isinstance(inter, DataArray):
@@ -279,17 +310,21 @@ class Dataset:
         else:
             other = inter
         assert tuple(self.da.data.shape) == tuple(other.shape)
-        if _is_torch(self.da.data) and not _is_torch(other):
-            import torch
-            other = torch.as_tensor(np.ascontiguousarray(other), device=self.da.data.device)
-        elif _is_torch(other) and not _is_torch(self.da.data):
-            other = other.cpu().numpy()
-        data = self.da.data * other
-        if update:
-            self.da = self.da._replace(data=data)
-            self.history.append("interacted")
-            return None
-        return self._with(data, "interacted")
+        x = self._hbm_time_major()
+        # the second array in the cube's own (time, latitude, longitude) order: layout only, the product runs in the kernel
+        perm = [self.da.dims.index(d) for d in ("time", "latitude", "longitude")]
+        if not _is_torch(other):
+            other = np.asarray(other)
+            if other.dtype not in (np.float32, np.float64):
+                other = other.astype(np.float64)
+            other = torch.from_numpy(np.ascontiguousarray(other))
+        other = other.to(x.device, non_blocking=True)
+        if other.dtype not in (torch.float32, torch.float64):
+            other = other.to(torch.float64)
+        other = other.permute(*perm).contiguous()
+        out_dtype = torch.float32 if (x.dtype == torch.float32 and other.dtype == torch.float32) else torch.float64
+        out = hip.transform(x, "inter", other=other, out_dtype=out_dtype)
+        return self._transformed(out, "interacted", update)
 
     def __repr__(self):
         return f"<aggfly_amd.Dataset {self.name or ''} {self.da.sizes} lon_is_360={self.lon_is_360}>"

@@ -11,8 +11,8 @@ Replaces, for ``engine="hip"``, the lazy xarray/dask graph the reference builds 
   pass (``hip.FusedPlan``) that reads the raw cube ONCE — the reference re-reads the raw
   data for every output name (`aggregate.py:133`);
 * a step list that does not fit the two-level shape (three 'aggregate' levels, a transform
-  on raw data, ``inter``) runs *staged*: the same GPU kernels, one step at a time, with the
-  intermediates kept in HBM.
+  on raw data or after the outer level) runs *staged*: the same GPU kernels, one step at a time,
+  with the intermediates kept in HBM (the element-wise transforms through `hip.transform`).
 
 Nothing here computes on the CPU; without the HIP library or a GPU every entry point raises.
 """
@@ -146,7 +146,7 @@ def lower_spec(key: str, steps):
                 for k2, tf in items:
                     n = ColumnProg(k2, c.inner, c.tf, c.outer)
                     if tf is not None:
-                        if tf[0] == "inter" or n.inner is None or n.outer is not None or n.tf is not None:
+                        if n.inner is None or n.outer is not None or n.tf is not None:
                             fusable = False
                         else:
                             n.tf = tf
@@ -194,7 +194,8 @@ _PLAN_CACHE_BYTES = 16 << 30        # plans own their scratch in HBM: bound what
 def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=None) -> hip.FusedPlan:
     exact = config.exact_order if exact_order is None else exact_order
     tune = config.tuning if tuning is None else tuning
-    ckey = (T, n_cells, dtype_code, _hash(ib, ob), repr(columns), exact, tune)
+    # the second cube of an 'inter' column is bound per run (hip.FusedPlan.bind_inter), so it is not part of the key
+    ckey = (T, n_cells, dtype_code, _hash(ib, ob), repr([{k: v for k, v in c.items() if k != "inter"} for c in columns]), exact, tune)
     p = _PLAN_CACHE.get(ckey)
     if p is None:
         p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune)
@@ -272,15 +273,44 @@ def get_csr(weights, dataset: Dataset):
 # --------------------------------------------------------------------------------------
 # fused execution
 # --------------------------------------------------------------------------------------
+def _is_f32(obj) -> bool:
+    obj = getattr(obj, "da", obj)
+    return str(getattr(obj, "dtype", "")).endswith("float32")
+
+
+def inter_time_major(other, G1: int, ny: int, nx: int, device):
+    """The second array of an 'inter' transform (`Dataset.interact`, `aggfly/dataset/dataset.py:483-518`) as an HBM tensor
+    ``[G1, ny, nx]``.  Like the reference it must have the shape of the data it multiplies — (latitude, longitude, time) of
+    the inner level's output; a Dataset / labelled array with the same dimension names is transposed first — else the
+    same ``AssertionError``.  Only layout changes here: the product itself runs in the kernel."""
+    import torch
+    if isinstance(other, Dataset):
+        other = other.da
+    if hasattr(other, "dims") and hasattr(other, "data"):
+        if set(other.dims) == {"latitude", "longitude", "time"}:
+            other = other.transpose("latitude", "longitude", "time")
+        other = other.data
+    assert tuple(other.shape) == (ny, nx, G1), f"inter array has shape {tuple(other.shape)}, the data it multiplies {(ny, nx, G1)}"
+    if not _is_torch(other):
+        other = np.asarray(other)
+        if other.dtype not in (np.float32, np.float64):
+            other = other.astype(np.float64)
+        other = torch.from_numpy(np.ascontiguousarray(other))
+    other = other.to(device, non_blocking=True)
+    if other.dtype not in (torch.float32, torch.float64):
+        other = other.to(torch.float64)
+    return other.permute(2, 0, 1).contiguous()
+
+
 def _column_dict(c: ColumnProg, f32_rules: bool = False) -> dict:
     d = {"inner": c.inner.calc}
     if f32_rules:
         # dtype walk of the reference's numba path on a float32 cube: an aggregate step stores its
         # output in its input's dtype; np.power with an int64 exponent promotes to float64
-        # (NumPy 2 promotion); the hinge stays float32
+        # (NumPy 2 promotion); the hinge stays float32; float32 times a float32 array stays float32
         r = hip.ROUND_INNER
-        is64 = c.tf is not None and c.tf[0] == "pow"
-        if c.tf is not None and c.tf[0] == "hinge":
+        is64 = c.tf is not None and (c.tf[0] == "pow" or (c.tf[0] == "inter" and not _is_f32(c.tf[1])))
+        if c.tf is not None and (c.tf[0] == "hinge" or (c.tf[0] == "inter" and not is64)):
             r |= hip.ROUND_HINGE
         if c.outer is not None and not is64:
             r |= hip.ROUND_FINAL
@@ -289,7 +319,9 @@ def _column_dict(c: ColumnProg, f32_rules: bool = False) -> dict:
         d["inner_args"] = c.inner.ddargs
         if c.inner.calc == "sine_dd" and c.inner.ddargs[2] not in (0.0, 1.0):
             raise ValueError("Invalid ddargs[2] value")                    # temporal.py:324
-    if c.tf is not None:
+    if c.tf is not None and c.tf[0] == "inter":
+        d["transform"], d["inter"] = c.tf
+    elif c.tf is not None:
         d["transform"], d["transform_arg"] = c.tf
     if c.outer is not None:
         d["outer"] = c.outer.calc
@@ -371,6 +403,9 @@ def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=N
         h = len(cols) // 2
         return _run_fused_pass(cube, cols[:h], ib, ob, None, True, exact_order) + \
             _run_fused_pass(cube, cols[h:], ib, ob, None, True, exact_order)
+    for j, cd in enumerate(cdicts):
+        if cd.get("transform") == "inter":
+            plan.bind_inter(j, inter_time_major(cd["inter"], len(ib) - 1, int(cube.shape[1]), int(cube.shape[2]), cube.device))
     if csr is not None:
         out = plan.run(cube, csr, want_cells=want_cells)
         return [PassResult([c.key for c in cols], None, plan, out.get("cells"), out)]

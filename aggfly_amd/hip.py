@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("AGGFLY_HIP_LIB") or os.path.join(_HERE, "libaggfly_hi
 # codes (include/aggfly_hip.h)
 F32, F64 = 0, 1
 MEAN, SUM, MIN, MAX, NANMEAN, DD, BINS, SINE_DD, IDENTITY = range(9)
-TF_NONE, TF_POW, TF_HINGE = 0, 1, 2
+TF_NONE, TF_POW, TF_HINGE, TF_INTER = 0, 1, 2, 3
 ROUND_INNER, ROUND_HINGE, ROUND_FINAL = 1, 2, 4
 CALC_CODE = {"mean": MEAN, "sum": SUM, "min": MIN, "max": MAX, "nanmean": NANMEAN,
              "dd": DD, "bins": BINS, "sine_dd": SINE_DD}
@@ -33,7 +33,7 @@ EXPORTS = (
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
-    "afhip_plan_profile_begin", "afhip_plan_profile_end",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform",
 )
 
 
@@ -100,6 +100,8 @@ def load():
     lib.afhip_plan_describe.argtypes = [vp, C.c_char_p, i32]
     lib.afhip_plan_run_temporal.argtypes = [vp, vp, vp, vp, vp]
     lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    lib.afhip_plan_bind_inter.argtypes = [vp, i32, vp, i32]
+    lib.afhip_transform.argtypes = [vp, i32, i64, i32, dbl, vp, i32, vp, i32, vp]
     lib.afhip_plan_profile_begin.argtypes = [vp, i64]
     lib.afhip_plan_profile_end.argtypes = [vp, C.POINTER(C.c_float), i64]
     lib.afhip_plan_profile_end.restype = i64
@@ -208,6 +210,29 @@ def _group(fn_name, cube, bounds, code=None, ddargs=None):
                 _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
                                              sub.ctypes.data, len(sub), tmp.data_ptr(), _stream_ptr()))
                 out[..., d0:d0 + len(sub)] = tmp
+    return out
+
+
+def transform(x, kind: str, arg: float = 0.0, other=None, out_dtype=None):
+    """Element-wise transform of an HBM tensor by the library's `k_transform` (`afhip_transform`): ``kind`` 'pow' (arg =
+    exponent; `np.power`, `aggfly/dataset/dataset.py:527-543`), 'hinge' (arg = knot; `dataset.py:475-481`) or 'inter'
+    (``other``: same-shape tensor; `np.multiply`, `dataset.py:547-563`).  -> a new tensor of ``out_dtype`` (default: x's)."""
+    torch = _torch()
+    lib = load()
+    require_gpu()
+    if not x.is_cuda:
+        raise HipEngineError("transform: the array must be resident in HBM (a CUDA/HIP tensor)")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    code = {"pow": TF_POW, "hinge": TF_HINGE, "inter": TF_INTER}[kind]
+    optr, ocode = None, 0
+    if code == TF_INTER:
+        if other is None or tuple(other.shape) != tuple(x.shape) or not other.is_cuda:
+            raise ValueError("transform('inter'): needs a second HBM tensor of the same shape")
+        other = other.contiguous()
+        optr, ocode = other.data_ptr(), _dtype_code(other)
+    _check(lib.afhip_transform(x.data_ptr(), _dtype_code(x), x.numel(), code, float(arg), optr, ocode,
+                               out.data_ptr(), _dtype_code(out), _stream_ptr()))
     return out
 
 
@@ -321,7 +346,7 @@ class FusedPlan:
         for j, c in enumerate(columns):
             cols[j].inner = CALC_CODE[c["inner"]]
             tf = c.get("transform")
-            cols[j].transform = {None: TF_NONE, "pow": TF_POW, "hinge": TF_HINGE}[tf]
+            cols[j].transform = {None: TF_NONE, "pow": TF_POW, "hinge": TF_HINGE, "inter": TF_INTER}[tf]
             cols[j].transform_arg = float(c.get("transform_arg", 0.0))
             outer = c.get("outer", "identity")
             cols[j].outer = IDENTITY if outer == "identity" else CALC_CODE[outer]
@@ -342,6 +367,16 @@ class FusedPlan:
         h = C.c_void_p()
         _check(lib.afhip_plan_create(C.byref(d), C.byref(h)))
         self._h = h
+        self.G1 = len(self.ib) - 1
+        self._inter = {}               # column -> the bound second cube (kept alive while bound)
+
+    def bind_inter(self, column: int, other):
+        """Bind an 'inter' column's second cube: an HBM tensor [G1, n_cells...] (float32 / float64, time-major)."""
+        other = other.contiguous()
+        if not other.is_cuda or other.numel() != self.G1 * self.n_cells or other.shape[0] != self.G1:
+            raise ValueError(f"inter array must be an HBM tensor of {self.G1} x {self.n_cells} elements (inner groups x cells)")
+        _check(load().afhip_plan_bind_inter(self._h, int(column), other.data_ptr(), _dtype_code(other)))
+        self._inter[int(column)] = other
 
     def describe(self) -> str:
         buf = C.create_string_buffer(2048)

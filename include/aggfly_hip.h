@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AFHIP_ABI_VERSION 1
+#define AFHIP_ABI_VERSION 2
 
 /* status codes */
 #define AFHIP_OK            0
@@ -56,12 +56,13 @@ extern "C" {
 #define AFHIP_TF_NONE  0
 #define AFHIP_TF_POW   1   /* Dataset.power / _power  aggfly/dataset/dataset.py:442-473,527-543 */
 #define AFHIP_TF_HINGE 2   /* Dataset.spline hinge (x>knot)*(x-knot), dataset.py:475-481 (knot 20) */
+#define AFHIP_TF_INTER 3   /* Dataset.interact / _interact: times a second array, dataset.py:483-518,547-563 */
 
 /* The reference stores every step's output in its input dtype (nb_kernels.py:257-262), so on a
  * float32 cube its intermediates are float32.  This engine keeps float64 throughout unless a
  * column asks for the reference's roundings: */
 #define AFHIP_ROUND_INNER 1   /* round the inner reducer's value to float32                  */
-#define AFHIP_ROUND_HINGE 2   /* evaluate the hinge transform in float32                     */
+#define AFHIP_ROUND_HINGE 2   /* evaluate the hinge / inter transform in float32             */
 #define AFHIP_ROUND_FINAL 4   /* round the column's final (outer) value to float32           */
 
 const char* afhip_last_error(void);
@@ -119,6 +120,16 @@ void afhip_csr_destroy(afhip_csr* csr);
  * block_dev [n_cells, nt] float64; out_dev [R, nt] float64. */
 int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
                         double* out_dev, void* stream);
+
+/* Element-wise transforms on a whole array — what Dataset.power / Dataset.spline / Dataset.interact do per dask block
+ * (`_power` np.power(block, exp) dataset.py:527-543; hinge (x > knot) * (x - knot) dataset.py:475-481; `_interact`
+ * np.multiply(block, other) dataset.py:547-563).  x_dev [n] of x_dtype -> out_dev [n] of out_dtype (AFHIP_F32 / AFHIP_F64);
+ * transform AFHIP_TF_POW (arg = exponent: integer exponents through the correctly rounded double-double chain, others
+ * through pow), AFHIP_TF_HINGE (arg = knot) or AFHIP_TF_INTER (other_dev [n] of other_dtype; arg unused).  Arithmetic is
+ * float64 and the store rounds to out_dtype, except that a float32 -> float32 hinge / product is evaluated in float32
+ * like numpy's.  In-place (out_dev == x_dev with equal dtypes) is allowed. */
+int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, double arg,
+                    const void* other_dev, int other_dtype, void* out_dev, int out_dtype, void* stream);
 
 /* Ingestion helper (no counterpart in the reference, whose chunks are assembled by dask on the host,
  * aggfly/dataset/dataset.py:697-728): copies the part [st, st+nt) x [sy, sy+ny) x [sx, sx+nx) of a
@@ -179,6 +190,12 @@ typedef struct afhip_plan_desc {
 typedef struct afhip_plan afhip_plan;
 int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out);
 void afhip_plan_destroy(afhip_plan* plan);
+/* AFHIP_TF_INTER columns: bind column `column`'s second cube before the plan runs.  inter_dev [G1, n_cells] of `dtype`
+ * (AFHIP_F32 / AFHIP_F64), time-major like the cube: the value the column's inner reducer gives inner group g at a cell
+ * is multiplied by inter_dev[g * n_cells + cell] (np.multiply(block, other), dataset.py:563, on the inner level's
+ * output, whose time axis is the inner groups).  The pointer is read by every later run until it is bound again; the
+ * caller keeps the memory alive.  A run with an unbound AFHIP_TF_INTER column fails with AFHIP_E_INVALID. */
+int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* inter_dev, int dtype);
 /* Bytes of device scratch the plan needs (per-chunk partials + the cell-major panel). */
 int64_t afhip_plan_workspace_bytes(const afhip_plan* plan);
 /* Human-readable lowering (kernel variant, chunks, slots) into buf; returns bytes needed. */

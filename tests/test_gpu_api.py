@@ -323,9 +323,15 @@ def test_daily_data_two_level_specs_collapse_to_one_level(torch_cuda):
 
 
 def test_interact_and_spline_transforms(torch_cuda):
-    """X2: `inter` (element-wise product with a second dataset, dataset.py:483-563) runs staged in
-    HBM; `spline` (hinge at 20, dataset.py:475-481) is fused.  Both against the oracle."""
+    """X2: `inter` (element-wise product with a second dataset, dataset.py:483-563) and `spline` (hinge at 20,
+    dataset.py:475-481) are both fused into the streaming kernel's group end: ONE pass.  Against the oracle."""
+    from aggfly_amd import engine as eng
     ds, w, ods, ow = _mid_case(np.float64)
+    assert eng.lower_spec("tx", [("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "inter", "inter": ds}),
+                                 ("aggregate", {"calc": "sum", "groupby": "month"})])[1] is True
+    passes = []
+    real = eng._run_fused_pass
+    eng._run_fused_pass = lambda *a, **k: passes.append(1) or real(*a, **k)
     daily = af.aggregate_time(dataset=ds, weights=None, p=[("aggregate", {"calc": "max", "groupby": "date"})])["p"]
     odaily = ra.aggregate_time(ods, {"p": [("aggregate", {"calc": "max", "groupby": "date"})]})["p"]
     spec = lambda other: dict(
@@ -333,12 +339,82 @@ def test_interact_and_spline_transforms(torch_cuda):
             ("aggregate", {"calc": "sum", "groupby": "month"})],
         sp=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "spline"}),
             ("aggregate", {"calc": "sum", "groupby": "month"})])
-    got = af.aggregate_dataset(dataset=ds, weights=w, **spec(daily))
+    try:
+        n0 = len(passes)
+        got = af.aggregate_dataset(dataset=ds, weights=w, **spec(daily))
+        assert len(passes) - n0 == 1                                        # inter + spline + their sums: one fused pass
+    finally:
+        eng._run_fused_pass = real
     want = ra.aggregate_dataset(ow, ods, engine="numba", **spec(odaily))
     assert list(got.columns) == list(want.columns) == ["geoid", "time", "tx", "sp_spline1", "sp_spline2"]
     assert len(got) == len(want)
     np.testing.assert_allclose(got[["tx", "sp_spline1", "sp_spline2"]].values, want[["tx", "sp_spline1", "sp_spline2"]].values,
                                rtol=1e-12, equal_nan=True)
+    # the second array as a bare (lat, lon, time) numpy array, and a wrong shape -> the reference's AssertionError
+    got2 = af.aggregate_dataset(dataset=ds, weights=w, **spec(np.ascontiguousarray(np.moveaxis(odaily.values, 0, -1))))
+    np.testing.assert_array_equal(got2["tx"].values, got["tx"].values)
+    with pytest.raises(AssertionError):
+        af.aggregate_dataset(dataset=ds, weights=w, **spec(odaily.values))          # (time, lat, lon): not the data's layout
+    # inter on RAW data (before any aggregate) and after the outer level stay staged — through hip.transform
+    spec3 = dict(r=[("transform", {"transform": "inter", "inter": ds}), ("aggregate", {"calc": "mean", "groupby": "month"})])
+    ospec3 = dict(r=[("transform", {"transform": "inter", "inter": ods}), ("aggregate", {"calc": "mean", "groupby": "month"})])
+    g3, w3 = af.aggregate_dataset(dataset=ds, weights=w, **spec3), ra.aggregate_dataset(ow, ods, engine="numba", **ospec3)
+    np.testing.assert_allclose(g3["r"].values, w3["r"].values, rtol=1e-12, equal_nan=True)
+
+
+def test_dataset_transforms_run_in_the_hip_library(torch_cuda):
+    """`Dataset.power / spline / interact` (dataset.py:442-518) run `afhip_transform` — host arrays are uploaded, nothing is
+    computed in numpy or torch — and follow numpy's dtype rules: float32 ** python int stays float32, ** np.int64 -> float64."""
+    from aggfly_amd import hip
+    rng = np.random.default_rng(8)
+    arr = rng.normal(18, 9, (30, 5, 7))
+    arr[3, 1, 2] = np.nan
+    time = pd.date_range("2001-01-01", periods=30, freq="D")
+    mk = lambda a: af.Dataset(af.DataArray(a, ["time", "latitude", "longitude"], {"time": time, "latitude": np.arange(5.0), "longitude": np.arange(7.0)}))
+    calls = []
+    real = hip.transform
+    hip.transform = lambda *a, **k: calls.append(a[1]) or real(*a, **k)
+    try:
+        for dt in (np.float64, np.float32):
+            a = arr.astype(dt)
+            ds = mk(a)                                                     # host-resident: uploaded by the transform
+            for e in (np.int64(2), np.int64(3), 2, -1, 0.5, np.float64(1.5)):
+                got = ds.power(e)
+                want = np.power(a, e)
+                assert str(got.da.dtype).endswith(str(want.dtype)), (dt, e, got.da.dtype, want.dtype)
+                # numpy's own pow is within an ulp, not correctly rounded (SVML on AVX-512 hosts): bit-equal only for x * x
+                tol = 0 if want.dtype == np.float64 and float(e) == 2 else (3e-7 if want.dtype == np.float32 else 4e-16)
+                np.testing.assert_allclose(got.cube().cpu().numpy(), want, rtol=tol, atol=0, equal_nan=True)
+            s1, s2 = ds.spline()
+            assert s1 is ds
+            np.testing.assert_array_equal(s2.cube().cpu().numpy(), (a > 20) * (a - 20))
+            other = rng.normal(1, 0.5, (5, 7, 30)).astype(dt)            # (lat, lon, time): the dataset's own layout
+            got = ds.interact(other)
+            np.testing.assert_array_equal(got.cube().cpu().numpy(), a * np.moveaxis(other, -1, 0))
+            assert str(got.da.dtype).endswith(str(a.dtype))
+            got = ds.interact(mk(np.moveaxis(other, -1, 0).astype(np.float64)))         # a Dataset, float64: promotes
+            np.testing.assert_array_equal(got.cube().cpu().numpy(), a.astype(np.float64) * np.moveaxis(other, -1, 0).astype(np.float64))
+            with pytest.raises(AssertionError):
+                ds.interact(other[:, :, :5])
+            d2 = mk(a)
+            assert d2.power(2, update=True) is None and d2.history[-1] == "power2"
+            np.testing.assert_allclose(d2.cube().cpu().numpy(), np.power(a, 2), rtol=3e-7 if dt == np.float32 else 0, equal_nan=True)
+    finally:
+        hip.transform = real
+    assert calls.count("pow") == 14 and calls.count("hinge") == 2 and calls.count("inter") == 4
+
+
+def test_non_integer_exponent_is_fused(torch_cuda):
+    """`np.power` with a non-integer exponent (dataset.py:543) goes through the kernel's pow(): mean@date -> x ** 1.5 / 0.5
+    -> sum@month in one pass, against the oracle."""
+    ds, w, ods, ow = _mid_case(np.float64)
+    spec = dict(t=[("aggregate", {"calc": "max", "groupby": "date"}), ("transform", {"transform": "power", "exp": [np.array([0.5, 1.5, 2.0])]}),
+                   ("aggregate", {"calc": "sum", "groupby": "month"})])
+    got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+    want = ra.aggregate_dataset(ow, ods, engine="numba", **spec)
+    cols = ["t_0.5", "t_1.5", "t_2.0"]
+    assert list(got.columns)[2:] == cols == list(want.columns)[2:] and len(got) == len(want)
+    np.testing.assert_allclose(got[cols].values, want[cols].values, rtol=1e-12, equal_nan=True)
 
 
 def test_zarr_streams_straight_into_hbm(torch_cuda, tmp_path):

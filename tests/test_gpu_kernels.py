@@ -549,3 +549,36 @@ def test_c_abi_from_plain_c(torch_cuda, tmp_path):
                            "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "C ABI OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("dtype,odtype", [(np.float64, np.float64), (np.float32, np.float32), (np.float32, np.float64)])
+def test_fused_inter_column_bit_exact(torch_cuda, dtype, odtype):
+    """AFHIP_TF_INTER (`Dataset.interact`, dataset.py:483-518,547-563) at the group end of the streaming kernel: mean@date
+    times a second cube [G1, cells], then sum@month — against the oracle's np.multiply between the two levels, bit for bit
+    (exact_order), on ragged row lengths (scalar fallback) and on rows that take the vector arms; an unbound column fails."""
+    from aggfly_amd import hip
+    for (T, ny, nx) in ((24 * 70 + 5, 5, 7), (24 * 70 + 5, 6, 20)):
+        cube = _cube(T, ny, nx, dtype, seed=21)
+        ib = np.concatenate([np.arange(0, T, 24), [T]]).astype(np.int64)
+        G1 = len(ib) - 1
+        ob = np.unique(np.concatenate([np.arange(0, G1, 30), [G1]])).astype(np.int64)
+        other = np.random.default_rng(22).normal(1.0, 0.6, (G1, ny, nx)).astype(odtype)
+        other[2, 1, 3] = np.nan
+        cols = [dict(inner="mean", transform="inter", outer="sum"), dict(inner="max", transform="inter", outer="max"),
+                dict(inner="mean", outer="sum")]
+        plan = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols, exact_order=True)
+        d = torch_cuda.from_numpy(cube).cuda()
+        with pytest.raises(ValueError, match="never bound"):
+            plan.run_temporal(d)
+        od = torch_cuda.from_numpy(other).cuda()
+        plan.bind_inter(0, od)
+        plan.bind_inter(1, od)
+        with pytest.raises(ValueError, match="no inter transform"):
+            plan.bind_inter(2, od)
+        got = plan.run_temporal(d).cpu().numpy().reshape(3, len(ob) - 1, ny, nx)
+        m = cport.resample(cube.astype(np.float64), ib, "mean")
+        mx = cport.resample(cube.astype(np.float64), ib, "max")
+        o64 = other.astype(np.float64)
+        np.testing.assert_array_equal(got[0], cport.resample(np.multiply(m, o64), ob, "sum"))
+        np.testing.assert_array_equal(got[1], cport.resample(np.multiply(mx, o64), ob, "max"))
+        np.testing.assert_array_equal(got[2], cport.resample(m, ob, "sum"))

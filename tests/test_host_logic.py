@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.afhip_abi_version() == 1
+    assert lib.afhip_abi_version() == 2
     assert isinstance(hip.device_count(), int)
 
 
@@ -179,24 +179,30 @@ def test_dataset_sel_keeps_every_dimension():
 
 
 def test_transform_dataset_and_multi_dd_keys():
-    """`transform_dataset` / `multi_dd_to_dict` (`aggregate.py:36-78,285-303`): the eager helpers name their outputs
-    exactly as the DSL lowering does (`key_{e}`, `key_spline1/2`, `key_{lo}_{hi}`)."""
+    """`transform_dataset` / `multi_dd_to_dict` (`aggregate.py:36-78,285-303`): the eager helpers run the library's
+    element-wise kernel — without a GPU they fail loudly instead of computing in numpy (their numbers are checked on
+    the GPU, `test_gpu_api.py::test_dataset_transforms_run_in_the_hip_library`); the key naming is host logic."""
     from aggfly_amd.aggregate import multi_dd_to_dict, transform_dataset
+    from aggfly_amd.hip import HipEngineError
     arr, time, lat, lon = gi.dataset_360_inputs()
     ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}))
-    vals, keys = transform_dataset(ds, "tavg", transform="power", exp=[np.arange(1, 4)])
-    assert list(keys) == ["tavg_1", "tavg_2", "tavg_3"]
-    for e, v in zip((1, 2, 3), vals):
-        np.testing.assert_array_equal(v.cube(), np.power(ds.cube(), np.int64(e)))
-    vals, keys = transform_dataset(ds, "t", transform="spline")
-    assert list(keys) == ["t_spline1", "t_spline2"]
-    a, b = list(vals)
-    np.testing.assert_array_equal(b.cube(), (ds.cube() > 20) * (ds.cube() - 20))
-    vals, keys = transform_dataset(ds, "t", transform="interact", inter=ds)
-    assert list(keys) == ["t"] and np.array_equal(list(vals)[0].cube(), ds.cube() * ds.cube())
+    for kw in (dict(transform="power", exp=[np.arange(1, 4)]), dict(transform="spline"), dict(transform="interact", inter=ds)):
+        with pytest.raises(HipEngineError):
+            transform_dataset(ds, "tavg", **kw)
     with pytest.raises(ValueError, match="No valid transform"):
         transform_dataset(ds, "t", transform="log")
     assert multi_dd_to_dict(["a", "b"], "dd", [[10, 30, 0], [0, 5, 1]]) == (["a", "b"], ["dd_10_30", "dd_0_5"])
+    # the DSL lowering names the same outputs: key_{e}, key_spline1/2, and `inter` keeps its key — all three fused
+    from aggfly_amd.engine import lower_spec
+    agg = ("aggregate", {"calc": "mean", "groupby": "date"})
+    cols, fusable = lower_spec("tavg", [agg, ("transform", {"transform": "power", "exp": [np.arange(1, 4)]})])
+    assert [c.key for c in cols] == ["tavg_1", "tavg_2", "tavg_3"] and fusable
+    cols, fusable = lower_spec("t", [agg, ("transform", {"transform": "spline"})])
+    assert [c.key for c in cols] == ["t_spline1", "t_spline2"] and fusable
+    cols, fusable = lower_spec("t", [agg, ("transform", {"transform": "inter", "inter": ds}), ("aggregate", {"calc": "sum", "groupby": "month"})])
+    assert [c.key for c in cols] == ["t"] and fusable and cols[0].tf[0] == "inter"
+    cols, fusable = lower_spec("t", [("transform", {"transform": "inter", "inter": ds}), agg])          # on raw data: staged
+    assert not fusable
 
 
 def test_lat_and_time_windows_on_the_host_route(tmp_path):
