@@ -224,6 +224,16 @@ extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_s
     return AFHIP_OK;
 }
 
+extern "C" int afhip_panel_divide(const double* num_dev, const double* den_dev, double* res_dev, int64_t K, int64_t R,
+                                  int64_t P, void* stream) {
+    if (!num_dev || !den_dev || !res_dev || K < 0 || R < 0 || P < 0) return fail(AFHIP_E_INVALID, "panel_divide: bad arguments");
+    const int64_t n = K * R * P;
+    if (n == 0) return AFHIP_OK;
+    hipLaunchKernelGGL(k_divide_num_den, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, num_dev, den_dev, res_dev, n, R * P);
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
 extern "C" int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, double arg,
                                const void* other_dev, int other_dtype, void* out_dev, int out_dtype, void* stream) {
     if (!x_dev || !out_dev || n < 0) return fail(AFHIP_E_INVALID, "transform: NULL array or negative size");

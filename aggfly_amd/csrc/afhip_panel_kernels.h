@@ -309,6 +309,16 @@ __global__ __launch_bounds__(WG) void k_panel_divide(const double* __restrict__ 
     }
 }
 
+// res[k][rp] = num[k][rp] / den[rp] where den != 0 else NaN (spatial.py:127-133) on separate arrays: the divide after the
+// all-reduce of a cell-sharded job.
+__global__ __launch_bounds__(WG) void k_divide_num_den(const double* __restrict__ num, const double* __restrict__ den,
+                                                       double* __restrict__ res, int64_t n, int64_t RP) {
+    const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const double de = den[i % RP];
+    res[i] = (de != 0.0) ? num[i] / de : nan64();
+}
+
 // x[K][C][nt] -> panel[C][nt][K+1] with shared validity (spatial.py:114-123); used by
 // afhip_spatial_wavg, whose input layout is the reference's (cell, time) block per name.
 __global__ __launch_bounds__(WG) void k_validity_panel(const double* __restrict__ x, double* __restrict__ panel,

@@ -33,7 +33,7 @@ EXPORTS = (
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
-    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform", "afhip_panel_divide",
 )
 
 
@@ -102,6 +102,7 @@ def load():
     lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     lib.afhip_plan_bind_inter.argtypes = [vp, i32, vp, i32]
     lib.afhip_transform.argtypes = [vp, i32, i64, i32, dbl, vp, i32, vp, i32, vp]
+    lib.afhip_panel_divide.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.afhip_plan_profile_begin.argtypes = [vp, i64]
     lib.afhip_plan_profile_end.argtypes = [vp, C.POINTER(C.c_float), i64]
     lib.afhip_plan_profile_end.restype = i64
@@ -234,6 +235,19 @@ def transform(x, kind: str, arg: float = 0.0, other=None, out_dtype=None):
     _check(lib.afhip_transform(x.data_ptr(), _dtype_code(x), x.numel(), code, float(arg), optr, ocode,
                                out.data_ptr(), _dtype_code(out), _stream_ptr()))
     return out
+
+
+def panel_divide(num, den, out=None):
+    """res = num / den where den != 0 else NaN (`aggfly/aggregate/spatial.py:127-133`): num [K, R, P], den [R, P] float64 HBM."""
+    torch = _torch()
+    require_gpu()
+    num, den = num.contiguous(), den.contiguous()
+    if num.dtype != torch.float64 or den.dtype != torch.float64 or num.ndim != 3 or tuple(num.shape[1:]) != tuple(den.shape) or not num.is_cuda:
+        raise ValueError("panel_divide: num [K, R, P] and den [R, P] must be float64 HBM tensors")
+    res = torch.empty_like(num) if out is None else out
+    K, R, P = (int(v) for v in num.shape)
+    _check(load().afhip_panel_divide(num.data_ptr(), den.data_ptr(), res.data_ptr(), K, R, P, _stream_ptr()))
+    return res
 
 
 def group_stat(cube, bounds, calc: str):

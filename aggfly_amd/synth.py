@@ -42,25 +42,31 @@ def temperature_cube(T: int, ny: int, nx: int, dtype=np.float64, seed: int = 202
 
 
 def _kd_rects(ny, nx, R, rng):
-    rects = [(0, ny, 0, nx)]
-    while len(rects) < R:
-        # split the largest rectangle along its longer side at a random interior cut
-        i = max(range(len(rects)), key=lambda q: (rects[q][1] - rects[q][0]) * (rects[q][3] - rects[q][2]))
-        y0, y1, x0, x1 = rects.pop(i)
+    """Recursive k-d split: always the LARGEST rectangle (the earliest one among equals) is cut along its longer side at a
+    random interior position.  A heap keyed on (-area, insertion order) picks exactly the rectangle a linear scan for the
+    first maximum would, in O(R log R) instead of O(R^2) (40,000 regions on the 0.1 degree grid took a minute)."""
+    import heapq
+    heap, alive, n = [(-(ny * nx), 0)], {0: (0, ny, 0, nx)}, 1
+    while len(alive) < R:
+        _, i = heapq.heappop(heap)
+        y0, y1, x0, x1 = alive.pop(i)
         h, w = y1 - y0, x1 - x0
-        if h * w < 2:
-            rects.append((y0, y1, x0, x1))
+        parts = None
+        if h * w >= 2:
+            if h >= w and h >= 2:
+                c = int(rng.integers(y0 + 1, y1))
+                parts = [(y0, c, x0, x1), (c, y1, x0, x1)]
+            elif w >= 2:
+                c = int(rng.integers(x0 + 1, x1))
+                parts = [(y0, y1, x0, c), (y0, y1, c, x1)]
+        if parts is None:                      # nothing left to split: the rectangle goes back (to the end, as before)
+            alive[n] = (y0, y1, x0, x1)
             break
-        if h >= w and h >= 2:
-            c = int(rng.integers(y0 + 1, y1))
-            rects += [(y0, c, x0, x1), (c, y1, x0, x1)]
-        elif w >= 2:
-            c = int(rng.integers(x0 + 1, x1))
-            rects += [(y0, y1, x0, c), (y0, y1, c, x1)]
-        else:
-            rects.append((y0, y1, x0, x1))
-            break
-    return rects
+        for r in parts:
+            alive[n] = r
+            heapq.heappush(heap, (-((r[1] - r[0]) * (r[3] - r[2])), n))
+            n += 1
+    return [alive[k] for k in sorted(alive)]
 
 
 def weights_table(ny: int, nx: int, R: int, seed: int = 7, secondary: bool = False,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-cell-timesteps/s of the fused transform + weighted reduce.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--shard time|cells]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], shapes per SURVEY.md §8d): one year of hourly ERA5-like
@@ -11,20 +11,34 @@ fp64, synthetic), ~3.1k regions with area weights, and the fused plan
     dd[10,30]@date -> sum@year      +      mean@date -> power[1..4] -> sum@year      (K = 5)
 
 A "step" is one whole pass of the hot path over one resident year: fused temporal kernel,
-slot merge + shared validity, CSR weighted sums, divide (and, for N > 1, the RCCL
-all-gather of the region x period panel, which runs on the collective's stream beside the
-next step's kernels; every gather completes inside the timed region).  Inputs are resident in HBM before the timed
-region.  With N > 1 every rank owns a different year (time-axis sharding on outer-period
-boundaries, weak scaling): value = N * T * cells / max-over-ranks time.
+slot merge + shared validity, CSR weighted sums, divide, and for N > 1 the one exchange step of the
+sharding.  Inputs are resident in HBM before the timed region.
+
+  --shard time   (default) every rank owns a different year (time-axis sharding on outer-period
+                 boundaries, the north_star's split): weak scaling, value = N * T * cells / max-over-ranks time;
+                 the exchange is the RCCL all-gather of the region x period panel (on the collective's
+                 stream beside the next step's kernels; every gather completes inside the timed region).
+  --shard cells  configs[1] itself has ONE output period, so N GPUs can only split its cells: every rank
+                 owns a latitude band of the SAME year, reduces it against the band's share of the weights,
+                 and one RCCL all-reduce(sum) of the (K+1) x R numerators / denominators + one divide finish
+                 the panel: strong scaling, value = T * cells / max-over-ranks time.
+
+N > 1 needs one GPU per rank and runs on RCCL ("nccl").  With fewer visible GPUs than local ranks the
+bench REFUSES to run unless AGGFLY_BENCH_BACKEND=gloo is set explicitly (a rehearsal: ranks share a card,
+the exchange goes through the host); the JSON line always carries the backend, the visible devices and the
+distinct devices the ranks really used.
 
 The JSON line also carries
-  roofline      the fused temporal kernel against the HBM peak: algorithmic bytes
-                (T * cells * 8 B per launch) / the kernel's mean duration,
-                measured with HIP events around every launch of the timed region;
-  cpu_baseline  the plain-C port of the reference's numba engine (oracle/c) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N = 1).
+  roofline       the fused temporal kernel against the HBM peak: algorithmic bytes
+                 (T * cells * 8 B per launch) / the kernel's mean duration,
+                 measured with HIP events around every launch of the timed region; `traffic` is the
+                 PMC-measured HBM bytes per launch from profiles/traffic.json with its provenance;
+  cpu_baseline   the plain-C port of the reference's numba engine (oracle/c) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N = 1);
+  other_configs  (N = 1) the other four BASELINE configs, a few steps each, kernel time and roofline.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,6 +51,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes: this pool's driver only supports dmabuf IPC
 
 HBM_PEAK_GBPS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy rate
+VALU_PEAK_LANE_INST = 256 * 4 * 16 * 2.4e9       # fp64 VALU issue peak: 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz
 
 
 def c2_columns():
@@ -45,17 +60,26 @@ def c2_columns():
     return cols
 
 
-def make_cube(torch, T, ny, nx, dtype, seed):
-    """ERA5-like synthetic temperatures generated on the device, slab by slab."""
+def make_cube(torch, T, ny, nx, dtype, seed, steps_per_day=24, lat_lo=0.6, lat_hi=1.4):
+    """ERA5-like synthetic temperatures generated on the device, slab by slab: seasonal cycle + a cycle
+    inside the day (24 hourly steps; 2 steps = (tmin, tmax) pairs; 1 = daily means) + N(0, 3)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     cube = torch.empty((T, ny, nx), dtype=dtype, device="cuda")
-    lat = torch.linspace(0.6, 1.4, ny, device="cuda", dtype=torch.float64)[None, :, None]
-    for k0 in range(0, T, 256):
-        k1 = min(T, k0 + 256)
+    lat = torch.linspace(lat_lo, lat_hi, ny, device="cuda", dtype=torch.float64)[None, :, None]
+    slab = max(1, (1 << 28) // max(ny * nx, 1))
+    for k0 in range(0, T, slab):
+        k1 = min(T, k0 + slab)
         k = torch.arange(k0, k1, device="cuda", dtype=torch.float64)
-        base = 15.0 + 12.0 * torch.sin(2 * np.pi * torch.floor(k / 24) / 365.0) + 6.0 * torch.sin(2 * np.pi * (k % 24) / 24.0)
-        noise = torch.randn((k1 - k0, ny, nx), generator=g, device="cuda", dtype=torch.float32).to(torch.float64) * 3.0
-        cube[k0:k1] = (base[:, None, None] * lat + noise).to(dtype)
+        base = 15.0 + 12.0 * torch.sin(2 * np.pi * torch.floor(k / steps_per_day) / 365.0)
+        if steps_per_day == 2:
+            base = base + 6.0 * (2.0 * (k % 2) - 1.0)                   # tmin, tmax
+        elif steps_per_day > 2:
+            base = base + 6.0 * torch.sin(2 * np.pi * (k % steps_per_day) / steps_per_day)
+        noise = torch.randn((k1 - k0, ny, nx), generator=g, device="cuda", dtype=torch.float32)
+        if dtype == torch.float32:
+            cube[k0:k1] = (base[:, None, None] * lat).to(torch.float32) + noise * 3.0
+        else:
+            cube[k0:k1] = base[:, None, None] * lat + noise.to(torch.float64) * 3.0
     return cube
 
 
@@ -69,6 +93,16 @@ def host_cores() -> int:
     except (OSError, ValueError):
         pass
     return n
+
+
+def lib_build_id() -> str:
+    """Identity of the HIP library this process runs: the first 12 hex digits of its SHA-256."""
+    from aggfly_amd import hip
+    h = hashlib.sha256()
+    with open(hip.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:12]
 
 
 def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
@@ -164,6 +198,92 @@ def cpu_baseline_dask_path(T, ny_sample, nx, seed, target_s=8.0):
                       f"thread pool of {cores})"}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the other BASELINE configs (N = 1): a few steps each, kernel time by HIP events, whole pass by the host clock
+# ---------------------------------------------------------------------------------------------------------------------
+def _valu_counts():
+    """VALU instructions per grid-cell-timestep of the VALU-bound kernels, from the committed PMC passes (profiles/)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_counts.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def run_other_configs(torch, steps=5, warmup=2):
+    from aggfly_amd import hip, synth
+    out = []
+    valu = _valu_counts()
+    edges = np.arange(-20, 50, 5.0)
+    cfgs = [
+        dict(name="C1", workload="BASELINE configs[0] on the counties extent: hourly t2m 1 year, 215x1440 cells, 3100 regions area weights, "
+                                 "mean@date->power[1,2]->sum@year, f32 storage, K=2",
+             T=8760, ny=215, nx=1440, spd=24, periods=1, R=3100, dtype="f32", secondary=False,
+             cols=[dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)]),
+        dict(name="C3", workload="BASELINE configs[2] shape: hourly t2m 40 years (T=350640), CONUS window 104x236 cells, 3100 regions with "
+                                 "population secondary weights, mean@date->power[1,2]->sum@year, f32 storage, K=2, P=40",
+             T=350640, ny=104, nx=236, spd=24, periods=40, R=3100, dtype="f32", secondary=True,
+             cols=[dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)]),
+        dict(name="C4", workload="BASELINE configs[3] shape: daily tas 251 years noleap (T=91615), 180x288 cells, 3600 regions with cropland "
+                                 "secondary weights, 13 temperature bins (5 degC, -20..45) per year, f32 storage, K=13, P=251",
+             T=91615, ny=180, nx=288, spd=1, periods=251, R=3600, dtype="f32", secondary=True, single_level=True,
+             cols=[dict(inner="bins", inner_args=(edges[i], edges[i + 1], 0)) for i in range(13)]),
+        dict(name="C5", workload="BASELINE configs[4] shape: 0.1 deg global 1801x3600 cells, 365 (tmin, tmax) pairs (T=730), 40000 regions, "
+                                 "sine_dd[10,30]@date->sum@year, f32 storage, K=1",
+             T=730, ny=1801, nx=3600, spd=2, periods=1, R=40000, dtype="f32", secondary=False,
+             cols=[dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum")]),
+    ]
+    only = os.environ.get("AGGFLY_BENCH_ONLY")          # e.g. "C5": one config (PMC passes over a single kernel)
+    for c in cfgs:
+        if only and c["name"] not in only.split(","):
+            continue
+        t_cfg = time.perf_counter()
+        try:
+            T, ny, nx = c["T"], c["ny"], c["nx"]
+            C = ny * nx
+            elem = 4 if c["dtype"] == "f32" else 8
+            dt_t = torch.float32 if c["dtype"] == "f32" else torch.float64
+            cube = make_cube(torch, T, ny, nx, dt_t, seed=20260105, steps_per_day=c["spd"])
+            ib = synth.hourly_bounds(T, c["spd"])
+            G1 = len(ib) - 1
+            ob = np.round(np.linspace(0, G1, c["periods"] + 1)).astype(np.int64)
+            if c.get("single_level"):
+                ib, ob = ib[ob], np.arange(c["periods"] + 1, dtype=np.int64)
+            tab = synth.weights_table(ny, nx, c["R"], seed=7, secondary=c["secondary"])
+            R = int(tab["index_right"].max()) + 1
+            csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, C)
+            plan = hip.FusedPlan(T, C, hip.F32 if c["dtype"] == "f32" else hip.F64, ib, ob, c["cols"])
+            outb = plan.run(cube, csr)
+            for _ in range(warmup):
+                plan.run(cube, csr, out=outb)
+            torch.cuda.synchronize()
+            plan.profile_begin(steps)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                plan.run(cube, csr, out=outb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            kms = plan.profile_end()
+            k_ms = float(np.mean(kms))
+            hbm = T * C * elem / (k_ms * 1e-3) / 1e9
+            row = {"config": c["name"], "workload": c["workload"], "dtype": c["dtype"], "steps": steps,
+                   "ms_per_step": dt / steps * 1e3, "value": T * C * steps / dt, "kernel": plan.describe().split()[0].replace("variant=", ""),
+                   "kernel_ms_mean": k_ms, "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
+                   "algorithmic_bytes_per_launch": T * C * elem, "regions": R, "nnz": int(csr.nnz)}
+            vc = valu.get(c["name"])
+            if vc:      # a VALU-bound kernel: its own roofline beside the HBM figure
+                inst = vc["valu_inst_per_cell_step"] * T * C / (k_ms * 1e-3)
+                row.update({"bound": "valu", "achieved": inst, "peak": VALU_PEAK_LANE_INST, "unit": "lane-instructions/s",
+                            "frac": inst / VALU_PEAK_LANE_INST, "valu_inst_per_cell_step": vc["valu_inst_per_cell_step"],
+                            "valu_count_source": vc.get("source"), "hbm_achieved_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBPS})
+            out.append(row)
+            del cube, csr, plan, outb
+        except Exception as e:  # never take the headline number down
+            out.append({"config": c["name"], "workload": c["workload"], "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
+        out[-1]["setup_and_run_s"] = round(time.perf_counter() - t_cfg, 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,26 +294,36 @@ def main():
     ap.add_argument("--T", type=int, default=8760)
     ap.add_argument("--regions", type=int, default=3100)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--shard", default="time", choices=["time", "cells"],
+                    help="N > 1: time = one year per GPU + all-gather (weak scaling); cells = latitude bands of one year + all-reduce (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from aggfly_amd import hip, synth
+    from aggfly_amd import distributed as D, hip, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE") or world)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     ndev = torch.cuda.device_count()
-    dev = local_rank % max(ndev, 1)          # rehearsal of N > 1 on a 1-GPU box shares the card
+    backend = None
+    if world > 1:
+        forced = os.environ.get("AGGFLY_BENCH_BACKEND")
+        if ndev < local_world and forced != "gloo":
+            raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible. RCCL needs one GPU per rank; "
+                             "a number measured with ranks sharing a card is not a scaling result. Set AGGFLY_BENCH_BACKEND=gloo "
+                             "to rehearse the N > 1 code path on fewer cards (the line then says backend gloo).")
+        backend = forced or "nccl"
+    dev = local_rank % max(ndev, 1)          # only a gloo rehearsal ever shares a card
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL needs one GPU per rank; AGGFLY_BENCH_BACKEND=gloo rehearses the N > 1 code path on one card
-        backend = os.environ.get("AGGFLY_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -204,28 +334,48 @@ def main():
     C = ny * nx
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     elem = 8 if args.dtype == "f64" else 4
-    cube = make_cube(torch, T, ny, nx, dtype, seed=20260101 + rank)          # rank r owns year r
+    cells_mode = args.shard == "cells"
     ib = synth.hourly_bounds(T)
     ob = np.array([0, len(ib) - 1], dtype=np.int64)
     tab = synth.weights_table(ny, nx, args.regions, seed=7)
     R = int(tab["index_right"].max()) + 1
-    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, C)
+    rows_, cols_, w_ = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+    if cells_mode:
+        # strong scaling: rank r owns latitude rows [y0, y1) of the same year and the weights that fall on them
+        y0, y1 = D.split_even(ny, rank, world)
+        if y1 <= y0:
+            raise SystemExit(f"--shard cells: {world} ranks for {ny} latitude rows")
+        my_ny = y1 - y0
+        cube = make_cube(torch, T, my_ny, nx, dtype, seed=20260101 + rank,
+                         lat_lo=0.6 + 0.8 * y0 / max(ny - 1, 1), lat_hi=0.6 + 0.8 * (y1 - 1) / max(ny - 1, 1))
+        br, bc, bw = D.band_csr_triplets(rows_, cols_, w_, ny, nx, y0, y1)
+        csr = hip.CSR(br, bc, bw, R, my_ny * nx)
+        my_C = my_ny * nx
+    else:
+        cube = make_cube(torch, T, ny, nx, dtype, seed=20260101 + rank)          # rank r owns year r
+        csr = hip.CSR(rows_, cols_, w_, R, C)
+        my_C = C
     cols = c2_columns()
     K = len(cols)
-    plan = hip.FusedPlan(T, C, hip.F64 if args.dtype == "f64" else hip.F32, ib, ob, cols)
+    plan = hip.FusedPlan(T, my_C, hip.F64 if args.dtype == "f64" else hip.F32, ib, ob, cols)
     out = {"num": torch.empty((K, R, 1), dtype=torch.float64, device="cuda"),
            "den": torch.empty((R, 1), dtype=torch.float64, device="cuda"),
            "res": torch.empty((K, R, 1), dtype=torch.float64, device="cuda")}
-    # N > 1: the region x period panel of every step is all-gathered (RCCL over xGMI).  Two result buffers, so that
+    # time sharding, N > 1: the region x period panel of every step is all-gathered.  Two result buffers, so that
     # the gather of step i (on the collective's own stream) overlaps the kernels of step i + 1; a buffer is reused
     # only after its gather has finished, and every gather is waited for inside the timed region.
-    pipelined = world > 1 and os.environ.get("AGGFLY_BENCH_PIPELINE", "1") != "0"
+    pipelined = world > 1 and not cells_mode and os.environ.get("AGGFLY_BENCH_PIPELINE", "1") != "0"
     outs = [out] + ([{k: torch.empty_like(v) for k, v in out.items()}] if pipelined else [])
     use_flat = world > 1 and dist.get_backend() == "nccl"
-    if use_flat:        # one RCCL call straight into [world, K, R, 1]
-        gathered = [torch.empty((world,) + tuple(out["res"].shape), dtype=torch.float64, device="cuda") for _ in outs]
-    else:
-        gathered = [[torch.empty_like(out["res"]) for _ in range(world)] for _ in outs] if world > 1 else None
+    gathered, flat = None, None
+    if world > 1 and not cells_mode:
+        if use_flat:        # one RCCL call straight into [world, K, R, 1]
+            gathered = [torch.empty((world,) + tuple(out["res"].shape), dtype=torch.float64, device="cuda") for _ in outs]
+        else:
+            gathered = [[torch.empty_like(out["res"]) for _ in range(world)] for _ in outs]
+    if cells_mode:
+        flat = torch.empty(((K + 1) * R,), dtype=torch.float64, device="cuda")     # num | den of one step, summed over ranks
+        full = torch.empty((K, R, 1), dtype=torch.float64, device="cuda")
     pending = [None] * len(outs)
 
     def step(i):
@@ -234,7 +384,14 @@ def main():
             pending[b].wait()                                 # the gather that last read this buffer
             pending[b] = None
         plan.run(cube, csr, out=outs[b])
-        if world > 1:
+        if cells_mode:
+            # one exchange: sum the ranks' numerators and denominators, then the library's divide (spatial.py:127-133)
+            flat[:K * R].copy_(outs[b]["num"].reshape(-1))
+            flat[K * R:].copy_(outs[b]["den"].reshape(-1))
+            if world > 1:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            hip.panel_divide(flat[:K * R].view(K, R, 1), flat[K * R:].view(R, 1), out=full)
+        elif world > 1:
             if use_flat:
                 w = dist.all_gather_into_tensor(gathered[b], outs[b]["res"], async_op=pipelined)
             else:
@@ -265,44 +422,73 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms = plan.profile_end()
-    if world > 1:       # outside the timed region: the gathered panel really holds this rank's result of the last step
-        b = (args.steps - 1) % len(outs)
+    # outside the timed region: the exchanged panel really holds this rank's result of the last step
+    b = (args.steps - 1) % len(outs)
+    if world > 1 and not cells_mode:
         mine = gathered[b][rank]
         if not torch.equal(torch.nan_to_num(mine), torch.nan_to_num(outs[b]["res"])):
             raise SystemExit(f"rank {rank}: gathered panel differs from the local result")
+    if cells_mode and world == 1:
+        if not torch.equal(torch.nan_to_num(full), torch.nan_to_num(outs[b]["res"])):
+            raise SystemExit("cell arm: the divided panel differs from the plan's own result")
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # which devices did the ranks really run on?
+    props = torch.cuda.get_device_properties(dev)
+    ident = (os.uname().nodename, str(getattr(props, "uuid", "")) or f"index{dev}", props.name)
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
 
     if rank == 0:
-        traffic = None
+        build = lib_build_id()
+        traffic, traffic_source, traffic_build = None, None, None
         try:   # PMC-derived HBM bytes per launch for this workload, collected in a separate rocprofv3 --pmc pass
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj.get(f"c2_{args.dtype}_T{T}_C{C}", {}).get("hbm_bytes_per_launch")
+            ent = tj.get(f"c2_{args.dtype}_T{T}_C{my_C}", {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "profiles/traffic.json: " + str(ent.get("source"))
+                traffic_build = ent.get("build")
         except (OSError, ValueError):
             pass
         ms_per_step = dt / args.steps * 1e3
-        value = world * T * C * args.steps / dt
+        units = (T * C) if cells_mode else (world * T * C)          # cells: one year split over the ranks; time: one year per rank
+        value = units * args.steps / dt
         k_ms = float(np.mean(kms)) if kms else float("nan")
-        achieved = T * C * elem / (k_ms * 1e-3) / 1e9
+        achieved = T * my_C * elem / (k_ms * 1e-3) / 1e9
+        if world == 1:
+            sharding = "single GPU" + (" (cell arm: num/den -> library divide, no exchange)" if cells_mode else "")
+        elif cells_mode:
+            sharding = (f"cell axis: {world} latitude bands of one year, one {'RCCL' if backend == 'nccl' else backend} all-reduce(sum) of "
+                        f"(K+1) x R doubles + one divide per step")
+        else:
+            sharding = (f"time axis, one year per GPU; {'RCCL' if backend == 'nccl' else backend} all-gather of the panel"
+                        + (", overlapped with the next step's kernels" if pipelined else ""))
         line = {
             "metric": "grid-cell-timesteps/s (fused transform+weighted reduce)",
             "value": value, "unit": "grid-cell-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if cells_mode else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ERA5-like hourly t2m 0.25deg, 1 year per GPU, US-counties extent "
+            "backend": backend if world > 1 else "none (single process)", "ranks": world, "devices_visible": ndev,
+            "devices_used": len({i[:2] for i in idents}), "device_names": sorted({i[2] for i in idents}),
+            "config": {"workload": "BASELINE configs[1]: ERA5-like hourly t2m 0.25deg, 1 year" + ("" if cells_mode else " per GPU") + ", US-counties extent "
                                    f"{ny}x{nx} cells, {R} regions area weights, fused dd[10,30]@date->sum@year + "
                                    "mean@date->power[1..4]->sum@year, %s, K=5" % ("fp64" if args.dtype == "f64" else "fp32 storage / fp64 accumulation"),
-                       "T": T, "cells": C, "regions": R, "columns": K, "nnz": int(csr.nnz),
-                       "sharding": ("time axis, one year per GPU; RCCL all-gather of the panel"
-                                    + (", overlapped with the next step's kernels" if pipelined else "")) if world > 1 else "single GPU",
-                       "plan": plan.describe()},
+                       "T": T, "cells": C, "cells_per_rank": my_C, "regions": R, "columns": K, "nnz": int(csr.nnz),
+                       "shard": args.shard, "sharding": sharding, "plan": plan.describe()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_source, "traffic_build": traffic_build, "build": build,
+                         "traffic_measured_on_this_build": bool(traffic_build) and traffic_build == build,
                          "kernel": "k_fused_temporal", "kernel_ms_mean": k_ms, "launches": len(kms),
-                         "algorithmic_bytes_per_launch": T * C * elem},
+                         "algorithmic_bytes_per_launch": T * my_C * elem},
         }
+        if world > 1 and len({i[:2] for i in idents}) < world:
+            line["warning"] = "ranks shared a GPU (gloo rehearsal): not a scaling measurement"
         if world == 1 and not args.no_cpu_baseline:
             # both CPU engines of the reference, restated (oracle/): the faster one is THE baseline
             cands = []
@@ -314,6 +500,10 @@ def main():
             cands.sort(key=lambda c: -(c["value"] or 0.0))
             line["cpu_baseline"] = cands[0]
             line["cpu_baseline_other_engine"] = cands[1]
+        if world == 1 and not args.no_other_configs and (T, ny, nx) == (8760, 215, 1440):
+            del cube
+            torch.cuda.empty_cache()
+            line["other_configs"] = run_other_configs(torch)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -148,6 +148,12 @@ int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
 int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int64_t K, int64_t nt,
                        double* num_dev, double* den_dev, double* res_dev, void* stream);
 
+/* The divide of SpatialAggregator.compute on its own (spatial.py:127-133): res = num / den where den != 0 else NaN.
+ * num_dev [K, R, P], den_dev [R, P], res_dev [K, R, P] float64.  For cell-axis sharding across GPUs: every rank's
+ * numerators and denominators are summed first (one all-reduce), then divided once. */
+int afhip_panel_divide(const double* num_dev, const double* den_dev, double* res_dev, int64_t K, int64_t R,
+                       int64_t P, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused plan: one pass over the raw cube for all output columns.
  *

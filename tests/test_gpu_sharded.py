@@ -253,3 +253,33 @@ def test_seasonal_store_gaps_on_shard_and_window_boundaries(torch_cuda, tmp_path
                        timeout=300, env=dict(env, WINDOW_BYTES=wb))
     assert r.returncode == 0, r.stderr[-2000:]
     pd.testing.assert_frame_equal(a, pd.read_csv(both), check_exact=True)
+
+
+def test_bench_two_rank_rehearsal_reports_backend_and_devices(torch_cuda, tmp_path):
+    """bench.py with 2 ranks on this one-GPU box: refused by default; with AGGFLY_BENCH_BACKEND=gloo it runs as a labelled
+    rehearsal — the JSON line says backend gloo, devices_visible 1, devices_used 1, and carries the warning.  Both sharding arms."""
+    import json
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible: the rehearsal path is for one-GPU boxes")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]
+    small = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--ny", "40", "--nx", "64", "--T", "720", "--regions", "30"]
+    env = {k: v for k, v in os.environ.items() if k != "AGGFLY_BENCH_BACKEND"}
+    r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr
+    for shard, scaling in (("time", "weak"), ("cells", "strong")):
+        r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small + ["--shard", shard], capture_output=True, text=True,
+                           timeout=600, env=dict(env, AGGFLY_BENCH_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["backend"] == "gloo" and line["devices_visible"] == 1 and line["devices_used"] == 1 and line["ranks"] == 2
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and "warning" in line and "gloo" in line["config"]["sharding"]
+        assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # one process, cell arm: the divide after the (absent) exchange reproduces the plan's own panel
+    r = subprocess.run([sys.executable, bench, "--steps", "2", "--warmup", "1", "--ny", "40", "--nx", "64", "--T", "720", "--regions", "30",
+                        "--shard", "cells", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["backend"].startswith("none") and line["devices_used"] == 1 and line["scaling"] == "strong"

@@ -350,3 +350,17 @@ def test_choose_backend_compares_with_the_local_world(monkeypatch):
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
     assert choose_backend(8) == "gloo" and choose_backend(16) == "nccl"
     assert choose_backend(1, "nccl") == "nccl"
+
+
+def test_bench_refuses_ranks_without_their_own_gpu():
+    """bench.py --gpus N: N ranks on fewer visible GPUs must not silently share a card and fall back to gloo — the run is
+    refused (non-zero exit) unless AGGFLY_BENCH_BACKEND=gloo asks for a rehearsal; --gpus N outside a launcher is refused too."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr and "AGGFLY_BENCH_BACKEND=gloo" in r.stderr
+    assert r.stdout.strip() == ""                                     # no JSON line from a refused run
