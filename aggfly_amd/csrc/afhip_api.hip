@@ -77,11 +77,27 @@ struct DevBuf {
 
 }  // namespace
 
+// Long rows are cut into segments that are summed by separate threads / waves and then added in row order
+// (k_csr_combine_segments): real admin-2 tables span four decades of row lengths, and one lane walking a 10^5-entry row
+// alone would be the whole kernel's tail.  The segment length follows the table: ~nnz / 4096 entries (64 .. 1024, a
+// multiple of 64), so that a table dominated by a few huge rows still spreads over the chip (a 55 k-entry table whose
+// longest row holds 19 k: 21.1 ms serial, 1.5 ms in 1024-entry segments, profiles/r02_spmm_skew.txt), while the rows of an
+// ordinary table (hundreds of entries) stay whole; a row is cut into at most 128 pieces (the combine adds them serially).
+// exact_order plans never segment (table order, one running sum).
+constexpr int64_t SPMM_SEG_MIN = 64, SPMM_SEG_MAX = 1024, SPMM_TARGET_SEGS = 4096, SPMM_MAX_PIECES = 128;
+
 struct afhip_csr {
-    int64_t R = 0, nnz = 0, n_cells = 0;
+    int64_t R = 0, nnz = 0, n_cells = 0, max_row = 0;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> cols;
     DevBuf<double> w;
+    // work list of the default (non-exact) route: segment v = entries [seg_ptr[v], seg_ptr[v+1]) of one row; its sums go
+    // to row seg_dst[v] of the sums buffer: the region's own row (an unsplit region) or scratch row R + k (a piece)
+    int64_t nseg = 0, n_extra = 0, n_split = 0;
+    DevBuf<int64_t> seg_ptr;
+    DevBuf<int32_t> seg_dst;
+    DevBuf<int32_t> split_row;      // [n_split] regions that were cut
+    DevBuf<int32_t> split_ptr;      // [n_split + 1] their pieces: scratch rows R + [split_ptr[i], split_ptr[i+1])
 };
 
 struct afhip_plan {
@@ -102,6 +118,8 @@ struct afhip_plan {
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
     bool hb_arith = false; double hb_w = 0, hb_lo0 = 0, hb_gl = 0, hb_gh = 0;   // ... with exactly representable edges
+    int xcd_remap = 1;        // measured +0.2..1 % on configs[1] (profiles/r01_xcd_remap.txt): harmless, kept on
+    bool counts_spmm = true;  // packed-count plans: gather the records directly when no per-cell output is asked for
     bool packed = false;      // single-level, all columns plain bin counts: partial holds packed records (FusedArgs::packed)
     PackFmt pk{};             // their format; pk_bw = bits per count
     int hb_bin_of_slot[MAX_THR] = {0};
@@ -174,10 +192,39 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
     }
     auto* h = new afhip_csr();
     h->R = R; h->nnz = nnz; h->n_cells = n_cells;
+    std::vector<int64_t> seg_ptr;
+    std::vector<int32_t> seg_dst, split_row, split_ptr(1, 0);
+    seg_ptr.reserve((size_t)R + 1); seg_dst.reserve((size_t)R);
+    auto up64 = [](int64_t x) { return (x + 63) / 64 * 64; };
+    int64_t seg = std::min(SPMM_SEG_MAX, std::max(SPMM_SEG_MIN, up64(nnz / SPMM_TARGET_SEGS)));
+    if (const char* e = getenv("AFHIP_SPMM_SEG")) seg = std::max<int64_t>(64, up64(atoll(e)));      // experiment knob
+    for (int64_t r = 0; r < R; ++r) {
+        const int64_t j0 = indptr[r], j1 = indptr[r + 1], len = j1 - j0;
+        h->max_row = std::max(h->max_row, len);
+        if (len <= seg) {
+            seg_ptr.push_back(j0); seg_dst.push_back((int32_t)r);
+        } else {
+            const int64_t want = std::min(SPMM_MAX_PIECES, (len + seg - 1) / seg);
+            const int64_t piece = up64((len + want - 1) / want);
+            const int64_t pieces = (len + piece - 1) / piece;
+            for (int64_t i = 0; i < pieces; ++i) {
+                seg_ptr.push_back(j0 + i * piece);
+                seg_dst.push_back((int32_t)(R + h->n_extra + i));
+            }
+            h->n_extra += pieces;
+            split_row.push_back((int32_t)r);
+            split_ptr.push_back((int32_t)h->n_extra);
+        }
+    }
+    seg_ptr.push_back(nnz);
+    h->nseg = (int64_t)seg_dst.size(); h->n_split = (int64_t)split_row.size();
+    if (R + h->n_extra > INT32_MAX) { delete h; return fail(AFHIP_E_INVALID, "csr_create: too many rows"); }
     int rc;
     if ((rc = h->indptr.upload(std::vector<int64_t>(indptr, indptr + R + 1))) ||
         (rc = h->cols.upload(c32)) ||
-        (rc = h->w.upload(std::vector<double>(w, w + nnz)))) {
+        (rc = h->w.upload(std::vector<double>(w, w + nnz))) ||
+        (rc = h->seg_ptr.upload(seg_ptr)) || (rc = h->seg_dst.upload(seg_dst)) ||
+        (rc = h->split_row.upload(split_row)) || (rc = h->split_ptr.upload(split_ptr))) {
         delete h;
         return rc;
     }
@@ -187,19 +234,54 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
 
 extern "C" void afhip_csr_destroy(afhip_csr* csr) { delete csr; }
 
-static int launch_spmm(const afhip_csr* csr, const double* X, double* out, int64_t Q, hipStream_t st) {
-    const int64_t n = csr->R * Q;
-    if (n == 0) return AFHIP_OK;
-    const unsigned blocks = (unsigned)((n + WG - 1) / WG);
-    hipLaunchKernelGGL(k_csr_spmm, dim3(blocks), dim3(WG), 0, st, csr->indptr.p, csr->cols.p, csr->w.p, X, out, csr->R, Q);
+// AGGFLY_HIP_EXACT_ORDER=1 (read once): the standalone spatial entry points then sum in table order like the plans
+// created with exact_order.  AFHIP_SPMM_SERIAL=1 (experiment knob): the serial kernel for every route.
+static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
+static bool spmm_serial_env() { static const bool v = env_flag("AFHIP_SPMM_SERIAL") || env_flag("AGGFLY_HIP_EXACT_ORDER"); return v; }
+
+// rows of the sums buffer a spatial stage needs: the regions + the scratch rows of cut regions
+static int64_t spmm_rows(const afhip_csr* csr) { return csr->R + csr->n_extra; }
+
+// out[r][q] = sum_j w[j] * X[col[j]][q] for every region r (rows [0, R) of `out`, which holds spmm_rows(csr) x Q doubles).
+//   exact:  one thread per (r, q) walks the whole row in table order — bit-identical to np.add.at (spatial.py:185);
+//   else:   rows in segments of <= SPMM_SEG entries; Q <= 16: one WAVE per segment, lanes stride over the entries and a fixed
+//           butterfly adds the 64 partial sums (deterministic, not table order: ~1e-16 from the serial sum); Q > 16: one
+//           thread per (segment, q); the pieces of a cut row are then added in row order.
+static int launch_spmm(const afhip_csr* csr, const double* X, double* out, int64_t Q, hipStream_t st, bool exact) {
+    if (csr->R * Q == 0) return AFHIP_OK;
+    if (exact || spmm_serial_env()) {
+        const int64_t n = csr->R * Q;
+        hipLaunchKernelGGL(k_csr_spmm, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, csr->indptr.p, (const int32_t*)nullptr,
+                           csr->cols.p, csr->w.p, X, out, csr->R, Q);
+        HIP_TRY(hipGetLastError());
+        return AFHIP_OK;
+    }
+    if (Q <= 16) {
+        const unsigned blocks = (unsigned)((csr->nseg + (WG / 64) - 1) / (WG / 64));      // one wave per segment
+        if (Q <= 2) hipLaunchKernelGGL(k_csr_spmm_wave<2>, dim3(blocks), dim3(WG), 0, st, csr->seg_ptr.p, csr->seg_dst.p, csr->cols.p, csr->w.p, X, out, csr->nseg, (int)Q);
+        else if (Q <= 4) hipLaunchKernelGGL(k_csr_spmm_wave<4>, dim3(blocks), dim3(WG), 0, st, csr->seg_ptr.p, csr->seg_dst.p, csr->cols.p, csr->w.p, X, out, csr->nseg, (int)Q);
+        else if (Q <= 8) hipLaunchKernelGGL(k_csr_spmm_wave<8>, dim3(blocks), dim3(WG), 0, st, csr->seg_ptr.p, csr->seg_dst.p, csr->cols.p, csr->w.p, X, out, csr->nseg, (int)Q);
+        else hipLaunchKernelGGL(k_csr_spmm_wave<16>, dim3(blocks), dim3(WG), 0, st, csr->seg_ptr.p, csr->seg_dst.p, csr->cols.p, csr->w.p, X, out, csr->nseg, (int)Q);
+    } else {
+        const int64_t n = csr->nseg * Q;
+        hipLaunchKernelGGL(k_csr_spmm, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, csr->seg_ptr.p, csr->seg_dst.p,
+                           csr->cols.p, csr->w.p, X, out, csr->nseg, Q);
+    }
     HIP_TRY(hipGetLastError());
+    if (csr->n_split) {
+        const int64_t n = csr->n_split * Q;
+        hipLaunchKernelGGL(k_csr_combine_segments, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, out, csr->split_row.p,
+                           csr->split_ptr.p, csr->R, Q, csr->n_split);
+        HIP_TRY(hipGetLastError());
+    }
     return AFHIP_OK;
 }
 
 extern "C" int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
                                    double* out_dev, void* stream) {
     if (!csr || !block_dev || !out_dev || nt < 0) return fail(AFHIP_E_INVALID, "scatter_block: bad arguments");
-    return launch_spmm(csr, block_dev, out_dev, nt, (hipStream_t)stream);
+    // the drop-in for _scatter_block: always the table-order sum (out_dev holds exactly R rows)
+    return launch_spmm(csr, block_dev, out_dev, nt, (hipStream_t)stream, true);
 }
 
 extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
@@ -272,24 +354,25 @@ extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int
     const int64_t C = csr->n_cells, Q = (K + 1) * nt;
     double *panel = nullptr, *sums = nullptr;
     HIP_TRY(hipMallocAsync((void**)&panel, (size_t)(C * Q) * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&sums, (size_t)std::max<int64_t>(csr->R * Q, 1) * sizeof(double), st));
-    {
+    hipError_t e = hipMallocAsync((void**)&sums, (size_t)std::max<int64_t>(spmm_rows(csr) * Q, 1) * sizeof(double), st);
+    int rc = AFHIP_OK;
+    if (e != hipSuccess) {
+        rc = fail(AFHIP_E_HIP, "hipMallocAsync failed: %s", hipGetErrorString(e));
+    } else {
         const int64_t n = C * nt;
         hipLaunchKernelGGL(k_validity_panel, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, x_dev, panel, C, nt, (int)K);
-        HIP_TRY(hipGetLastError());
-    }
-    int rc = launch_spmm(csr, panel, sums, Q, st);
-    if (rc) return rc;
-    {
-        const int64_t n = K > 0 ? csr->R * nt : 0;            // one thread per (region, time step)
-        if (n) {
-            hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, sums, num_dev, den_dev, res_dev, csr->R, nt, (int)K);
-            HIP_TRY(hipGetLastError());
+        if ((e = hipGetLastError()) != hipSuccess) rc = fail(AFHIP_E_HIP, "k_validity_panel launch failed: %s", hipGetErrorString(e));
+        if (!rc) rc = launch_spmm(csr, panel, sums, Q, st, false);
+        const int64_t m = csr->R * nt;                            // one thread per (region, time step)
+        if (!rc && m) {
+            hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((m + WG - 1) / WG)), dim3(WG), 0, st, sums, num_dev, den_dev, res_dev, csr->R, nt, (int)K);
+            if ((e = hipGetLastError()) != hipSuccess) rc = fail(AFHIP_E_HIP, "k_panel_divide launch failed: %s", hipGetErrorString(e));
         }
     }
-    HIP_TRY(hipFreeAsync(panel, st));
-    HIP_TRY(hipFreeAsync(sums, st));
-    return AFHIP_OK;
+    // both scratch buffers go back on every path (stream-ordered: after the kernels that read them)
+    (void)hipFreeAsync(panel, st);
+    if (sums) (void)hipFreeAsync(sums, st);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -635,6 +718,9 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     auto a256 = [](int64_t b) { return (b + 255) / 256 * 256; };
     // packed counts: integer-bin single-level variant, every column a plain bin count, no period longer than a
     // 16-bit counter holds (0xFFFF is the NaN mark)
+    // experiment knobs, read once per plan (never on the run path)
+    if (const char* e = getenv("AFHIP_XCD_REMAP")) pl->xcd_remap = atoi(e) ? 1 : 0;
+    pl->counts_spmm = !getenv("AFHIP_NO_COUNTS_SPMM");
     pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
     for (const ColOp& c : pl->cols)
         pl->packed = pl->packed && c.src == SRC_THR && c.tf == TF_NONE && c.rounding == 0 && c.outer == OUT_FIRST;
@@ -703,8 +789,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     fa.gtab = pl->d_gtab.p; fa.chunks = pl->d_chunks.p;
     fa.partial = partial; fa.K = pl->K; fa.nthr = pl->nthr;
     fa.n_tiles = (int32_t)pl->tiles;
-    fa.xcd_remap = 1;      // measured +0.2..1 % on configs[1] (profiles/r01_xcd_remap.txt): harmless, kept on
-    if (const char* e = getenv("AFHIP_XCD_REMAP")) fa.xcd_remap = atoi(e) ? 1 : 0;   // experiment knob
+    fa.xcd_remap = pl->xcd_remap;
     for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];
     for (int i = pl->nthr; i < MAX_THR; ++i) {       // padded slots never fire
         fa.thr[i] = ThrSlot{};
@@ -794,7 +879,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     const int64_t K = plan->K, P = plan->desc.P, Q = (K + 1) * P;
     // partial + panel live in the caller's workspace when given; the small [R][Q] sums
     // buffer is always plan-owned (its size depends on the CSR, not on the plan)
-    const int64_t sums_bytes = (std::max<int64_t>(csr->R * Q, 1) * 8 + 255) / 256 * 256;
+    const int64_t sums_bytes = (std::max<int64_t>(spmm_rows(csr) * Q, 1) * 8 + 255) / 256 * 256;
     if (plan->sums_bytes < sums_bytes) {
         if (plan->sums) { HIP_TRY(hipFree(plan->sums)); plan->sums = nullptr; plan->sums_bytes = 0; }
         HIP_TRY(hipMalloc((void**)&plan->sums, (size_t)sums_bytes));
@@ -814,18 +899,26 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
     if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
-    if (plan->packed && !cells_dev && plan->n_slots <= P && !getenv("AFHIP_NO_COUNTS_SPMM")) {
+    const bool exact = plan->desc.exact_order != 0 || spmm_serial_env();
+    if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {
         // bin-count plan, no per-cell output wanted: the weighted sums gather the packed counts directly
-        // (every period has at most one slot: single-level plans are never split)
-        const int64_t nq = csr->R * P;
+        // (every period has at most one slot: single-level plans are never split); long rows in segments unless exact
+        const int64_t nv = exact ? csr->R : csr->nseg, nq = nv * P;
         if (nq) {
-            hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st, csr->indptr.p, csr->cols.p,
-                               csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)K, plan->desc.n_cells, plan->pk);
+            hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st,
+                               exact ? csr->indptr.p : csr->seg_ptr.p, exact ? (const int32_t*)nullptr : csr->seg_dst.p, csr->cols.p,
+                               csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk);
             HIP_TRY(hipGetLastError());
+            if (!exact && csr->n_split) {
+                const int64_t n = csr->n_split * Q;
+                hipLaunchKernelGGL(k_csr_combine_segments, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, plan->sums, csr->split_row.p,
+                                   csr->split_ptr.p, csr->R, Q, csr->n_split);
+                HIP_TRY(hipGetLastError());
+            }
         }
     } else {
         if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
-        if ((rc = launch_spmm(csr, panel, plan->sums, Q, st))) return rc;
+        if ((rc = launch_spmm(csr, panel, plan->sums, Q, st, exact))) return rc;
     }
     const int64_t n = K > 0 ? csr->R * P : 0;                 // one thread per (region, period)
     if (n) {

@@ -209,14 +209,17 @@ __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, co
 // k_csr_spmm: x = where(valid, count, 0), valid = no NaN among the K columns; a count plan's columns are NaN
 // together (empty period) or not at all, so column 0 tells.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+// Rows may be segments of regions (launch_spmm in afhip_api.hip): row v = entries [indptr[v], indptr[v+1]); its record goes
+// to row dst_row[v] of `out` (null: v itself).
+__global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restrict__ indptr, const int32_t* __restrict__ dst_row,
+                                                        const int32_t* __restrict__ cols,
                                                         const double* __restrict__ w, const void* __restrict__ packed,
                                                         const int32_t* __restrict__ slot_ptr, double* __restrict__ out,
                                                         int64_t R, int64_t P, int K, int64_t C, const PackFmt pk) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;       // = r * P + p: a wave walks the periods of one region
     if (tid >= R * P) return;
     const int64_t r = tid / P, p = tid - r * P;
-    double* dst = out + tid * (K + 1);
+    double* dst = out + ((dst_row ? (int64_t)dst_row[r] : r) * P + p) * (K + 1);
     const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
     double acc[MAX_COLS + 1];
 #pragma unroll
@@ -256,12 +259,13 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// k_csr_spmm: out[r][q] = sum_j w[j] * X[col[j]][q], j over the row in table order.
-// One thread per (r, q), q fastest, so a wave reads whole rows of X contiguously.  The
+// k_csr_spmm: out[dst[v]][q] = sum_j w[j] * X[col[j]][q], j over row v = [indptr[v], indptr[v+1]) in table order (dst null:
+// v itself; rows may be segments of regions, see launch_spmm in afhip_api.hip).
+// One thread per (v, q), q fastest, so a wave reads whole rows of X contiguously.  The
 // product is rounded before the add (no FMA): np.add.at adds the already-rounded
 // contrib = w * block[...] (spatial.py:183-185).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ indptr,
+__global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ indptr, const int32_t* __restrict__ dst,
                                                  const int32_t* __restrict__ cols,
                                                  const double* __restrict__ w,
                                                  const double* __restrict__ X, double* __restrict__ out,
@@ -281,7 +285,74 @@ __global__ __launch_bounds__(WG) void k_csr_spmm(const int64_t* __restrict__ ind
         for (int u = 0; u < 8; ++u) accv = __dadd_rn(accv, p[u]);
     }
     for (; j < j1; ++j) accv = __dadd_rn(accv, __dmul_rn(w[j], X[(int64_t)cols[j] * Q + q]));
-    out[tid] = accv;
+    out[(dst ? (int64_t)dst[r] : r) * Q + q] = accv;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_csr_spmm_wave: the same sums for few output columns (Q <= QB <= 16: annual panels, K + 1 values per cell), one WAVE per
+// row (segment).  One thread per (row, q) leaves a wave with 64 / Q different rows, each lane walking its own row alone:
+// uncoalesced index / weight reads, and the longest of those rows holds the other lanes.  Here the lanes stride over the
+// row's entries (cols / w read as contiguous runs, 64 x UNR gathers in flight per wave), every lane keeps Q partial sums,
+// and a fixed xor butterfly adds the 64 partials: deterministic, the same for any launch shape, but not the table
+// order of np.add.at (spatial.py:185) — plans created with exact_order take k_csr_spmm instead.
+// ---------------------------------------------------------------------------------------
+template <int QB>
+__global__ __launch_bounds__(WG) void k_csr_spmm_wave(const int64_t* __restrict__ seg_ptr, const int32_t* __restrict__ dst,
+                                                      const int32_t* __restrict__ cols, const double* __restrict__ w,
+                                                      const double* __restrict__ X, double* __restrict__ out,
+                                                      int64_t nseg, int Q) {
+    const int64_t v = (int64_t)blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (v >= nseg) return;                                        // whole waves leave together: no partial-wave shuffles
+    const int lane = threadIdx.x & 63;
+    const int64_t j0 = seg_ptr[v], j1 = seg_ptr[v + 1];
+    double acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[q] = 0.0;
+    constexpr int UNR = QB <= 4 ? 4 : 2;                          // entries in flight per lane
+    int64_t j = j0 + lane;
+    for (; j + (UNR - 1) * 64 < j1; j += UNR * 64) {
+        double x[UNR][QB], wj[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t c = (int64_t)cols[j + u * 64] * Q;
+            wj[u] = w[j + u * 64];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) x[u][q] = (q < Q) ? X[c + q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[q] = __dadd_rn(acc[q], __dmul_rn(wj[u], x[u][q]));
+    }
+    for (; j < j1; j += 64) {
+        const int64_t c = (int64_t)cols[j] * Q;
+        const double wj = w[j];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = __dadd_rn(acc[q], __dmul_rn(wj, (q < Q) ? X[c + q] : 0.0));
+    }
+    // xor butterfly over the 64 lanes: every lane ends with the same sum, the shape never depends on the data
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = __dadd_rn(acc[q], __shfl_xor(acc[q], m, 64));
+    }
+    if (lane == 0) {
+        double* o = out + (int64_t)dst[v] * Q;
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            if (q < Q) o[q] = acc[q];
+    }
+}
+
+// The pieces of a cut region, added in row order: sums[split_row[i]][q] = sum over scratch rows R + [split_ptr[i], split_ptr[i+1]).
+__global__ __launch_bounds__(WG) void k_csr_combine_segments(double* __restrict__ sums, const int32_t* __restrict__ split_row,
+                                                             const int32_t* __restrict__ split_ptr, int64_t R, int64_t Q, int64_t n_split) {
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (tid >= n_split * Q) return;
+    const int64_t i = tid / Q, q = tid - i * Q;
+    double a = 0.0;
+    for (int64_t k = split_ptr[i]; k < split_ptr[i + 1]; ++k) a = __dadd_rn(a, sums[(R + k) * Q + q]);
+    sums[(int64_t)split_row[i] * Q + q] = a;
 }
 
 // sums[R][P][K+1] -> num[K][R][P], den[R][P], res[K][R][P] (spatial.py:127-133).

@@ -69,9 +69,48 @@ def _kd_rects(ny, nx, R, rng):
     return [alive[k] for k in sorted(alive)]
 
 
+def skewed_weights_table(ny: int, nx: int, R: int, seed: int = 7, sigma: float = 2.0, longest: int = 100_000,
+                         lat0: float = 24.0, dlat: float = 0.25) -> pd.DataFrame:
+    """A weights table whose rows span four decades of lengths, like real admin-2 / GADM regions on a fine grid (a k-d
+    split gives near-uniform rows): region sizes are log-normal (``sigma`` in log space), the largest region is at least
+    ``longest`` cells (or a third of the grid), every region holds at least one cell, and the sizes add up to the grid.
+    Regions are runs of cells in row-major order (bands and pieces of bands); the last cell of a run also belongs to the
+    next region with a random fraction, like a border cell.  Same schema and ordering as `weights_table`."""
+    rng = np.random.default_rng(seed)
+    C = ny * nx
+    R = min(R, C)
+    raw = rng.lognormal(0.0, sigma, R)
+    big = int(np.argmax(raw))
+    want_big = min(longest, C // 3)
+    rest = C - want_big - (R - 1)                       # cells left once every other region has its first cell
+    others = np.delete(raw, big)
+    share = np.floor(others / others.sum() * max(rest, 0)).astype(np.int64)
+    sizes = np.ones(R, dtype=np.int64)
+    sizes[np.arange(R) != big] += share
+    sizes[big] = C - (sizes.sum() - 1)                   # the remainder: >= want_big
+    order = rng.permutation(R)                           # where each region sits along the grid
+    starts = np.concatenate([[0], np.cumsum(sizes[order])])
+    coslat = np.cos(np.deg2rad(lat0 + dlat * np.arange(ny)))
+    cell = np.arange(C, dtype=np.int64)
+    reg = np.repeat(order, sizes[order]).astype(np.int64)
+    wt = coslat[cell // nx].copy()
+    # border cells: the first cell of the next run also gets a share of this region
+    nxt = starts[1:-1]
+    u = rng.uniform(0.05, 0.95, len(nxt))
+    df = pd.DataFrame({"cell_id": np.concatenate([cell, nxt]), "index_right": np.concatenate([reg, order[:-1]]).astype(np.int64),
+                       "weight": np.concatenate([wt, coslat[nxt // nx] * u])})
+    return df.sort_values(["index_right", "cell_id"], kind="stable").reset_index(drop=True)
+
+
 def weights_table(ny: int, nx: int, R: int, seed: int = 7, secondary: bool = False,
-                  zero_frac: float = 0.0, lat0: float = 24.0, dlat: float = 0.25) -> pd.DataFrame:
-    """Weights table [cell_id, index_right, weight] over an ny x nx grid with ~R regions."""
+                  zero_frac: float = 0.0, lat0: float = 24.0, dlat: float = 0.25, skew: str = None) -> pd.DataFrame:
+    """Weights table [cell_id, index_right, weight] over an ny x nx grid with ~R regions.  ``skew="lognormal"``: row
+    lengths over four decades with one row of >= 10^5 cells (`skewed_weights_table`) instead of the near-uniform k-d split."""
+    if skew == "lognormal":
+        df = skewed_weights_table(ny, nx, R, seed=seed, lat0=lat0, dlat=dlat)
+        return _secondary_and_zero(df, ny, nx, seed, secondary, zero_frac, int(df["index_right"].max()) + 1)
+    if skew is not None:
+        raise ValueError("skew must be None or 'lognormal'")
     rng = np.random.default_rng(seed)
     rects = _kd_rects(ny, nx, R, rng)
     coslat = np.cos(np.deg2rad(lat0 + dlat * np.arange(ny)))
@@ -87,6 +126,10 @@ def weights_table(ny: int, nx: int, R: int, seed: int = 7, secondary: bool = Fal
     df = pd.DataFrame({"cell_id": np.concatenate(cell).astype(np.int64),
                        "index_right": np.concatenate(reg).astype(np.int64),
                        "weight": np.concatenate(wt)})
+    return _secondary_and_zero(df, ny, nx, seed, secondary, zero_frac, len(rects))
+
+
+def _secondary_and_zero(df, ny, nx, seed, secondary, zero_frac, n_regions):
     if secondary:
         pop = np.random.default_rng(seed + 11).lognormal(0.0, 1.5, ny * nx)
         raster = pop[df["cell_id"].to_numpy()]
@@ -94,8 +137,8 @@ def weights_table(ny: int, nx: int, R: int, seed: int = 7, secondary: bool = Fal
         tot = pd.Series(raster).groupby(df["index_right"].to_numpy()).transform("sum").to_numpy()
         df["weight"] = area * raster / tot                      # grid_weights.py:487-489
     if zero_frac > 0:
-        nz = max(1, int(zero_frac * len(rects)))
-        zr = np.random.default_rng(seed + 12).choice(len(rects), nz, replace=False)
+        nz = max(1, int(zero_frac * n_regions))
+        zr = np.random.default_rng(seed + 12).choice(n_regions, nz, replace=False)
         df.loc[df["index_right"].isin(zr), "weight"] = 0.0
     # table order as a geodataframe join would give it: by region, then cell
     return df.sort_values(["index_right", "cell_id"], kind="stable").reset_index(drop=True)

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--spd", type=int, default=24, help="steps per inner group (24 hourly, 1 daily, 2 tmin/tmax)")
     ap.add_argument("--periods", type=int, default=1, help="outer periods (years)")
     ap.add_argument("--regions", type=int, default=3100)
+    ap.add_argument("--skew", default=None, choices=[None, "lognormal"],
+                    help="lognormal: region sizes over four decades with one row of >= 1e5 cells (synth.skewed_weights_table)")
     ap.add_argument("--data", default="iid", choices=["iid", "era5"],
                     help="iid: 15 + N(0, 12) per element (every wave meets every branch); era5: seasonal + diurnal cycle + N(0, 3), "
                          "the synthetic field of SURVEY.md 8(d) (neighbouring cells and days resemble each other, as in real data)")
@@ -65,7 +67,9 @@ def main():
         cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)]
     else:
         raise SystemExit("plan must be c1, c2, c4 or c5")
-    wdf = synth.weights_table(a.ny, a.nx, a.regions, seed=7)
+    wdf = synth.weights_table(a.ny, a.nx, a.regions, seed=7, skew=a.skew)
+    rl = wdf.groupby("index_right").size()
+    print(f"weights table: {len(rl)} regions, {len(wdf)} entries, row lengths min {rl.min()} median {int(rl.median())} max {rl.max()}", flush=True)
     R = int(wdf["index_right"].max()) + 1
     csr = hip.CSR(wdf["index_right"].to_numpy(), wdf["cell_id"].to_numpy(), wdf["weight"].to_numpy(), R, C)
     code = hip.F64 if a.dtype == "f64" else hip.F32
@@ -102,7 +106,7 @@ def main():
                      "cell_steps_per_s": a.T * C / (float(np.median(tot[t])) / 1e3)})
         print(json.dumps(rows[-1]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/kbench_{a.plan}_{a.dtype}_{a.ny}x{a.nx}{'' if a.data == 'iid' else '_' + a.data}.json", "w") as f:
+    with open(f"gpurun_out/kbench_{a.plan}_{a.dtype}_{a.ny}x{a.nx}{'' if a.data == 'iid' else '_' + a.data}{'' if not a.skew else '_' + a.skew}.json", "w") as f:
         json.dump({"args": vars(a), "bytes": bytes_alg, "rows": rows}, f, indent=1)
 
 

@@ -356,7 +356,8 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     np.testing.assert_array_equal(hip.group_bins(d, bounds, dda).cpu().numpy(), want)
     cols = [dict(inner="bins", inner_args=r) for r in dda]
     code = hip.F64 if dtype == np.float64 else hip.F32
-    plan = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), cols)
+    # exact_order: the spatial sums below run in table order on every route (bit for bit against the host loop)
+    plan = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), cols, exact_order=True)
     assert "_hist" in plan.describe(), plan.describe()
     got = plan.run_temporal(d).cpu().numpy()                             # [D, G, cells]
     np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want.reshape(3, -1, 13))
@@ -385,7 +386,7 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     # 13 counts of up to 365 fit a 16-byte record (9-bit fields); one 730-step period needs 10 bits -> 16-bit fields, 32 bytes
     assert "packed-counts16" in plan.describe(), plan.describe()
     whole = np.array([0, T], dtype=np.int64)
-    plan_w = hip.FusedPlan(T, ny * nx, code, whole, np.arange(2), cols)
+    plan_w = hip.FusedPlan(T, ny * nx, code, whole, np.arange(2), cols, exact_order=True)
     assert "packed-counts32" in plan_w.describe(), plan_w.describe()
     want_w = cport.block_bins(cube, whole, dda).reshape(1, -1, 13)
     np.testing.assert_array_equal(np.transpose(plan_w.run_temporal(d).cpu().numpy(), (1, 2, 0)), want_w)
@@ -582,3 +583,60 @@ def test_fused_inter_column_bit_exact(torch_cuda, dtype, odtype):
         np.testing.assert_array_equal(got[0], cport.resample(np.multiply(m, o64), ob, "sum"))
         np.testing.assert_array_equal(got[1], cport.resample(np.multiply(mx, o64), ob, "max"))
         np.testing.assert_array_equal(got[2], cport.resample(m, ob, "sum"))
+
+
+def test_skewed_rows_take_the_wave_and_segment_paths(torch_cuda):
+    """Real admin-2 tables span four decades of row lengths.  On a log-normal table (rows of 2 .. 50,000 entries) the
+    default spatial stage runs one wave per row segment (few output columns) or one thread per (segment, column) and adds
+    the pieces of cut rows in order — a different association than np.add.at's table order, so 1e-12 against the oracle's
+    `_scatter_block` restatement (spatial.py:181-199); `afhip_scatter_block` and exact_order plans keep the table order
+    bit for bit."""
+    from aggfly_amd import hip
+    ny, nx, R = 300, 500, 800
+    tab = synth.weights_table(ny, nx, R, seed=11, skew="lognormal", zero_frac=0.01)
+    lens = tab.groupby("index_right").size()
+    assert lens.max() >= 40_000 and lens.min() <= 3 and (lens > 1024).sum() >= 5             # cut rows exist
+    ridx, cidx, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+    nR = int(ridx.max()) + 1
+    csr = hip.CSR(ridx, cidx, w, nR, ny * nx)
+    rng = np.random.default_rng(12)
+    for K, nt in ((1, 1), (2, 1), (5, 1), (3, 3), (2, 10)):          # Q = 2, 3, 6, 12 (one wave per segment) and 30 (thread per column)
+        x = rng.normal(20, 5, (K, ny * nx, nt))
+        x[0, rng.integers(0, ny * nx, 500), rng.integers(0, nt, 500)] = np.nan
+        nums, den, ids = spatial_num_den({f"k{k}": x[k] for k in range(K)}, tab, np.arange(ny * nx))
+        gn, gd, gr = csr.wavg(torch_cuda.from_numpy(x).cuda())
+        np.testing.assert_allclose(gd.cpu().numpy(), den, rtol=1e-12, atol=0)
+        for k in range(K):
+            np.testing.assert_allclose(gn[k].cpu().numpy(), nums[f"k{k}"], rtol=1e-12, atol=1e-9)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = np.where(den != 0, np.stack([nums[f"k{k}"] for k in range(K)]) / den, np.nan)
+        np.testing.assert_allclose(gr.cpu().numpy(), want, rtol=1e-11, equal_nan=True)
+    block = rng.normal(20, 5, (ny * nx, 3))
+    np.testing.assert_array_equal(csr.scatter_block(torch_cuda.from_numpy(block).cuda()).cpu().numpy(), ref_scatter(block, ridx, cidx, w, nR))
+    # a fused plan: exact_order = table order bit for bit; the default = the same numbers to rounding
+    T = 24 * 20
+    cube = _cube(T, ny, nx, np.float64, seed=13)
+    ib = synth.hourly_bounds(T)
+    ob = np.array([0, len(ib) - 1], dtype=np.int64)
+    cols = [dict(inner="mean", outer="sum"), dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+    d = torch_cuda.from_numpy(cube).cuda()
+    ex = hip.FusedPlan(T, ny * nx, hip.F64, ib, ob, cols, exact_order=True).run(d, csr, want_cells=True)
+    cells = ex["cells"].cpu().numpy()                                 # [K, 1, C]
+    valid = ~np.isnan(cells).any(axis=0)[0]
+    for k in range(2):
+        np.testing.assert_array_equal(ex["num"][k, :, 0].cpu().numpy(),
+                                      ref_scatter(np.where(valid, cells[k, 0], 0.0)[:, None], ridx, cidx, w, nR)[:, 0])
+    fast = hip.FusedPlan(T, ny * nx, hip.F64, ib, ob, cols).run(d, csr)
+    np.testing.assert_allclose(fast["res"].cpu().numpy(), ex["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+    # bin counts (packed records gathered directly, segments of cut rows added afterwards) == the panel route
+    Td = 365 * 3
+    daily = _cube(Td, ny, nx, np.float32, seed=14)[::1]
+    edges = np.arange(-20, 50, 5.0)
+    bcols = [dict(inner="bins", inner_args=(edges[i], edges[i + 1], 0)) for i in range(13)]
+    yb = np.array([0, 365, 730, 1095], dtype=np.int64)
+    plan = hip.FusedPlan(Td, ny * nx, hip.F32, yb, np.arange(4, dtype=np.int64), bcols)
+    assert "packed-counts" in plan.describe()
+    dd = torch_cuda.from_numpy(daily).cuda()
+    direct = plan.run(dd, csr)["res"].cpu().numpy()
+    via_panel = plan.run(dd, csr, want_cells=True)["res"].cpu().numpy()
+    np.testing.assert_allclose(direct, via_panel, rtol=1e-12, equal_nan=True)
