@@ -268,6 +268,44 @@ def _same_labels(a, b) -> bool:
     return len(a) == len(b) and bool(np.all(np.asarray(a) == np.asarray(b)))
 
 
+def union_labels(axes):
+    """The output time axis of several names: the sorted UNION of their labels, as the reference's
+    `xr.combine_by_coords` (an outer join, `aggfly/aggregate/spatial.py:90-92`) builds it, and each axis' positions in it."""
+    if all(isinstance(t, CFTimeIndex) for t in axes):
+        if len({t.calendar for t in axes}) != 1:
+            raise ValueError("output variables are on different calendars")
+        secs = np.unique(np.concatenate([t.seconds for t in axes]))
+        return CFTimeIndex(secs, axes[0].calendar), [np.searchsorted(secs, t.seconds) for t in axes]
+    if any(isinstance(t, CFTimeIndex) for t in axes):
+        raise ValueError("output variables mix a CF calendar with a standard one")
+    idx = [pd.DatetimeIndex(t) for t in axes]
+    u = idx[0]
+    for t in idx[1:]:
+        u = u.union(t)
+    return u, [u.get_indexer(t) for t in idx]
+
+
+def _aligned_cells(datasets):
+    """-> (x [K, n_cells, P] float64 in HBM, labels): every name's [P_k, ny, nx] result laid on the union of the names'
+    output labels.  Where a name has no value for a label the reference's outer join fills NaN (`spatial.py:90-97`); the
+    shared validity mask then voids that period for EVERY name (`spatial.py:114-119`) and its rows are dropped — only
+    placement happens here (index copies), the masking is the spatial kernels'."""
+    import torch
+    axes = [_labels_of(d) for d in datasets]
+    same = all(_same_labels(axes[0], a) for a in axes[1:])
+    labels, pos = (axes[0], None) if same else union_labels(axes)
+    xs = []
+    for i, d in enumerate(datasets):
+        c = eng.device_cube(d)                                   # [P_k, ny, nx]
+        c = c.reshape(c.shape[0], -1).to(torch.float64)
+        if not same:
+            full = torch.full((len(labels), c.shape[1]), float("nan"), dtype=torch.float64, device=c.device)
+            full.index_copy_(0, torch.as_tensor(np.asarray(pos[i], dtype=np.int64), device=c.device), c)
+            c = full
+        xs.append(c.t())
+    return torch.stack(xs).contiguous(), labels
+
+
 def _label_values(labels):
     if isinstance(labels, CFTimeIndex):
         arr = np.empty(len(labels), dtype=object)
@@ -365,19 +403,8 @@ class SpatialAggregator:
         self.zero_weight = getattr(weights, "zero_weight", "area")
 
     def compute(self, npartitions: int = None) -> pd.DataFrame:
-        import torch
-        labels = _labels_of(self.dataset[0])
-        for d in self.dataset[1:]:
-            if not _same_labels(labels, _labels_of(d)):
-                raise ValueError("all output variables must share one output time axis "
-                                 "(the reference would align them with NaN fill and drop the rows)")
         csr, region_ids = eng.get_csr(self.weights_obj, self.dataset[0])
-        # [K, n_cells, P] float64 in HBM
-        xs = []
-        for d in self.dataset:
-            c = eng.device_cube(d)                                   # [P, ny, nx]
-            xs.append(c.reshape(c.shape[0], -1).t().to(torch.float64))
-        x = torch.stack(xs).contiguous()
+        x, labels = _aligned_cells(self.dataset)                      # [K, n_cells, P] float64 in HBM, P = union of the labels
         _, _, res = csr.wavg(x)
         return _assemble_frame(res, self.names, region_ids, labels, self.weights_obj)
 
@@ -436,16 +463,8 @@ def panel_arrays(weights, dataset: Dataset, aggregator_dict, engine: str = "auto
             if len(pr) == 1 and pr[0].panel is not None:
                 return pr[0].panel["res"], names, region_ids, labels
     tdict = aggregate_time(dataset, weights, aggregator_dict, engine=engine)
-    labels = _labels_of(next(iter(tdict.values())))
-    xs = []
-    for nm in names:
-        d = tdict[nm]
-        if not _same_labels(labels, _labels_of(d)):
-            raise ValueError("all output variables must share one output time axis "
-                             "(the reference would align them with NaN fill and drop the rows)")
-        c = eng.device_cube(d)
-        xs.append(c.reshape(c.shape[0], -1).t().to(torch.float64))
-    _, _, res = csr.wavg(torch.stack(xs).contiguous())
+    x, labels = _aligned_cells([tdict[nm] for nm in names])
+    _, _, res = csr.wavg(x)
     return res, names, region_ids, labels
 
 

@@ -140,13 +140,41 @@ def aggregate_space(dataset_dict: dict, weights: OWeights) -> pd.DataFrame:
     """`aggregate_space` `aggregate.py:165-198` + `SpatialAggregator.__init__/compute`."""
     names = list(dataset_dict)
     dsl = [dataset_dict[n].rescaled_to_180() for n in names]          # spatial.py:60
-    time = dsl[0].time
+    # `xr.combine_by_coords` of one dataset per name (spatial.py:90-92) is an OUTER join on the time coordinate: the
+    # output axis is the sorted union of the names' labels, and a name without a label there is NaN — which makes that
+    # period invalid for every name (shared validity, spatial.py:114-119)
+    time, pos = _union_time([d.time for d in dsl])
     arrs = {}
-    for nm, d in zip(names, dsl):
+    for nm, d, at in zip(names, dsl, pos):
         T = d.values.shape[0]
-        arrs[nm] = np.asarray(d.values, dtype=np.float64).reshape(T, -1).T   # (cell, time), row-major lat x lon
+        a = np.full((int(np.prod(d.values.shape[1:])), len(time)), np.nan)
+        a[:, at] = np.asarray(d.values, dtype=np.float64).reshape(T, -1).T   # (cell, time), row-major lat x lon
+        arrs[nm] = a
     tlabels = list(time) if not isinstance(time, pd.DatetimeIndex) else time.values
     return spatial_compute(arrs, tlabels, weights.table, weights.cell_id, weights.zero_weight)
+
+
+def _union_time(axes):
+    """Sorted union of time axes (all DatetimeIndex, or all on one CF calendar) and each axis' positions in it."""
+    if all(isinstance(t, pd.DatetimeIndex) for t in axes):
+        u = axes[0]
+        for t in axes[1:]:
+            u = u.union(t)
+        return u, [u.get_indexer(t) for t in axes]
+    first = axes[0]
+    assert all(getattr(t, "calendar", None) == first.calendar for t in axes), "mixed calendars"
+    key = lambda t: t.day_ordinal() * 24 + t.hour
+    keys = [key(t) for t in axes]
+    allk = np.unique(np.concatenate(keys))
+    where = {}
+    for t, k in zip(axes, keys):
+        for i, kk in enumerate(k):
+            where.setdefault(int(kk), (t, i))
+    pick = [where[int(kk)] for kk in allk]
+    OracleCFIndex = type(first)
+    u = OracleCFIndex([t.year[i] for t, i in pick], [t.month[i] for t, i in pick], [t.day[i] for t, i in pick],
+                      [t.hour[i] for t, i in pick], first.calendar)
+    return u, [np.searchsorted(allk, k) for k in keys]
 
 
 def aggregate_dataset(weights: OWeights, dataset: ODataset = None, aggregator_dict=None,

@@ -642,3 +642,115 @@ def test_concurrent_host_threads_share_cached_plans(torch_cuda):
         for a, b in zip(alone, together):
             pd.testing.assert_frame_equal(a, b, check_exact=True)
     assert not alone[0].drop(columns=["geoid", "time"]).equals(alone[1].drop(columns=["geoid", "time"]))     # the cubes do differ
+
+
+def _reference_cache_feather(project_dir, table, module_dict, obj_dict):
+    """Write ``table`` where the reference's ProjectCache would (`aggfly/cache/project_cache.py:46-47,207-226`):
+    ``{project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather`` (+ the mod.yaml beside it), Feather V2 = the Arrow IPC file
+    format, sha = sha256(json.dumps(str(dict)))[:15]."""
+    import hashlib
+    import pyarrow as pa
+    sha = lambda d: hashlib.sha256(json.dumps(str(d), sort_keys=True).encode("utf8")).hexdigest()[:15]
+    d = os.path.join(project_dir, "tmp", "GridWeights", f"mod-{sha(module_dict)}")
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "mod.yaml"), "w").write("".join(f"{k}: {v}\n" for k, v in module_dict.items()))
+    path = os.path.join(d, f"{sha(obj_dict)}.feather")
+    with pa.OSFile(path, "wb") as f:
+        t = pa.Table.from_pandas(table, preserve_index=False)
+        with pa.ipc.new_file(f, t.schema) as w:
+            w.write_table(t)
+    return path
+
+
+def test_feather_weights_cache_through_to_the_panel(torch_cuda, tmp_path, dataset_360, georegion):
+    """N3: a weights table the reference cached as Feather V2 (`project_cache.py:72-100`, written by `grid_weights.py:169-196`
+    with its extra columns) is read with `weights_from_feather` / found by the CLI in the project cache and carried through
+    `aggregate_dataset` on the GPU: the G2 golden on the 0-360 dataset; then a mid-size 0-360 case with a cell that is
+    absent from the climate grid (dropped, `spatial.py:171-172`) and a zero-weight region kept as a NaN row under
+    zero_weight="nan" (`spatial.py:144-153`) against the oracle."""
+    from aggfly_amd.cli import pipeline
+    # ---- G2: the reference's own pinned table (test_aggregate.py:234-237), with the columns its cache file carries
+    g2 = gi.g2_weights_table().sort_values("cell_id").reset_index(drop=True)
+    g2["area_weight"] = g2["weight"] * 2.0
+    g2["raster_weight"] = 0.5
+    path = _reference_cache_feather(str(tmp_path / "proj"), g2, {"grid": "2x2", "regions": "hull"}, {"func": "weights", "raster_weights": "pop"})
+    assert "/tmp/GridWeights/mod-" in path and path.endswith(".feather")
+    assert pipeline.find_weights_table(SimpleNamespace(weights_table=None, project_dir=str(tmp_path / "proj"))) == path
+    w = af.weights_from_feather(path, dataset_360, georegion)
+    assert list(w.weights.columns[:3]) == ["cell_id", "index_right", "weight"] and w.zero_weight == "nan"
+    df = af.aggregate_dataset(dataset=dataset_360.to_device(), weights=w, **gi.g2_spec())
+    assert list(df.columns) == ["geoid", "time", "tavg_1", "tavg_2"]
+    assert np.allclose(df[["tavg_1", "tavg_2"]].values, np.array(G["G2_panel"]["values"]))
+    # ---- mid-size: 0-360 longitudes, an absent cell, a zero-weight region
+    T, ny, nx = 24 * 40, 9, 14
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=51, ocean_frac=0.1, scattered_nan=20)
+    time = pd.date_range("2002-03-01", periods=T, freq="h")
+    lat, lon = 30 + 0.5 * np.arange(ny), 170 + 1.5 * np.arange(nx)            # crosses 180: the +-180 re-sort reorders the columns
+    tab = synth.weights_table(ny, nx, 7, seed=52, secondary=True)
+    tab.loc[tab["index_right"] == 3, "weight"] = 0.0                              # a zero-weight region
+    absent = pd.DataFrame({"cell_id": [ny * nx + 5, ny * nx + 9], "index_right": [1, 2], "weight": [0.7, 0.3]})
+    tab = pd.concat([tab, absent], ignore_index=True)                             # cells the climate grid does not have
+    tab["area_weight"] = tab["weight"]
+    regions = pd.DataFrame({"geoid": [f"r{i}" for i in range(7)]})
+    path2 = _reference_cache_feather(str(tmp_path / "proj2"), tab, {"grid": "9x14"}, {"func": "weights", "raster_weights": None})
+    ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
+    for policy in ("nan", "area"):
+        w2 = af.weights_from_feather(path2, ds, af.GeoRegions(regions), zero_weight=policy)
+        spec = dict(t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                       ("aggregate", {"calc": "sum", "groupby": "month"})],
+                    dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "month"})])
+        got = af.aggregate_dataset(dataset=ds.deepcopy().to_device(), weights=w2, **spec)
+        ow = ra.OWeights(tab, np.arange(ny * nx), regions["geoid"], "geoid", policy)
+        want = ra.aggregate_dataset(ow, ra.ODataset(cube, time, lat, lon, True), engine="numba", **spec)
+        assert list(got.columns) == list(want.columns) and len(got) == len(want)
+        assert list(got["geoid"]) == list(want["geoid"])
+        cols = ["t_1", "t_2", "dd"]
+        np.testing.assert_allclose(got[cols].values, want[cols].values, rtol=1e-12, equal_nan=True)
+        z = got[got["geoid"] == "r3"]
+        assert (len(z) == 2 and z[cols].isna().all().all()) if policy == "nan" else len(z) == 0      # kept as NaN rows / dropped
+
+
+@pytest.mark.parametrize("calendar", ["standard", "noleap"])
+def test_mismatched_output_time_axes_follow_the_outer_join(torch_cuda, calendar):
+    """Names with different output frequencies (`month` and `year`): the reference lays them on the UNION of their labels
+    (`xr.combine_by_coords`, an outer join with NaN fill, spatial.py:90-97); a period that one name lacks is invalid for
+    every name (shared validity, :114-119) and its rows are dropped (:144-153) — except the NaN rows of zero-weight
+    regions under zero_weight="nan", which appear at every label of the union.  Against the oracle's restatement."""
+    ny, nx = 8, 10
+    ndays = 365 * 2 + 40
+    if calendar == "standard":
+        time = pd.date_range("2001-01-01", periods=ndays, freq="D")
+        otime = time
+    else:
+        time = af.cf_range("2001-01-01", ndays, "D", "noleap")
+        otime = cf_daily_index("noleap", ndays, start=(2001, 1, 1))
+    cube = synth.temperature_cube(ndays, ny, nx, seed=81, steps_per_day=1, ocean_frac=0.1, scattered_nan=15)
+    lat, lon = 30 + 0.5 * np.arange(ny), 250 + 0.5 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, 6, seed=82, secondary=True)
+    tab.loc[tab["index_right"] == 2, "weight"] = 0.0
+    regions = pd.DataFrame({"geoid": [f"r{i}" for i in range(6)]})
+    spec = dict(m=[("aggregate", {"calc": "mean", "groupby": "month"})],
+                y=[("aggregate", {"calc": "max", "groupby": "year"})],
+                dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "year"})])
+    ds = af.Dataset(_xr(cube, time, lat, lon), lon_is_360=True)
+    for policy in ("nan", "area"):
+        w = af.weights_from_objects(ds, af.GeoRegions(regions), table=tab, zero_weight=policy)
+        got = af.aggregate_dataset(dataset=ds.deepcopy().to_device(), weights=w, **spec)
+        ow = ra.OWeights(tab, np.arange(ny * nx), regions["geoid"], "geoid", policy)
+        want = ra.aggregate_dataset(ow, ra.ODataset(cube, otime, lat, lon, True), engine="numba", **spec)
+        assert list(got.columns) == list(want.columns) == ["geoid", "time", "m", "y", "dd"] and len(got) == len(want)
+        ymd = lambda t: (t.year, t.month, t.day)
+        assert [ymd(t) for t in got["time"]] == [ymd(t) for t in want["time"]] and list(got["geoid"]) == list(want["geoid"])
+        np.testing.assert_allclose(got[["m", "y", "dd"]].values, want[["m", "y", "dd"]].values, rtol=1e-12, equal_nan=True)
+        live = got[got["geoid"] != "r2"]
+        # only the labels EVERY name has survive: the two year ends that are month ends of the data too (the third
+        # year's label, 2003-12-31, has no monthly value: the data end in February 2003)
+        assert sorted({str(t)[:10] for t in live["time"]}) == ["2001-12-31", "2002-12-31"]
+        z = got[got["geoid"] == "r2"]           # union = 26 month ends + 2003-12-31
+        assert (len(z) == 27 and z[["m", "y", "dd"]].isna().all().all()) if policy == "nan" else len(z) == 0
+    # the eager pieces behave the same: aggregate_time then aggregate_space on names with different axes
+    w = af.weights_from_objects(ds, af.GeoRegions(regions), table=tab, zero_weight="area")
+    tdict = af.aggregate_time(dataset=ds.deepcopy().to_device(), weights=w, **spec)
+    assert len(tdict["m"].time) == 26 and len(tdict["y"].time) == 3
+    df = af.aggregate_space(tdict, w)
+    assert sorted({str(t)[:10] for t in df["time"]}) == ["2001-12-31", "2002-12-31"]

@@ -154,6 +154,35 @@ def _need(torch, gb):
         pytest.skip(f"needs {gb} GB of free HBM")
 
 
+def _check_sampled_regions(torch, out, tab, n_regions, n_pick, seed):
+    """The spatial stage of a full-size run (`SpatialAggregator.compute`, spatial.py:103-133): for a sample of regions,
+    recompute num / den / res on the host from the GPU's OWN per-cell output, entry by entry in table order — the order
+    `np.add.at` visits them (spatial.py:185) — for all columns and periods at once.  Exact for exact_order plans."""
+    cells = out["cells"]                                               # [K, P, C] in HBM
+    num, den, res = (out[k].cpu().numpy() for k in ("num", "den", "res"))
+    K, P = cells.shape[0], cells.shape[1]
+    rows = tab["index_right"].to_numpy()
+    order = np.argsort(rows, kind="stable")
+    starts = np.searchsorted(rows[order], np.arange(n_regions + 1))
+    cid, wts = tab["cell_id"].to_numpy()[order], tab["weight"].to_numpy()[order]
+    checked = 0
+    for r in np.random.default_rng(seed).choice(n_regions, n_pick, replace=False):
+        c, w = cid[starts[r]:starts[r + 1]], wts[starts[r]:starts[r + 1]]
+        vals = cells[:, :, torch.from_numpy(c).cuda()].cpu().numpy()  # [K, P, entries]
+        valid = ~np.isnan(vals).any(axis=0)                            # [P, entries]: shared across the K columns
+        d = np.zeros(P)
+        n = np.zeros((K, P))
+        for i in range(len(c)):
+            d += w[i] * valid[:, i]
+            n += w[i] * np.where(valid[:, i], vals[:, :, i], 0.0)
+        np.testing.assert_array_equal(den[r], d)
+        np.testing.assert_array_equal(num[:, r], n)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            np.testing.assert_array_equal(res[:, r], np.where(d != 0, n / d, np.nan))
+        checked += 1
+    return checked
+
+
 def test_c3_forty_years_hourly_f32(torch_cuda):
     """configs[2]: ERA5 hourly, 40 years (T = 350,640) on the CONUS window, f32 storage, P = 40."""
     torch = torch_cuda
@@ -176,6 +205,16 @@ def test_c3_forty_years_hourly_f32(torch_cuda):
         np.testing.assert_allclose(got[k], want, rtol=4e-16, atol=0, equal_nan=True)
     want = cport.resample(cport.resample(host, ib, "dd", [10, 30, 0]), ob, "sum").reshape(len(ob) - 1, -1)
     np.testing.assert_array_equal(got[2], want)
+    # the whole path: 3,100 regions with population (secondary) weights, 2 % of them zero-weight -> K x R x 40 panel
+    tab = synth.weights_table(ny, nx, 3100, seed=13, secondary=True, zero_frac=0.02)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, ny * nx)
+    out = plan.run(cube, csr, want_cells=True)
+    assert torch.equal(torch.nan_to_num(out["cells"]), torch.nan_to_num(cells))
+    assert _check_sampled_regions(torch, out, tab, R, 48, 14) == 48
+    assert np.isnan(out["res"].cpu().numpy()).any(axis=(0, 2)).sum() >= int(0.02 * R)          # zero-weight regions: den 0 -> NaN
+    fast = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, cols).run(cube, csr)                        # default order: to rounding
+    np.testing.assert_allclose(fast["res"].cpu().numpy(), out["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
 
 
 def test_c4_cmip6_daily_bins_251_years(torch_cuda):
@@ -199,6 +238,27 @@ def test_c4_cmip6_daily_bins_251_years(torch_cuda):
     got = cells[:, :, torch.from_numpy(pick).cuda()].cpu().numpy()  # [D, G, cells]
     np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want)
     assert (got.sum(axis=0) <= 365).all()
+    # the whole path at full size: 3,600 regions x 251 years x 13 bins with cropland (secondary) weights.  The packed-count
+    # gather (no per-cell output) must equal the panel route bit for bit, and sampled regions the table-order host sums.
+    tab = synth.weights_table(ny, nx, 3600, seed=23, secondary=True, zero_frac=0.01)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, ny * nx)
+    exact = hip.FusedPlan(T, ny * nx, hip.F32, ob, np.arange(252), [dict(inner="bins", inner_args=r) for r in dda], exact_order=True)
+    assert "packed-counts16" in exact.describe()
+    direct = exact.run(cube, csr, want_cells=False)
+    via_panel = exact.run(cube, csr, want_cells=True)
+    for key in ("num", "den", "res"):
+        assert torch.equal(torch.nan_to_num(direct[key], nan=-1.0), torch.nan_to_num(via_panel[key], nan=-1.0)), key
+    assert _check_sampled_regions(torch, via_panel, tab, R, 40, 24) == 40
+    fast = plan.run(cube, csr, want_cells=False)                                                 # default plan: same panel to rounding
+    np.testing.assert_allclose(fast["res"].cpu().numpy(), direct["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+    # a table with four decades of row lengths (one region of 17,280 cells): segments + ordered combine
+    skew = synth.weights_table(ny, nx, 3600, seed=25, skew="lognormal")
+    Rs = int(skew["index_right"].max()) + 1
+    csr_s = hip.CSR(skew["index_right"].to_numpy(), skew["cell_id"].to_numpy(), skew["weight"].to_numpy(), Rs, ny * nx)
+    ex_s = exact.run(cube, csr_s, want_cells=True)
+    assert _check_sampled_regions(torch, ex_s, skew, Rs, 40, 26) == 40
+    np.testing.assert_allclose(plan.run(cube, csr_s)["res"].cpu().numpy(), ex_s["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
 
 
 def test_c5_sine_dd_tenth_degree_global(torch_cuda):
@@ -217,3 +277,29 @@ def test_c5_sine_dd_tenth_degree_global(torch_cuda):
     for k, dd in enumerate(([10, 30, 0], [0, 18, 1])):
         want = cport.resample(cport.resample(host, ib, "sine_dd", dd), ob, "sum").reshape(-1)
         np.testing.assert_allclose(got[k], want, rtol=1e-10, atol=1e-9, equal_nan=True)
+    # the whole path: 40,000 admin-2-like regions (7 M table entries), then the same on a log-normal table whose
+    # largest region holds > 10^5 cells
+    for kw, seed in ((dict(), 33), (dict(skew="lognormal"), 35)):
+        tab = synth.weights_table(ny, nx, 40000, seed=seed, **kw)
+        R = int(tab["index_right"].max()) + 1
+        csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, ny * nx)
+        out = plan.run(cube, csr, want_cells=True)
+        assert _check_sampled_regions(torch, out, tab, R, 40, seed + 1) == 40
+        if kw:      # the longest row as well: > 10^5 entries in one running sum
+            big = int(tab.groupby("index_right").size().idxmax())
+            assert (tab["index_right"] == big).sum() >= 100_000
+            cells = out["cells"]
+            sub = tab[tab["index_right"] == big]
+            c, w = sub["cell_id"].to_numpy(), sub["weight"].to_numpy()
+            vals = cells[:, 0, torch.from_numpy(c).cuda()].cpu().numpy()
+            valid = ~np.isnan(vals).any(axis=0)
+            d = 0.0
+            n = np.zeros(2)
+            for i in range(len(c)):
+                d += w[i] * valid[i]
+                n += w[i] * np.where(valid[i], vals[:, i], 0.0)
+            assert out["den"][big, 0].item() == d and np.array_equal(out["num"][:, big, 0].cpu().numpy(), n)
+        fast = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"),
+                                                             dict(inner="sine_dd", inner_args=(0, 18, 1), outer="sum")]).run(cube, csr)
+        np.testing.assert_allclose(fast["res"].cpu().numpy(), out["res"].cpu().numpy(), rtol=1e-11, equal_nan=True)
+        del csr, out
