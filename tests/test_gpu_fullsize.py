@@ -183,6 +183,38 @@ def _check_sampled_regions(torch, out, tab, n_regions, n_pick, seed):
     return checked
 
 
+def test_c1_counties_extent_f32_storage(torch_cuda):
+    """configs[0] on the counties extent as the production stores hold it: float32 (T = 8760, 215 x 1440), the reference's
+    own plan mean@date -> power(1, 2) -> sum@year, 3,100 regions with area weights.  Sampled cells against the oracle run
+    on the float64-cast input (the float64 contract), sampled regions in table order, and the
+    reference's float32 dtype walk (match_reference_f32 roundings) against the oracle's numba path on the float32 input."""
+    torch = torch_cuda
+    _need(torch, 20)
+    cube = _fill(torch, T, NY, NX, torch.float32, 41, 24)
+    ib = synth.hourly_bounds(T)
+    ob = np.array([0, len(ib) - 1], dtype=np.int64)
+    cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)]
+    plan = hip.FusedPlan(T, C, hip.F32, ib, ob, cols, exact_order=True)
+    tab = synth.weights_table(NY, NX, 3100, seed=43)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, C)
+    out = plan.run(cube, csr, want_cells=True)
+    pick, host = _sample_cells(torch, cube, 96, 42)                 # host: the sampled columns cast to float64
+    got = out["cells"][:, 0, torch.from_numpy(pick).cuda()].cpu().numpy()
+    m = cport.resample(host, ib, "mean")
+    np.testing.assert_array_equal(got[0], cport.resample(m, ob, "sum").reshape(-1))       # power 1: exact
+    np.testing.assert_array_equal(got[1], cport.resample(m * m, ob, "sum").reshape(-1))   # power 2 = x * x: exact
+    assert _check_sampled_regions(torch, out, tab, R, 40, 44) == 40
+    # the reference's own dtype walk on float32 data: inner mean stored as float32, np.power(float32, int64) -> float64
+    rcols = [dict(c, rounding=hip.ROUND_INNER) for c in cols]
+    got32 = hip.FusedPlan(T, C, hip.F32, ib, ob, rcols, exact_order=True).run_temporal(cube)[:, 0, torch.from_numpy(pick).cuda()].cpu().numpy()
+    m32 = cport.resample(host, ib, "mean").astype(np.float32).astype(np.float64)
+    for k, e in enumerate((1, 2)):
+        np.testing.assert_allclose(got32[k], cport.resample(np.power(m32, e), ob, "sum").reshape(-1), rtol=4e-16, atol=0, equal_nan=True)
+    fast = hip.FusedPlan(T, C, hip.F32, ib, ob, cols).run(cube, csr)
+    np.testing.assert_allclose(fast["res"].cpu().numpy(), out["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+
+
 def test_c3_forty_years_hourly_f32(torch_cuda):
     """configs[2]: ERA5 hourly, 40 years (T = 350,640) on the CONUS window, f32 storage, P = 40."""
     torch = torch_cuda
