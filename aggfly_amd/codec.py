@@ -59,13 +59,16 @@ def load():
         lib.afcodec_zstd_bound.argtypes = [C.c_int64]
         lib.afcodec_zstd_encode.restype = C.c_int64
         lib.afcodec_zstd_encode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
+        lib.afcodec_blosc_lz4_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int32), C.c_void_p]
         _lib = lib
     return _lib
 
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_mt", "afcodec_blosc_decode_many",
            "afcodec_blosc_decode_files", "afcodec_decode_files", "afcodec_decode_ranges",
-           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode")
+           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode", "afcodec_blosc_lz4_plan")
 
 
 def _err(lib, what):
@@ -230,3 +233,30 @@ def lz4_decode(buf, nbytes: int, out: np.ndarray | None = None) -> np.ndarray:
     if r < 0:
         raise _err(lib, "lz4_decode")
     return out[:r] if r != out.nbytes and out.ndim == 1 else out
+
+
+# record layouts shared with libaggfly_hip (include/aggfly_hip.h: afhip_lz4_stream, afhip_shuffle_block)
+LZ4_STREAM = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("csize", "<i4"), ("dsize", "<i4"), ("to_out", "<i4"), ("pad", "<i4")])
+SHUFFLE_BLOCK = np.dtype([("tmp_off", "<i8"), ("out_off", "<i8"), ("bsize", "<i4"), ("typesize", "<i4")])
+E_UNSUPPORTED = -2
+
+
+def blosc_lz4_plan(base: np.ndarray, comp_off, comp_size, out_off, out_size, streams: np.ndarray, blocks: np.ndarray):
+    """Plan the GPU-side decode of Blosc-1 chunks that sit in ``base`` (uint8; chunk i = ``comp_size[i]`` bytes at
+    ``comp_off[i]``): fills ``streams`` (dtype `LZ4_STREAM`) and ``blocks`` (dtype `SHUFFLE_BLOCK`) for
+    `hip.lz4_decode_streams` / `hip.unshuffle_blocks`.  -> (n_streams, n_blocks, tmp_bytes, max_dsize, results);
+    ``results[i]`` = decoded size, or `E_UNSUPPORTED` for a chunk the GPU route does not take (decode it on the host);
+    malformed containers raise `CodecError`."""
+    lib = load()
+    n = len(comp_off)
+    co, cs, oo, osz = (np.ascontiguousarray(a, dtype=np.int64) for a in (comp_off, comp_size, out_off, out_size))
+    res = np.zeros(n, dtype=np.int64)
+    ns, nb, tmp, maxd = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    assert streams.dtype == LZ4_STREAM and blocks.dtype == SHUFFLE_BLOCK and base.dtype == np.uint8
+    rc = lib.afcodec_blosc_lz4_plan(base.ctypes.data, n, co.ctypes.data, cs.ctypes.data, oo.ctypes.data, osz.ctypes.data,
+                                    streams.ctypes.data, len(streams), C.byref(ns), blocks.ctypes.data, len(blocks), C.byref(nb),
+                                    C.byref(tmp), C.byref(maxd), res.ctypes.data)
+    bad = [int(i) for i in np.nonzero((res < 0) & (res != E_UNSUPPORTED))[0]]
+    if bad or (rc and rc != E_UNSUPPORTED):
+        raise CodecError(f"blosc_lz4_plan: chunks {bad[:8]} are malformed: {lib.afcodec_last_error().decode()}")
+    return int(ns.value), int(nb.value), int(tmp.value), int(maxd.value), res

@@ -21,6 +21,7 @@
 #include "../../include/aggfly_hip.h"
 #include "afhip_kernels.h"
 #include "afhip_panel_kernels.h"
+#include "afhip_lz4_kernels.h"
 #include "afhip_variants.h"
 
 using namespace afhip;
@@ -302,6 +303,39 @@ extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_s
         case 8: hipLaunchKernelGGL(k_place_box<uint64_t>, grid, block, 0, s, (const uint64_t*)chunk_dev, (uint64_t*)cube_dev, by, bx, st, sy, sx, nt, ny, nx, NY, NX, t0, y0, x0); break;
         default: return fail(AFHIP_E_INVALID, "place_box: elem_size must be 2, 4 or 8");
     }
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_lz4_decode_streams(const void* comp_dev, const afhip_lz4_stream* streams_dev, int64_t n_streams, int32_t max_dsize,
+                                        void* tmp_dev, void* out_dev, int32_t* errors_dev, void* stream) {
+    static_assert(sizeof(afhip_lz4_stream) == sizeof(Lz4Stream) && sizeof(afhip_shuffle_block) == sizeof(ShufBlock), "record layouts");
+    if (!comp_dev || !streams_dev || !errors_dev || n_streams < 0 || (!tmp_dev && !out_dev))
+        return fail(AFHIP_E_INVALID, "lz4_decode_streams: NULL argument");
+    if (max_dsize < 0) return fail(AFHIP_E_INVALID, "lz4_decode_streams: negative max_dsize");
+    if (n_streams == 0) return AFHIP_OK;
+    if (n_streams > 0x7fffffff) return fail(AFHIP_E_INVALID, "lz4_decode_streams: too many streams for one launch");
+    static bool attr_set = false;
+    if (!attr_set) {      // more than 64 KiB of dynamic LDS per workgroup needs the attribute
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lz4_streams, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4_LDS_MAX));
+        attr_set = true;
+    }
+    // output ring: the whole stream when it is short, else 64 KiB of history + the segment being written
+    const int ring = (int)std::min<int64_t>(LZ4_RING_MAX, std::max<int64_t>(LZ4_SEG, ((int64_t)max_dsize + LZ4_SEG - 1) / LZ4_SEG * LZ4_SEG));
+    hipLaunchKernelGGL(k_lz4_streams, dim3((unsigned)n_streams), dim3(64), (size_t)ring + LZ4_IN, (hipStream_t)stream, (const uint8_t*)comp_dev,
+                       (const Lz4Stream*)streams_dev, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, ring);
+    HIP_TRY(hipGetLastError());
+    return AFHIP_OK;
+}
+
+extern "C" int afhip_unshuffle_blocks(const void* tmp_dev, void* out_dev, const afhip_shuffle_block* blocks_dev, int64_t n_blocks,
+                                      int32_t max_bsize, void* stream) {
+    if (!tmp_dev || !out_dev || !blocks_dev || n_blocks < 0 || max_bsize < 0) return fail(AFHIP_E_INVALID, "unshuffle_blocks: bad arguments");
+    if (n_blocks == 0) return AFHIP_OK;
+    if (n_blocks > 65535) return fail(AFHIP_E_INVALID, "unshuffle_blocks: more than 65535 blocks in one call");
+    const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)max_bsize / 2 + 255) / 256));
+    hipLaunchKernelGGL(k_unshuffle_blocks, dim3(tiles, (unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)tmp_dev,
+                       (uint8_t*)out_dev, (const ShufBlock*)blocks_dev);
     HIP_TRY(hipGetLastError());
     return AFHIP_OK;
 }

@@ -303,6 +303,89 @@ static int blosc_block(const blosc_ctx* x, int64_t b) {
     return AFCODEC_OK;
 }
 
+/* ---- plan of a GPU-side decode (include/aggfly_codec.h: afcodec_blosc_lz4_plan) ----
+ * Parses the containers of n chunks and lists, for the kernels of libaggfly_hip (afhip_lz4_decode_streams,
+ * afhip_unshuffle_blocks), every LZ4 stream with its place in the compressed bytes and in the output, and every block whose
+ * byte shuffle has to be undone.  Nothing is decoded here. */
+typedef struct { int64_t src_off, dst_off; int32_t csize, dsize, to_out, pad; } lz4_stream_t;
+typedef struct { int64_t tmp_off, out_off; int32_t bsize, typesize; } shuf_block_t;
+#define GPU_STREAM_MAX 65536
+
+int afcodec_blosc_lz4_plan(const void* base, int64_t n, const int64_t* comp_off, const int64_t* comp_size, const int64_t* out_off,
+                           const int64_t* out_size, void* streams_v, int64_t cap_streams, int64_t* n_streams, void* blocks_v,
+                           int64_t cap_blocks, int64_t* n_blocks, int64_t* tmp_bytes, int32_t* max_dsize, int64_t* results) {
+    lz4_stream_t* streams = (lz4_stream_t*)streams_v;
+    shuf_block_t* blocks = (shuf_block_t*)blocks_v;
+    int64_t ns = 0, nb = 0, tmp = 0;
+    int32_t maxd = 0;
+    int rc_all = AFCODEC_OK;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t* c = (const uint8_t*)base + comp_off[i];
+        const int64_t csz = comp_size[i];
+        results[i] = 0;
+        int64_t nbytes, blocksize; int32_t ts, flags;
+        int rc = afcodec_blosc_info(c, csz, &nbytes, &blocksize, &ts, &flags);
+        if (rc) { results[i] = rc; rc_all = rc; continue; }
+        if (nbytes > out_size[i]) { results[i] = rc_all = fail(AFCODEC_E_SIZE, "destination smaller than the chunk's nbytes"); continue; }
+        results[i] = nbytes;
+        if (nbytes == 0) continue;
+        const int64_t cbytes = le32(c + 12);
+        if (flags & 0x02) {                                             /* stored chunk: plain copies, 64 KiB per wave */
+            if (cbytes < 16 + nbytes) { results[i] = rc_all = fail(AFCODEC_E_FORMAT, "stored chunk shorter than nbytes"); continue; }
+            for (int64_t o = 0; o < nbytes; o += GPU_STREAM_MAX) {
+                const int32_t len = (int32_t)((nbytes - o) < GPU_STREAM_MAX ? (nbytes - o) : GPU_STREAM_MAX);
+                if (ns >= cap_streams) return fail(AFCODEC_E_SIZE, "stream list too small");
+                streams[ns++] = (lz4_stream_t){comp_off[i] + 16 + o, out_off[i] + o, len, len, 1, 0};
+            }
+            continue;
+        }
+        const int codec = (flags >> 5) & 7;
+        if (codec != 1 || (flags & 0x04)) { results[i] = AFCODEC_E_UNSUPPORTED; rc_all = fail(AFCODEC_E_UNSUPPORTED, "not an LZ4 chunk with byte shuffle or none: decode on the host"); continue; }
+        if (blocksize <= 0 || ts <= 0 || blocksize > nbytes) { results[i] = rc_all = fail(AFCODEC_E_FORMAT, "bad blocksize / typesize"); continue; }
+        const int64_t nblocks = (nbytes + blocksize - 1) / blocksize, leftover = nbytes % blocksize;
+        if (16 + 4 * nblocks > cbytes) { results[i] = rc_all = fail(AFCODEC_E_FORMAT, "block table beyond the chunk"); continue; }
+        const int dont_split = (flags >> 4) & 1, want_shuffle = (flags & 0x01) && ts > 1;
+        const int64_t ns0 = ns, nb0 = nb, tmp0 = tmp;
+        int bad = 0;
+        for (int64_t b = 0; b < nblocks && !bad; ++b) {
+            const int last_short = (b == nblocks - 1) && leftover > 0;
+            const int64_t bsize = last_short ? leftover : blocksize;
+            int nsplits = 1;
+            if (!dont_split && ts <= 16 && blocksize / ts >= 128 && !last_short) nsplits = ts;
+            const int64_t neblock = bsize / nsplits;
+            const int64_t start = (int64_t)(int32_t)le32(c + 16 + 4 * b);
+            if (start < 16 + 4 * nblocks || start >= cbytes) { bad = AFCODEC_E_FORMAT; break; }
+            int64_t dst_base;
+            if (want_shuffle) {
+                if (nb >= cap_blocks) return fail(AFCODEC_E_SIZE, "block list too small");
+                blocks[nb++] = (shuf_block_t){tmp, out_off[i] + b * blocksize, (int32_t)bsize, ts};
+                dst_base = tmp;
+                tmp += (bsize + 15) & ~(int64_t)15;
+            } else {
+                dst_base = out_off[i] + b * blocksize;
+            }
+            const uint8_t* src = c + start;
+            for (int j = 0; j < nsplits; ++j) {
+                if (src + 4 > c + cbytes) { bad = AFCODEC_E_FORMAT; break; }
+                const int32_t sz = (int32_t)le32(src);
+                src += 4;
+                if (sz < 0 || src + sz > c + cbytes || sz > neblock + neblock / 255 + 16) { bad = AFCODEC_E_FORMAT; break; }
+                if (ns >= cap_streams) return fail(AFCODEC_E_SIZE, "stream list too small");
+                streams[ns++] = (lz4_stream_t){comp_off[i] + (src - c), dst_base + j * neblock, sz, (int32_t)neblock, want_shuffle ? 0 : 1, 0};
+                if (neblock > maxd) maxd = (int32_t)neblock;
+                src += sz;
+            }
+        }
+        if (bad) {
+            ns = ns0; nb = nb0; tmp = tmp0;
+            results[i] = bad;
+            rc_all = fail(bad, "malformed block table or stream header");
+        }
+    }
+    *n_streams = ns; *n_blocks = nb; *tmp_bytes = tmp; *max_dsize = maxd;
+    return rc_all;
+}
+
 /* Decodes one chunk into dst (capacity dstsize); returns the number of bytes written or < 0. */
 int64_t afcodec_blosc_decode(const void* chunk, int64_t csize, void* dstv, int64_t dstsize) {
     blosc_ctx x;
@@ -494,9 +577,9 @@ int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const*
 /* Encoder for the writer side (dataset_to_zarr, synthetic stores of the ingestion benchmark):
  * LZ4, byte shuffle on request, blocks never split.  Readable by any Blosc-1 decoder. */
 int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize) {
-    if (blocksize <= 0) blocksize = 1 << 18;
+    if (blocksize <= 0) blocksize = 1 << 16;                     /* the smallest automatic block */
     const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
-    return 16 + nblocks * 8 + nbytes + nbytes / 255 + 64;
+    return 16 + nblocks * (4 + 4 * 16) + nbytes + nbytes / 255 + 64;      /* block table + up to 16 stream headers per block */
 }
 int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
                                  void* dstv, int64_t cap) {
@@ -505,7 +588,8 @@ int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize,
     int rc = need_lz4();
     if (rc) return rc;
     if (nbytes < 0 || nbytes > 0x7fffffffLL - 64 || typesize < 1 || typesize > 255) return fail(AFCODEC_E_SIZE, "bad nbytes / typesize");
-    if (blocksize <= 0) blocksize = 1 << 18;
+    /* like c-blosc at level 5: 64 KiB per byte plane (blocks of 64 KiB x typesize, split into one LZ4 stream per plane) */
+    if (blocksize <= 0) { blocksize = (int64_t)65536 * (typesize <= 16 ? typesize : 1); if (blocksize > (1 << 20)) blocksize = 1 << 20; }
     blocksize -= blocksize % typesize;
     if (blocksize < typesize) blocksize = typesize;
     if (blocksize > nbytes && nbytes > 0) blocksize = nbytes;
@@ -520,21 +604,30 @@ int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize,
         put32(dst + 12, (uint32_t)(16 + nbytes));
         return 16 + nbytes;
     }
-    dst[2] = (uint8_t)((do_shuf ? 0x01 : 0) | 0x10 | (1 << 5));
+    /* split blocks (flag 0x10 clear), as c-blosc writes LZ4 chunks: a full block of a shuffled buffer is typesize
+     * streams, one per byte plane; the short last block is one stream (the reader's rule in blosc_block) */
+    dst[2] = (uint8_t)((do_shuf ? 0x01 : 0) | (do_shuf ? 0 : 0x10) | (1 << 5));
     put32(dst + 8, (uint32_t)blocksize);
     const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const int64_t leftover = nbytes % blocksize;
     uint8_t* tmp = do_shuf ? (uint8_t*)malloc((size_t)blocksize) : NULL;
     if (do_shuf && !tmp) return fail(AFCODEC_E_SIZE, "out of memory");
     int64_t pos = 16 + 4 * nblocks;
     for (int64_t b = 0; b < nblocks; ++b) {
-        const int64_t bsize = (b == nblocks - 1) ? nbytes - b * blocksize : blocksize;
+        const int last_short = (b == nblocks - 1) && leftover > 0;
+        const int64_t bsize = last_short ? leftover : blocksize;
         const uint8_t* in = src + b * blocksize;
         if (do_shuf) { shuffle_bytes(typesize, bsize, in, tmp); in = tmp; }
         put32(dst + 16 + 4 * b, (uint32_t)pos);
-        int csz = p_lz4_enc((const char*)in, (char*)dst + pos + 4, (int)bsize, (int)(bsize - 1));   /* 0 if it does not shrink */
-        if (csz <= 0) { memcpy(dst + pos + 4, in, (size_t)bsize); csz = (int)bsize; }
-        put32(dst + pos, (uint32_t)csz);
-        pos += 4 + csz;
+        int nsplits = 1;
+        if (do_shuf && typesize <= 16 && blocksize / typesize >= 128 && !last_short) nsplits = typesize;
+        const int64_t ne = bsize / nsplits;
+        for (int j = 0; j < nsplits; ++j) {
+            int csz = p_lz4_enc((const char*)in + j * ne, (char*)dst + pos + 4, (int)ne, (int)(ne - 1));   /* 0 if it does not shrink */
+            if (csz <= 0) { memcpy(dst + pos + 4, in + j * ne, (size_t)ne); csz = (int)ne; }
+            put32(dst + pos, (uint32_t)csz);
+            pos += 4 + csz;
+        }
     }
     free(tmp);
     put32(dst + 12, (uint32_t)pos);

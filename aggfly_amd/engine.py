@@ -280,17 +280,19 @@ def _is_f32(obj) -> bool:
 
 def inter_time_major(other, G1: int, ny: int, nx: int, device):
     """The second array of an 'inter' transform (`Dataset.interact`, `aggfly/dataset/dataset.py:483-518`) as an HBM tensor
-    ``[G1, ny, nx]``.  Like the reference it must have the shape of the data it multiplies — (latitude, longitude, time) of
-    the inner level's output; a Dataset / labelled array with the same dimension names is transposed first — else the
-    same ``AssertionError``.  Only layout changes here: the product itself runs in the kernel."""
+    ``[G1, ny, nx]``.  Like the reference it must have the shape of the data it multiplies, else the same
+    ``AssertionError``: a Dataset / labelled array is transposed by dimension name first (any order works); a bare array
+    must be (time, latitude, longitude) of the inner level's output — the layout the reference's compiled engine leaves
+    its step outputs in (`nb_kernels.py:293`), and the one the staged path of this engine has at the same point.  Only
+    layout changes here: the product itself runs in the kernel."""
     import torch
     if isinstance(other, Dataset):
         other = other.da
     if hasattr(other, "dims") and hasattr(other, "data"):
         if set(other.dims) == {"latitude", "longitude", "time"}:
-            other = other.transpose("latitude", "longitude", "time")
+            other = other.transpose("time", "latitude", "longitude")
         other = other.data
-    assert tuple(other.shape) == (ny, nx, G1), f"inter array has shape {tuple(other.shape)}, the data it multiplies {(ny, nx, G1)}"
+    assert tuple(other.shape) == (G1, ny, nx), f"inter array has shape {tuple(other.shape)}, the data it multiplies {(G1, ny, nx)}"
     if not _is_torch(other):
         other = np.asarray(other)
         if other.dtype not in (np.float32, np.float64):
@@ -299,7 +301,7 @@ def inter_time_major(other, G1: int, ny: int, nx: int, device):
     other = other.to(device, non_blocking=True)
     if other.dtype not in (torch.float32, torch.float64):
         other = other.to(torch.float64)
-    return other.permute(2, 0, 1).contiguous()
+    return other.contiguous()
 
 
 def _column_dict(c: ColumnProg, f32_rules: bool = False) -> dict:

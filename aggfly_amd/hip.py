@@ -33,7 +33,7 @@ EXPORTS = (
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
-    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform", "afhip_panel_divide",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform", "afhip_panel_divide", "afhip_lz4_decode_streams", "afhip_unshuffle_blocks",
 )
 
 
@@ -103,6 +103,8 @@ def load():
     lib.afhip_plan_bind_inter.argtypes = [vp, i32, vp, i32]
     lib.afhip_transform.argtypes = [vp, i32, i64, i32, dbl, vp, i32, vp, i32, vp]
     lib.afhip_panel_divide.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+    lib.afhip_lz4_decode_streams.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    lib.afhip_unshuffle_blocks.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.afhip_plan_profile_begin.argtypes = [vp, i64]
     lib.afhip_plan_profile_end.argtypes = [vp, C.POINTER(C.c_float), i64]
     lib.afhip_plan_profile_end.restype = i64
@@ -138,6 +140,19 @@ def place_box(chunk, cube, box_in_chunk, at):
     (st, sy, sx, nt, ny, nx), (t0, y0, x0) = box_in_chunk, at
     _check(load().afhip_place_box(chunk.data_ptr(), cube.data_ptr(), chunk.element_size(), chunk.shape[1], chunk.shape[2],
                                   st, sy, sx, nt, ny, nx, cube.shape[1], cube.shape[2], t0, y0, x0, _stream_ptr()))
+
+
+def lz4_decode_streams(comp, streams, n_streams: int, max_dsize: int, tmp, out, errors):
+    """`afhip_lz4_decode_streams`: decode ``n_streams`` LZ4 streams (records in the uint8 HBM tensor ``streams``, planned
+    by `codec.blosc_lz4_plan`) of the compressed bytes ``comp`` into ``tmp`` / ``out`` on the current stream; malformed
+    streams bump the int32 HBM counter ``errors``."""
+    _check(load().afhip_lz4_decode_streams(comp.data_ptr(), streams.data_ptr(), int(n_streams), int(max_dsize),
+                                           tmp.data_ptr() if tmp is not None else None, out.data_ptr(), errors.data_ptr(), _stream_ptr()))
+
+
+def unshuffle_blocks(tmp, out, blocks, n_blocks: int, max_bsize: int):
+    """`afhip_unshuffle_blocks`: Blosc's byte shuffle undone per block (records in the uint8 HBM tensor ``blocks``)."""
+    _check(load().afhip_unshuffle_blocks(tmp.data_ptr(), out.data_ptr(), blocks.data_ptr(), int(n_blocks), int(max_bsize), _stream_ptr()))
 
 
 def require_gpu():

@@ -508,10 +508,48 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np, t_range, yx_box), za
         if not whole_rows and za.native_kind is not None:
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
+        if za.native_kind == "blosc" and _gpu_decodable(za):
+            # Blosc-LZ4 chunks cross PCIe compressed and are decoded in HBM: the scatter route, whatever the chunk grid
+            return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if need_post else None, out_np), za
     finally:
         if pool is not None:
             pool.shutdown()
+
+
+def _gpu_decodable(za) -> bool:
+    """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
+    from the first chunk file's header.  The route is OPT-IN (``AGGFLY_HIP_GPU_DECODE=1``): measured on MI355X it moves
+    5-13 GB/s of decoded data where the host threads + page-locked staging move 25-37 GB/s, on fields of every
+    compressibility tried (`profiles/r02_gpu_decode_by_ratio.json`): one wave resolves LZ4 sequences one
+    after the other and the 64 KiB history ring leaves two waves per CU."""
+    if os.environ.get("AGGFLY_HIP_GPU_DECODE", "0") != "1" or za.native_kind != "blosc":
+        return False
+    hit = getattr(za, "_gpu_decodable", None)
+    if hit is not None:
+        return hit
+    ok = False
+    try:
+        for idx in np.ndindex(*[-(-s_ // c_) for s_, c_ in zip(za.shape, za.chunks)]):
+            loc = za.chunk_locator(tuple(int(i) for i in idx))
+            if loc is None:
+                continue
+            with open(loc[0], "rb") as f:
+                f.seek(loc[1])
+                h = f.read(16)
+            if len(h) == 16 and h[0] == 2:
+                flags, ts = h[2], h[3]
+                nbytes, blocksize = int.from_bytes(h[4:8], "little"), int.from_bytes(h[8:12], "little")
+                ok = bool(flags & 0x02) or (((flags >> 5) & 7) == 1 and not (flags & 0x04) and blocksize > 0 and nbytes == za.chunk_nbytes)
+                za._blosc_geometry = (max(blocksize, 1), max(ts, 1))
+            break
+    except OSError:
+        ok = False
+    try:
+        za._gpu_decodable = ok
+    except AttributeError:
+        pass
+    return ok
 
 
 def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None, t_range=None, yx_box=None):
@@ -537,23 +575,79 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
         per = 1          # big chunks decode block-parallel on the whole team: one per batch pipelines best with the upload
     idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
     nstage = 2 if len(idxs) > per else 1
-    host = _pinned_stage(per * cb, nstage)
+    gpu_dec = _gpu_decodable(za)
+    if gpu_dec:
+        # compressed bytes + the two record lists of a batch share one page-locked slot and one H2D copy
+        cmax = (int(codec.load().afcodec_blosc_bound(cb, 0)) + 63) // 64 * 64
+        bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
+        nblk = -(-cb // bsz)
+        cap_streams = per * (nblk * tsz + cb // 65536 + 2)          # one stream per byte plane of a block; stored chunks in 64 KiB pieces
+        cap_blocks = per * nblk
+        rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
+        host = _pinned_stage(per * cmax + rec_bytes, nstage)
+        comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
+        tmp_dev = torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device)
+        errors = torch.zeros(1, dtype=torch.int32, device=device)
+    else:
+        host = _pinned_stage(per * cb, nstage)
     dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
     copy_stream = torch.cuda.Stream(device=device)
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
     # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
     copy_stream.wait_stream(torch.cuda.current_stream(device))
     done = [None, None]
+    trace = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
+    tt = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
+    import time as _time
     for b, lo in enumerate(range(0, len(idxs), per)):
         batch = idxs[lo:lo + per]
         k = b % nstage
+        _t0 = _time.perf_counter()
         if done[k] is not None:
             done[k].synchronize()                       # both staging buffers of slot k are free again
-        hbuf = host[k][:len(batch) * cb].numpy()
-        outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
-        res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], outs, threads=threads)
+        tt["wait"] += _time.perf_counter() - _t0
+        _t0 = _time.perf_counter()
+        if gpu_dec:
+            # host: read the chunk files as they are, packed back to back; parse the containers into the record lists
+            locs = [za.chunk_locator(i) for i in batch]
+            sizes = np.array([-1 if l is None else (l[2] if l[2] >= 0 else os.path.getsize(l[0]) - l[1]) for l in locs], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum((np.maximum(sizes, 0) + 63) // 64 * 64)])
+            hall = host[k].numpy()
+            res = codec.decode_ranges("raw", locs, [hall[offs[i]:offs[i] + max(int(sizes[i]), 0)] for i in range(len(batch))], threads=threads)
+            tt["read"] += _time.perf_counter() - _t0
+            _t0 = _time.perf_counter()
+            present = [i for i, r in enumerate(res) if r != -100]
+            rec0 = int(offs[-1])
+            streams = hall[rec0:rec0 + cap_streams * codec.LZ4_STREAM.itemsize].view(codec.LZ4_STREAM)
+            blocks = hall[rec0 + streams.nbytes:rec0 + streams.nbytes + cap_blocks * codec.SHUFFLE_BLOCK.itemsize].view(codec.SHUFFLE_BLOCK)
+            n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], np.asarray(present, dtype=np.int64) * cb,
+                                                                        np.full(len(present), cb, dtype=np.int64), streams, blocks)
+            if (pres != cb).any():
+                badc = [za.chunk_locator(batch[present[i]])[0] for i in np.nonzero(pres != cb)[0][:4]]
+                raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
+                                       "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
+            assert tmp_bytes <= tmp_dev.numel()
+            bl0 = rec0 + streams.nbytes
+            tt["plan"] += _time.perf_counter() - _t0
+        else:
+            hbuf = host[k][:len(batch) * cb].numpy()
+            outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
+            res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], outs, threads=threads)
+            tt["read"] += _time.perf_counter() - _t0
+        _t0 = _time.perf_counter()
         with torch.cuda.stream(copy_stream):
-            dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
+            if gpu_dec:
+                n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                    # compressed bytes + stream records: one copy
+                comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
+                if n_bl:
+                    n2 = n_bl * codec.SHUFFLE_BLOCK.itemsize
+                    comp_dev[k][bl0:bl0 + n2].copy_(host[k][bl0:bl0 + n2], non_blocking=True)
+                if n_st:
+                    hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev, dev[k], errors)
+                if n_bl:
+                    hip.unshuffle_blocks(tmp_dev, dev[k], comp_dev[k][bl0:], n_bl, int(blocks["bsize"][:n_bl].max()))
+            else:
+                dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
                 c0 = it * tc                            # first step of the chunk
                 t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
@@ -571,10 +665,18 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             ev = torch.cuda.Event()
             ev.record(copy_stream)
             done[k] = ev
+        tt["enqueue"] += _time.perf_counter() - _t0
     with torch.cuda.stream(copy_stream):
         if post is not None:
             post(cube)
+    _t0 = _time.perf_counter()
     copy_stream.synchronize()
+    if trace:
+        tt["drain"] = _time.perf_counter() - _t0
+        print("ingest trace:", {"gpu_decode": gpu_dec, "batches": -(-len(idxs) // per), "chunks_per_batch": per, **{k_: round(v * 1e3, 2) for k_, v in tt.items()}}, flush=True)
+    if gpu_dec and int(errors.item()):
+        raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
+                               "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")
     torch.cuda.current_stream(device).wait_stream(copy_stream)
     return cube
 

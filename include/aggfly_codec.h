@@ -39,6 +39,21 @@ int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize);
 int64_t afcodec_blosc_encode_lz4(const void* src, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
                                  void* dst, int64_t cap);
 
+/* Plan of a GPU-side decode (libaggfly_hip: afhip_lz4_decode_streams / afhip_unshuffle_blocks, include/aggfly_hip.h): the
+ * containers of n Blosc-1 chunks — chunk i = comp_size[i] bytes at base + comp_off[i], its decoded bytes wanted at offset
+ * out_off[i] (capacity out_size[i]) of the output buffer — are parsed on the host and turned into
+ *   streams [*n_streams]  afhip_lz4_stream records: every LZ4 stream (a block, or one byte plane of a split block) with its
+ *                         offset in the compressed bytes (relative to base: the device copy keeps the same offsets) and
+ *                         its destination (the output, or the shuffled scratch of *tmp_bytes bytes); stored streams and
+ *                         stored chunks appear with csize == dsize;
+ *   blocks  [*n_blocks]   afhip_shuffle_block records: blocks whose byte shuffle is undone from the scratch into the output.
+ * Nothing is decoded here.  results[i] = the chunk's decoded size, or < 0: AFCODEC_E_UNSUPPORTED marks a chunk the GPU
+ * route does not take (another codec than LZ4, bit shuffle) — decode it on the host; the call then returns that code too.
+ * *max_dsize = the longest stream (sizes the kernel's LDS ring). */
+int afcodec_blosc_lz4_plan(const void* base, int64_t n, const int64_t* comp_off, const int64_t* comp_size, const int64_t* out_off,
+                           const int64_t* out_size, void* streams, int64_t cap_streams, int64_t* n_streams, void* blocks,
+                           int64_t cap_blocks, int64_t* n_blocks, int64_t* tmp_bytes, int32_t* max_dsize, int64_t* results);
+
 /* Chunk files of one codec kind (0 raw, 1 Blosc-1, 2 Zstandard frame, 3 zlib or gzip stream, 4 numcodecs LZ4;
  * kind + 16 * element_size adds a byte-unshuffle after the codec: HDF5 / netCDF-4 shuffle + deflate chunks): read and
  * decoded paths[i] -> dsts[i], one chunk per OpenMP thread. */

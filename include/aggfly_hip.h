@@ -140,6 +140,21 @@ int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
                     int64_t nt, int64_t ny, int64_t nx,
                     int64_t NY, int64_t NX, int64_t t0, int64_t y0, int64_t x0, void* stream);
 
+/* Chunk decode in HBM ("or GPU-side decode"; the reference decodes on host threads inside its dask
+ * graph, aggfly/dataset/dataset.py:697-728).  Blosc-1 chunks whose streams are LZ4 cross PCIe compressed; the host parses
+ * the containers (afcodec_blosc_lz4_plan, include/aggfly_codec.h) into the two record lists below, which travel to HBM with
+ * the compressed bytes.  afhip_lz4_decode_streams: one wave per stream decodes it inside LDS (a 64 KiB history ring: streams
+ * of any length) and writes dsize bytes to (to_out ? out_dev : tmp_dev) + dst_off; stored streams (csize == dsize) are
+ * copied.  max_dsize = the longest dsize of the list (sizes the ring).  A malformed stream writes nothing outside its own
+ * destination and adds 1 to *errors_dev (read it after the next synchronisation).
+ * afhip_unshuffle_blocks: Blosc's byte shuffle undone, tmp_dev -> out_dev.  All pointers are device memory. */
+typedef struct afhip_lz4_stream { int64_t src_off, dst_off; int32_t csize, dsize, to_out, pad; } afhip_lz4_stream;
+typedef struct afhip_shuffle_block { int64_t tmp_off, out_off; int32_t bsize, typesize; } afhip_shuffle_block;
+int afhip_lz4_decode_streams(const void* comp_dev, const afhip_lz4_stream* streams_dev, int64_t n_streams, int32_t max_dsize,
+                             void* tmp_dev, void* out_dev, int32_t* errors_dev, void* stream);
+int afhip_unshuffle_blocks(const void* tmp_dev, void* out_dev, const afhip_shuffle_block* blocks_dev, int64_t n_blocks,
+                           int32_t max_bsize, void* stream);
+
 /* Replaces the body of SpatialAggregator.compute (spatial.py:110-133) for K names:
  * shared validity (all K non-NaN), den = W.valid, num_k = W.where(valid, x_k, 0),
  * res = num/den where den != 0 else NaN.

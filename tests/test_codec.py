@@ -286,3 +286,71 @@ def test_short_chunks_are_refused(tmp_path):
     # an absent chunk is not a short chunk
     os.remove(za.chunk_locator((1, 0, 0))[0])
     assert codec.decode_ranges("raw", [za.chunk_locator((0, 0, 0)), za.chunk_locator((1, 0, 0))], outs, threads=2) == [9216, -100]
+
+
+def _plan_one(chunk: bytes, nbytes: int):
+    base = np.frombuffer(chunk, dtype=np.uint8).copy()
+    streams = np.zeros(4096, dtype=codec.LZ4_STREAM)
+    blocks = np.zeros(1024, dtype=codec.SHUFFLE_BLOCK)
+    ns, nb, tmpb, maxd, res = codec.blosc_lz4_plan(base, [0], [len(chunk)], [0], [nbytes], streams, blocks)
+    return base, streams[:ns], blocks[:nb], tmpb, maxd, int(res[0])
+
+
+@pytest.mark.parametrize("case", CASES, ids=_id)
+def test_gpu_decode_plan_on_real_cblosc_chunks(case):
+    """`afcodec_blosc_lz4_plan` (the host half of the GPU-side decode) on every chunk the real c-blosc 1.21 wrote: LZ4 /
+    LZ4HC chunks with byte shuffle or none (and stored chunks) are planned, everything else is handed back as unsupported.
+    The plan is then EXECUTED on the host with liblz4 (pyarrow's lz4_raw) + a numpy unshuffle — what `k_lz4_streams` and
+    `k_unshuffle_blocks` do in HBM — and must reproduce the recipe bit for bit."""
+    import pyarrow as pa
+    chunk = base64.b64decode(case["chunk_b64"])
+    raw = recipe(case["recipe"], case["n"], case["dtype"], case["seed"])
+    info = codec.blosc_info(chunk)
+    base, streams, blocks, tmpb, maxd, res = _plan_one(chunk, raw.nbytes)
+    takes = info["stored"] or (case["cname"] in ("lz4", "lz4hc") and case["shuffle"] != 2)
+    if not takes:
+        assert res == codec.E_UNSUPPORTED and len(streams) == 0 and len(blocks) == 0
+        return
+    assert res == raw.nbytes
+    out = np.zeros(raw.nbytes, dtype=np.uint8)
+    tmp = np.zeros(max(tmpb, 1), dtype=np.uint8)
+    covered = np.zeros(raw.nbytes, dtype=np.int32)
+    for s in streams:
+        src = base[s["src_off"]:s["src_off"] + s["csize"]].tobytes()
+        dec = src if s["csize"] == s["dsize"] else pa.Codec("lz4_raw").decompress(src, decompressed_size=int(s["dsize"]), asbytes=True)
+        assert len(dec) == s["dsize"]
+        (out if s["to_out"] else tmp)[s["dst_off"]:s["dst_off"] + s["dsize"]] = np.frombuffer(dec, dtype=np.uint8)
+        if s["to_out"]:
+            covered[s["dst_off"]:s["dst_off"] + s["dsize"]] += 1
+    for b in blocks:
+        ts, bs = int(b["typesize"]), int(b["bsize"])
+        n = bs // ts
+        planes = tmp[b["tmp_off"]:b["tmp_off"] + n * ts].reshape(ts, n)
+        out[b["out_off"]:b["out_off"] + n * ts] = planes.T.reshape(-1)
+        out[b["out_off"] + n * ts:b["out_off"] + bs] = tmp[b["tmp_off"] + n * ts:b["tmp_off"] + bs]
+        covered[b["out_off"]:b["out_off"] + bs] += 1
+    assert (covered == 1).all()                                   # every output byte has exactly one producer
+    assert out.tobytes() == raw.tobytes()
+
+
+def test_gpu_decode_plan_refuses_damage_and_batches():
+    lz4 = [c for c in CASES if c["cname"] in ("lz4", "lz4hc") and c["shuffle"] == 1 and c["nbytes"] >= 100000][:2]
+    assert len(lz4) == 2
+    chunks = [base64.b64decode(c["chunk_b64"]) for c in lz4] + [base64.b64decode(next(c for c in CASES if c["cname"] == "zstd")["chunk_b64"])]
+    offs = np.concatenate([[0], np.cumsum([(len(c) + 63) // 64 * 64 for c in chunks])])
+    base = np.zeros(offs[-1], dtype=np.uint8)
+    for o, c in zip(offs, chunks):
+        base[o:o + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    streams, blocks = np.zeros(4096, dtype=codec.LZ4_STREAM), np.zeros(1024, dtype=codec.SHUFFLE_BLOCK)
+    nb = [lz4[0]["nbytes"], lz4[1]["nbytes"], 10 ** 6]
+    ns, nbk, tmpb, maxd, res = codec.blosc_lz4_plan(base, offs[:3], [len(c) for c in chunks], [0, nb[0], nb[0] + nb[1]], nb, streams, blocks)
+    assert list(res[:2]) == nb[:2] and res[2] == codec.E_UNSUPPORTED            # the zstd chunk goes back to the host
+    assert ns > 0 and (streams["src_off"][:ns] < offs[2]).all()                 # ... and left no records behind
+    assert (streams["dst_off"][:ns][streams["to_out"][:ns] == 0] < tmpb).all() and tmpb >= nb[0] + nb[1]
+    bad = base.copy(); bad[offs[1] + 16:offs[1] + 20] = np.frombuffer((2 ** 31 - 1).to_bytes(4, "little"), dtype=np.uint8)
+    with pytest.raises(codec.CodecError, match="malformed"):
+        codec.blosc_lz4_plan(bad, offs[:2], [len(c) for c in chunks[:2]], [0, nb[0]], nb[:2], streams, blocks)
+    with pytest.raises(codec.CodecError):
+        codec.blosc_lz4_plan(base, offs[:1], [len(chunks[0])], [0], [100], streams, blocks)          # destination too small
+    with pytest.raises(codec.CodecError):
+        codec.blosc_lz4_plan(base, offs[:1], [len(chunks[0])], [0], nb[:1], streams[:2], blocks)     # record list too small

@@ -350,11 +350,12 @@ def test_interact_and_spline_transforms(torch_cuda):
     assert len(got) == len(want)
     np.testing.assert_allclose(got[["tx", "sp_spline1", "sp_spline2"]].values, want[["tx", "sp_spline1", "sp_spline2"]].values,
                                rtol=1e-12, equal_nan=True)
-    # the second array as a bare (lat, lon, time) numpy array, and a wrong shape -> the reference's AssertionError
-    got2 = af.aggregate_dataset(dataset=ds, weights=w, **spec(np.ascontiguousarray(np.moveaxis(odaily.values, 0, -1))))
+    # the second array as a bare numpy array in the step output's (time, lat, lon) layout (the reference's compiled engine
+    # leaves its outputs so, nb_kernels.py:293), and a wrong shape -> the reference's AssertionError
+    got2 = af.aggregate_dataset(dataset=ds, weights=w, **spec(odaily.values))
     np.testing.assert_array_equal(got2["tx"].values, got["tx"].values)
     with pytest.raises(AssertionError):
-        af.aggregate_dataset(dataset=ds, weights=w, **spec(odaily.values))          # (time, lat, lon): not the data's layout
+        af.aggregate_dataset(dataset=ds, weights=w, **spec(np.ascontiguousarray(np.moveaxis(odaily.values, 0, -1))))
     # inter on RAW data (before any aggregate) and after the outer level stay staged — through hip.transform
     spec3 = dict(r=[("transform", {"transform": "inter", "inter": ds}), ("aggregate", {"calc": "mean", "groupby": "month"})])
     ospec3 = dict(r=[("transform", {"transform": "inter", "inter": ods}), ("aggregate", {"calc": "mean", "groupby": "month"})])

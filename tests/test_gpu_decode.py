@@ -1,0 +1,160 @@
+"""Chunk decode in HBM (`afhip_lz4_decode_streams` + `afhip_unshuffle_blocks`, planned by `afcodec_blosc_lz4_plan`):
+every LZ4 chunk the real c-blosc 1.21 wrote decodes bit-exact on the GPU; damaged streams are counted, never followed out of
+bounds; stores read through `dataset_from_path(device="cuda")` give the same cube with the decode on the GPU or on the host."""
+import base64
+import json
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_blosc_fixtures import recipe          # noqa: E402
+
+import aggfly_amd as af                         # noqa: E402
+from aggfly_amd import codec, synth             # noqa: E402
+
+pytestmark = pytest.mark.gpu
+CASES = json.load(open(os.path.join(HERE, "golden", "blosc_fixtures.json")))["cases"]
+
+
+def _gpu_decode(torch, chunks, nbytes):
+    """Plan + decode a batch of chunks on the GPU -> (list of decoded uint8 arrays | None for unsupported, error count)."""
+    from aggfly_amd import hip
+    offs = np.concatenate([[0], np.cumsum([(len(c) + 63) // 64 * 64 for c in chunks])]).astype(np.int64)
+    base = np.zeros(max(int(offs[-1]), 64), dtype=np.uint8)
+    for o, c in zip(offs, chunks):
+        base[o:o + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    out_off = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in nbytes])]).astype(np.int64)
+    streams, blocks = np.zeros(1 << 16, dtype=codec.LZ4_STREAM), np.zeros(1 << 14, dtype=codec.SHUFFLE_BLOCK)
+    ns, nb, tmpb, maxd, res = codec.blosc_lz4_plan(base, offs[:-1], [len(c) for c in chunks], out_off[:-1], nbytes, streams, blocks)
+    comp = torch.from_numpy(base).cuda()
+    st = torch.from_numpy(streams[:max(ns, 1)].view(np.uint8).copy()).cuda()
+    bl = torch.from_numpy(blocks[:max(nb, 1)].view(np.uint8).copy()).cuda()
+    out = torch.full((max(int(out_off[-1]), 64),), 0xAB, dtype=torch.uint8, device="cuda")
+    tmp = torch.zeros(max(tmpb, 64), dtype=torch.uint8, device="cuda")
+    errors = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if ns:
+        hip.lz4_decode_streams(comp, st, ns, maxd, tmp, out, errors)
+    if nb:
+        hip.unshuffle_blocks(tmp, out, bl, nb, int(blocks["bsize"][:nb].max()))
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    got = [host[o:o + n] if r >= 0 else None for o, n, r in zip(out_off[:-1], nbytes, res)]
+    return got, int(errors.item()), host, out_off
+
+
+def test_real_cblosc_lz4_chunks_decode_bit_exact_in_hbm(torch_cuda):
+    chunks = [base64.b64decode(c["chunk_b64"]) for c in CASES]
+    raws = [recipe(c["recipe"], c["n"], c["dtype"], c["seed"]) for c in CASES]
+    got, nerr, host, out_off = _gpu_decode(torch_cuda, chunks, [r.nbytes for r in raws])
+    assert nerr == 0
+    taken = 0
+    for c, g, r in zip(CASES, got, raws):
+        info = codec.blosc_info(base64.b64decode(c["chunk_b64"]))
+        if info["stored"] or (c["cname"] in ("lz4", "lz4hc") and c["shuffle"] != 2):
+            assert g is not None
+            assert g.tobytes() == r.tobytes(), (c["cname"], c["shuffle"], c["dtype"], c["recipe"], c["n"])
+            taken += 1
+        else:
+            assert g is None
+    assert taken >= 25
+    # the 64-byte gaps between the outputs were never written
+    for o, n, nxt in zip(out_off[:-1], [r.nbytes for r in raws], out_off[1:]):
+        assert (host[o + n:nxt] == 0xAB).all()
+
+
+@pytest.mark.parametrize("dtype,n,shuffle,blocksize", [("<f4", 1_000_000, True, 0), ("<f8", 333_333, True, 65536), ("<f4", 17, True, 0),
+                                                        ("<i2", 50_000, False, 4096), ("<f4", 700_001, True, 10_000), ("<f4", 262_144, True, 262_144)])
+def test_in_tree_encoder_chunks_decode_in_hbm(torch_cuda, dtype, n, shuffle, blocksize):
+    """Multi-block chunks (up to 61 blocks x 4 byte planes), a short last block, tiny chunks, unshuffled int16, and data of
+    every compressibility: smooth (long matches), noisy mantissas (stored planes), constant (maximal matches), random."""
+    rng = np.random.default_rng(n)
+    for kind in ("smooth", "noisy", "constant", "random", "runs"):
+        if kind == "smooth":
+            x = (280 + 10 * np.sin(np.arange(n) / 50)).astype(dtype)
+        elif kind == "noisy":
+            x = (280 + 10 * np.sin(np.arange(n) / 50) + rng.normal(0, 0.3, n)).astype(dtype)
+        elif kind == "constant":
+            x = np.full(n, 273.15).astype(dtype)
+        elif kind == "random":
+            x = np.frombuffer(rng.bytes(n * np.dtype(dtype).itemsize), dtype=dtype).copy()
+        else:                                                        # long literal runs between long matches
+            x = np.where((np.arange(n) // 700) % 2 == 0, 1.5, rng.normal(0, 1, n)).astype(dtype)
+        enc = codec.blosc_encode(x, x.dtype.itemsize, shuffle, blocksize)
+        assert codec.blosc_decode(enc).tobytes() == x.tobytes()
+        got, nerr, _, _ = _gpu_decode(torch_cuda, [enc], [x.nbytes])
+        assert nerr == 0 and got[0] is not None and got[0].tobytes() == x.tobytes(), kind
+
+
+def test_damaged_streams_are_counted_not_followed(torch_cuda):
+    """Garbage in the payload: the kernel must stop at the first impossible offset / length, bump the error counter and leave
+    everything outside the stream's own destination untouched (the 0xAB guard bytes around the outputs)."""
+    rng = np.random.default_rng(5)
+    x = (280 + 10 * np.sin(np.arange(400_000) / 50) + rng.normal(0, 0.05, 400_000)).astype("<f4")
+    enc = bytearray(codec.blosc_encode(x, 4, True, 0))
+    good = bytes(enc)
+    total_err = 0
+    for trial in range(6):
+        bad = bytearray(good)
+        lo = 16 + 4 * 7 + 64
+        for _ in range(40):                                          # overwrite runs of payload bytes (block table kept)
+            p = int(rng.integers(lo, len(bad) - 16))
+            bad[p:p + 8] = rng.bytes(8)
+        try:
+            got, nerr, host, out_off = _gpu_decode(torch_cuda, [good, bytes(bad), good], [x.nbytes] * 3)
+        except codec.CodecError:
+            continue                                                 # a stream-length prefix was hit: refused by the planner
+        total_err += nerr
+        assert got[0].tobytes() == x.tobytes() and got[2].tobytes() == x.tobytes()        # the neighbours are intact
+        for o, nxt in zip(out_off[:-1] + x.nbytes, out_off[1:]):
+            assert (host[o:nxt] == 0xAB).all()
+    assert total_err > 0
+
+
+def _store(tmp_path, name, cube, chunks, time=None):
+    T, ny, nx = cube.shape
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"],
+                                 {"time": time if time is not None else pd.date_range("2001-01-01", periods=T, freq="h"),
+                                  "latitude": 30 + 0.25 * np.arange(ny), "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+    path = str(tmp_path / name)
+    af.dataset_to_zarr(ds, path, var="t2m", chunks=chunks)
+    return path
+
+
+@pytest.mark.parametrize("layout", ["time_contiguous", "space_tiled", "whole_series_tiles"])
+def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkeypatch, layout):
+    """`dataset_from_path(device="cuda")` on Blosc-LZ4 stores: with the chunks decoded in HBM (default) or on the host threads
+    (the default; AGGFLY_HIP_GPU_DECODE=1 opts in) the cube is the same, bit for bit — whole store, a time window, a region box; the GPU route
+    never calls the host Blosc decoder."""
+    T, ny, nx = 24 * 30, 40, 64
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=3, ocean_frac=0.1, scattered_nan=40) + np.float32(273.15)
+    chunks = {"time_contiguous": {"time": 48, "latitude": ny, "longitude": nx}, "space_tiled": {"time": 100, "latitude": 16, "longitude": 24},
+              "whole_series_tiles": {"time": T, "latitude": 8, "longitude": 16}}[layout]
+    path = _store(tmp_path, "s.zarr", cube, chunks)
+    from aggfly_amd import io as afio
+    kinds = []
+    real = codec.decode_ranges
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")                 # the route is opt-in
+    dev = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
+    assert set(kinds) == {"raw"}, kinds                              # files read as they are; no host decode
+    np.testing.assert_array_equal(dev.cube().cpu().numpy(), cube)
+    win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-05", "2001-01-11"))
+    np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[24 * 4:24 * 11])
+    kinds.clear()
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "0")
+    host = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
+    assert "blosc" in set(kinds)
+    np.testing.assert_array_equal(host.cube().cpu().numpy(), dev.cube().cpu().numpy())
+
+
+def test_float64_stores_decode_in_hbm(torch_cuda, tmp_path, monkeypatch):
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")
+    T, ny, nx = 24 * 10, 12, 20
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=4, scattered_nan=10)
+    path = _store(tmp_path, "d.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
+    np.testing.assert_array_equal(af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda").cube().cpu().numpy(), cube)

@@ -42,9 +42,15 @@ def _random_steps(rng):
         p1["ddargs"] = _dd(rng, multi1)
     steps = [("aggregate", p1)]
     fan = multi1
-    if kind in (2, 3) and not multi1:
-        if rng.random() < 0.7:
+    if kind in (2, 3, 4) and not multi1:
+        u = rng.random()
+        if kind == 4:          # X2: product with a second array of the inner level's shape (filled in by the caller)
+            steps.append(("transform", {"transform": "inter", "inter": "__OTHER__"}))
+        elif u < 0.6:
             steps.append(("transform", {"transform": "power", "exp": np.arange(1, int(rng.integers(2, 5)))}))
+            fan = True
+        elif u < 0.75:         # non-integer and negative exponents: the kernel's pow() variants
+            steps.append(("transform", {"transform": "power", "exp": np.array([0.5, float(rng.choice([1.5, 2.5, -1.0]))])}))
             fan = True
         else:
             steps.append(("transform", {"transform": "spline"}))
@@ -115,15 +121,24 @@ def test_random_specs_match_oracle(torch_cuda, seed):
                     out_freq = last
                     spec[f"v{v}"] = steps
                     break
-        try:
-            want = ra.aggregate_dataset(ow, ods, engine="numba", **spec)
-        except ValueError as e:
-            # names whose output time axes differ in length (e.g. week->month next to date->month):
-            # the oracle cannot stack them; the product must refuse too rather than mis-align
-            assert "broadcast" in str(e)
-            with pytest.raises(ValueError, match="share one output time axis"):
-                af.aggregate_dataset(dataset=ds, weights=w, **spec)
-            continue
+        # an `inter` step multiplies by a random array of the inner level's shape, (time', lat, lon): the layout of a step
+        # output in the oracle, in the reference's compiled engine, and on both the fused and the staged path here
+        ospec = {}
+        for name, steps in spec.items():
+            osteps, psteps = [], []
+            for k, prm in steps:
+                if k == "transform" and prm.get("inter") == "__OTHER__":
+                    inner = ra.OTemporalAggregator(**steps[0][1]).execute(ods)
+                    other = rng.normal(1.0, 0.5, inner.values.shape)
+                    other[rng.integers(0, other.shape[0]), rng.integers(0, ny), rng.integers(0, nx)] = np.nan
+                    osteps.append((k, dict(prm, inter=other)))
+                    psteps.append((k, dict(prm, inter=other.copy())))
+                else:
+                    osteps.append((k, prm))
+                    psteps.append((k, prm))
+            ospec[name], spec[name] = osteps, psteps
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = ra.aggregate_dataset(ow, ods, engine="numba", **ospec)    # names with different label sets: outer join, like the product
         got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
         assert list(got.columns) == list(want.columns), spec
         assert len(got) == len(want), spec
