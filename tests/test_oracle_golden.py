@@ -163,3 +163,33 @@ def test_c_port_matches_numpy_restatement():
     ri, ci, w = rng.integers(0, 6, 50), rng.integers(0, 35, 50), rng.random(50)
     from oracle.ref_spatial import scatter_block
     np.testing.assert_array_equal(cport.scatter_block(blk, ri, ci, w, 6), scatter_block(blk, ri, ci, w, 6))
+
+
+def test_T4_sine_parts_are_the_single_sine_integrals():
+    """T4 has no reference-held numeric vector (the reference's sine tests are properties, `test_aggregate.py:382-427`), so
+    the restatement of `_block_sine_dd`'s closed forms (`nb_kernels.py:224-249`) is anchored analytically instead: on a
+    window whose mean is its mid-range the single-sine model is T(t) = tavg + alpha sin(2 pi t) over one day, and the
+    cooling part must be the day's mean of max(T - thr, 0), the heating part the mean of max(thr - T, 0) — here by
+    numerical quadrature, for thresholds below, inside and above the window.  (This pins the algebra of the formulas both the
+    oracle and the kernel's `sine_arc` restate; their agreement with each other is the 1e-10 GPU test.)"""
+    from scipy.integrate import quad
+    rng = np.random.default_rng(77)
+    for _ in range(40):
+        tmin = float(rng.uniform(-10, 30))
+        tmax = tmin + float(rng.uniform(0.5, 25))
+        tavg, alpha = (tmin + tmax) / 2, (tmax - tmin) / 2
+        T = lambda t: tavg + alpha * np.sin(2 * np.pi * t)
+        for thr in (tmin - 3.0, tmin + 0.1 * (tmax - tmin), tavg, tmin + 0.93 * (tmax - tmin), tmax + 2.0):
+            stats = [np.array([v]) for v in (tmin, tmax, tavg)]
+            cool = float(rt._sine_part_cooling(thr, *stats)[0])
+            heat = float(rt._sine_part_heating(thr, *stats)[0])
+            # break points of the integrands: where the sine crosses the threshold
+            pts = None
+            if tmin < thr < tmax:
+                th0 = np.arcsin((thr - tavg) / alpha) / (2 * np.pi)
+                pts = sorted({(th0) % 1.0, (0.5 - th0) % 1.0})
+            want_c = quad(lambda t: max(T(t) - thr, 0.0), 0, 1, points=pts, limit=200, epsabs=1e-12, epsrel=1e-12)[0]
+            want_h = quad(lambda t: max(thr - T(t), 0.0), 0, 1, points=pts, limit=200, epsabs=1e-12, epsrel=1e-12)[0]
+            assert abs(cool - want_c) <= 1e-9 * max(1.0, abs(want_c)), (tmin, tmax, thr, cool, want_c)
+            assert abs(heat - want_h) <= 1e-9 * max(1.0, abs(want_h)), (tmin, tmax, thr, heat, want_h)
+            assert abs((cool - heat) - (tavg - thr)) <= 1e-9 * max(1.0, abs(tavg - thr))        # max(x,0) - max(-x,0) = x, averaged
