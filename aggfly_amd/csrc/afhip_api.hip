@@ -315,6 +315,17 @@ extern "C" int afhip_lz4_decode_streams(const void* comp_dev, const afhip_lz4_st
     if (max_dsize < 0) return fail(AFHIP_E_INVALID, "lz4_decode_streams: negative max_dsize");
     if (n_streams == 0) return AFHIP_OK;
     if (n_streams > 0x7fffffff) return fail(AFHIP_E_INVALID, "lz4_decode_streams: too many streams for one launch");
+    // Two kernels, both kept: the default writes straight to the destination and reads match sources back through L2 — no
+    // LDS, 32 waves per CU overlap the round trips (8.2 / 17.8 GB/s of LZ4 output on 896 / 1,792 concurrent streams, growing
+    // with the number of streams in flight); AFHIP_LZ4_LDS=1 decodes inside a 64 KiB LDS history ring, one or two waves
+    // per CU (3.7 / 4.8 GB/s on the same streams; profiles/r02_ingest_trace_gpu_decode.txt).
+    static const bool use_lds = [] { const char* e = getenv("AFHIP_LZ4_LDS"); return e && atoi(e) != 0; }();
+    if (!use_lds) {
+        hipLaunchKernelGGL(k_lz4_streams_hbm, dim3((unsigned)n_streams), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)comp_dev,
+                           (const Lz4Stream*)streams_dev, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev);
+        HIP_TRY(hipGetLastError());
+        return AFHIP_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {      // more than 64 KiB of dynamic LDS per workgroup needs the attribute
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz4_streams, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4_LDS_MAX));

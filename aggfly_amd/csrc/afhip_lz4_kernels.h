@@ -246,6 +246,272 @@ __global__ __launch_bounds__(64) void k_lz4_streams(const uint8_t* __restrict__ 
     if (op & (LZ4_SEG - 1)) flush(op & ~(LZ4_SEG - 1), op & (LZ4_SEG - 1));       // the last, partial segment
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lz4_streams_hbm: the same decode WITHOUT the LDS ring — the output is written straight to its destination and a match
+// reads its source back from there.  A wave's stores and later loads of the same bytes are ordered by s_waitcnt vmcnt(0)
+// (the store has reached L2) and the loads are L2-served (agent-scope relaxed atomics = sc1: the per-CU L1 is not kept
+// coherent with the stores).  Every sequence therefore pays one or two L2 round trips — several times the LDS version's
+// latency — but the kernel holds no LDS, so 16-32 waves per CU overlap those round trips instead of one or two.
+// The input window is read from global memory (read-only, L1-cached).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ld_l2_u8(const uint8_t* p) {
+    // 32-bit aligned container load, L2-served; the byte is extracted in registers
+    const uint32_t* q = (const uint32_t*)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)((v >> (8 * ((uintptr_t)p & 3))) & 0xff);
+}
+
+// i mod m for 0 <= i < 64 * m (the packed matches of k_lz4_streams_hbm: i < 64): six compare-subtract steps, no division
+__device__ __forceinline__ int small_mod(int i, int m) {
+#pragma unroll
+    for (int sft = 5; sft >= 0; --sft) i -= (i >= (m << sft)) ? (m << sft) : 0;
+    return i;
+}
+
+constexpr int LZ4_GROUP = 8;       // sequences parsed from one 64-byte window
+constexpr int LZ4_NEAR = 4096;     // the last bytes of the output, mirrored in LDS: matches into them wait for nothing
+
+__global__ __launch_bounds__(64) void k_lz4_streams_hbm(const uint8_t* __restrict__ comp, const Lz4Stream* __restrict__ streams,
+                                                        uint8_t* tmp, uint8_t* out, int32_t* __restrict__ errors) {
+    // Every output byte is also written to near[position mod LZ4_NEAR]: a match whose source lies within the last
+    // LZ4_NEAR bytes — the common case on byte planes of smooth fields — reads it from there (LDS operations of a wave run in
+    // order: no wait for the store to reach L2, no L2 round trip for the load); older history comes back from HBM / L2.
+    __shared__ uint8_t near[LZ4_NEAR];
+    const Lz4Stream s = streams[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint8_t* __restrict__ src = comp + s.src_off;
+    uint8_t* dst = (s.to_out ? out : tmp) + s.dst_off;
+    const int csize = s.csize, dsize = s.dsize;
+    if (csize == dsize) {
+        if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
+            const int body = dsize & ~15;
+            for (int i = lane * 16; i < body; i += 64 * 16) *(uint4*)(dst + i) = *(const uint4*)(src + i);
+            for (int i = body + lane; i < dsize; i += 64) dst[i] = src[i];
+        } else {
+            for (int i = lane; i < dsize; i += 64) dst[i] = src[i];
+        }
+        return;
+    }
+    if (csize <= 0 || dsize <= 0) {
+        if (lane == 0) atomicAdd(errors, 1);
+        return;
+    }
+    auto put = [&](int pos, int v) {                              // one output byte: HBM and the near ring
+        dst[pos] = (uint8_t)v;
+        near[pos & (LZ4_NEAR - 1)] = (uint8_t)v;
+    };
+    int p = 0, op = 0;
+    int acked = 0;                                               // output bytes [0, acked) are known to have reached L2
+    bool bad = false;
+    int w_next = src[lane < csize ? lane : csize - 1];           // the window of the next iteration, loaded one iteration ahead
+    while (true) {
+        if (p >= csize) { bad = true; break; }
+        const int w = w_next;
+        const int wl = (csize - p) < 64 ? (csize - p) : 64;      // valid bytes of the window
+        // ---- parse as many whole sequences as the window holds: token (+ at most one extension byte per length), up to 61
+        // literals, offset, a match of at most 64 bytes.  One window load then serves up to LZ4_GROUP sequences instead of
+        // one; what does not fit takes the generic path below. ----
+        uint64_t rec[LZ4_GROUP];                                 // literal start (6 bits) | L (6) << 6 | M (7) << 12 | offset << 19
+        int n = 0, c = 0, run = op;
+#pragma unroll
+        for (int k = 0; k < LZ4_GROUP; ++k) {
+            if (n != k || c >= wl) continue;                     // (stopped earlier)
+            const int tok = __builtin_amdgcn_readlane(w, c);
+            int L = tok >> 4, M = (tok & 15) + 4, pos = c + 1;
+            if (L == 15) {
+                if (pos >= wl) continue;
+                const int e = __builtin_amdgcn_readlane(w, pos);
+                if (e == 255) continue;                          // a literal run of 270 or more: generic path
+                L += e;
+                ++pos;
+            }
+            const int lc = pos;
+            pos += L;
+            if (pos + 2 > wl) continue;
+            const int off = __builtin_amdgcn_readlane(w, pos) | (__builtin_amdgcn_readlane(w, pos + 1) << 8);
+            pos += 2;
+            if ((tok & 15) == 15) {
+                if (pos >= wl) continue;
+                const int e = __builtin_amdgcn_readlane(w, pos);
+                M += e;
+                ++pos;
+                if (e == 255 || M > 64) continue;
+            }
+            if (p + pos > csize - 1) continue;                   // the stream's last bytes: generic path
+            if (L > dsize - run) { bad = true; continue; }
+            run += L;
+            if (off == 0 || off > run || M > dsize - run) { bad = true; continue; }
+            run += M;
+            rec[k] = (uint64_t)lc | ((uint64_t)L << 6) | ((uint64_t)M << 12) | ((uint64_t)off << 19);
+            c = pos;
+            n = k + 1;
+        }
+        if (bad) break;
+        if (n > 0) {
+            {   // the next window is on its way while this group's stores and loads run
+                const int a2 = p + c + lane;
+                w_next = src[a2 < csize ? a2 : csize - 1];
+            }
+            // ---- all the group's literals in ONE store: a lane of the window knows which sequence its byte belongs to ----
+            {
+                int my = -1, o = op;
+#pragma unroll
+                for (int k = 0; k < LZ4_GROUP; ++k) {
+                    if (k < n) {
+                        const int lc = (int)(rec[k] & 63), L = (int)((rec[k] >> 6) & 63), M = (int)((rec[k] >> 12) & 127);
+                        if (lane >= lc && lane < lc + L) my = o + lane - lc;
+                        o += L + M;
+                    }
+                }
+                if (my >= 0) put(my, w);
+            }
+            // ---- matches: consecutive ones that do not read what a pending one writes share the lanes of one load / store
+            // pair.  The ring now holds the group's literals too (up to position `run`): bytes from run - LZ4_NEAR on are near. ----
+            int my_src = 0, my_dst = -1, used = 0, pend_lo = 0, o = op;
+            bool my_near = false;
+            auto flush = [&]() {
+                if (used) {
+                    if (my_dst >= 0) put(my_dst, my_near ? (int)near[my_src & (LZ4_NEAR - 1)] : ld_l2_u8(dst + my_src));
+                    my_dst = -1;
+                    used = 0;
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < LZ4_GROUP; ++k) {
+                if (k < n) {
+                    const int L = (int)((rec[k] >> 6) & 63), M = (int)((rec[k] >> 12) & 127), off = (int)(rec[k] >> 19);
+                    o += L;                                       // the match's destination
+                    const int from = o - off, src_end = from + (M < off ? M : off);
+                    if (used && (src_end > pend_lo || used + M > 64)) flush();     // reads a pending match's bytes / lanes used up
+                    const bool is_near = from >= run - LZ4_NEAR;
+                    if (!is_near && src_end > acked) {           // old history that may not have reached L2 yet
+                        flush();
+                        __builtin_amdgcn_s_waitcnt(0);
+                        acked = o;
+                    }
+                    if (!used) pend_lo = o;
+                    const int i = lane - used;
+                    if (i >= 0 && i < M) {
+                        my_src = from + (off < M ? small_mod(i, off) : i);
+                        my_dst = o + i;
+                        my_near = is_near;
+                    }
+                    used += M;
+                    o += M;
+                }
+            }
+            flush();
+            p += c;
+            op = run;
+            continue;
+        }
+        // ---- generic path: one sequence with long length extensions, long copies, or the stream's last sequence ----
+        const int token = __builtin_amdgcn_readlane(w, 0);
+        int L = token >> 4, hdr = 1;
+        bool window_ok = true;                                    // the offset still sits in the window
+        if (L == 15) {
+            int q = p + 1;
+            while (true) {
+                if (q >= csize) { bad = true; break; }
+                const int a2 = q + lane;
+                const int w2 = src[a2 < csize ? a2 : csize - 1];
+                const uint64_t not255 = __builtin_amdgcn_ballot_w64(w2 != 255 || a2 >= csize);
+                const int k = not255 ? __builtin_ctzll(not255) : 64;
+                if (k < 64) {
+                    if (q + k >= csize) { bad = true; break; }
+                    L += 255 * k + __builtin_amdgcn_readlane(w2, k);
+                    q += k + 1;
+                    break;
+                }
+                L += 255 * 64;
+                q += 64;
+                if (L > dsize) { bad = true; break; }
+            }
+            if (bad) break;
+            hdr = q - p;
+            window_ok = false;
+        }
+        if (L > dsize - op || p + hdr + L > csize) { bad = true; break; }
+        if (window_ok && 1 + L <= wl) {
+            if (lane >= 1 && lane < 1 + L) put(op + lane - 1, w);
+        } else {
+            const uint8_t* from = src + p + hdr;
+            for (int i = lane; i < L; i += 64) put(op + i, from[i]);
+        }
+        p += hdr + L;
+        op += L;
+        if (p >= csize) break;
+        if (p + 2 > csize) { bad = true; break; }
+        int off;
+        if (window_ok && 1 + L + 2 <= wl) {
+            off = __builtin_amdgcn_readlane(w, 1 + L) | (__builtin_amdgcn_readlane(w, 2 + L) << 8);
+        } else {
+            const int o2 = src[p + (lane & 1)];
+            off = __builtin_amdgcn_readlane(o2, 0) | (__builtin_amdgcn_readlane(o2, 1) << 8);
+        }
+        p += 2;
+        int M = (token & 15) + 4;
+        if ((token & 15) == 15) {
+            while (true) {
+                if (p >= csize) { bad = true; break; }
+                const int a2 = p + lane;
+                const int w2 = src[a2 < csize ? a2 : csize - 1];
+                const uint64_t not255 = __builtin_amdgcn_ballot_w64(w2 != 255 || a2 >= csize);
+                const int k = not255 ? __builtin_ctzll(not255) : 64;
+                if (k < 64) {
+                    if (p + k >= csize) { bad = true; break; }
+                    M += 255 * k + __builtin_amdgcn_readlane(w2, k);
+                    p += k + 1;
+                    break;
+                }
+                M += 255 * 64;
+                p += 64;
+                if (M > dsize) { bad = true; break; }
+            }
+            if (bad) break;
+        }
+        if (off == 0 || off > op || M > dsize - op) { bad = true; break; }
+        if (off <= LZ4_NEAR - 64) {
+            // a near match of any length, 64 bytes a step through the ring.  off >= 64: a step reads bytes of earlier steps /
+            // sequences only.  Shorter periods: the first step repeats the last `off` bytes; later steps copy from P bytes
+            // back, P = the multiple of `off` in [64, 64 + off): written by earlier steps, never further back than the ring
+            // keeps even for matches much longer than the ring
+            const int P = off >= 64 ? off : off * ((64 + off - 1) / off);
+            for (int i0 = 0; i0 < M; i0 += 64) {
+                const int i = i0 + lane;
+                if (i < M) put(op + i, near[((i0 == 0 && off < 64) ? op - off + lane % off : op + i - P) & (LZ4_NEAR - 1)]);
+            }
+        } else {
+            // old history: it must have reached L2 — wait for this wave's outstanding stores only when the source touches bytes
+            // stored since the last wait
+            if (op - off + (M < off ? M : off) > acked) {
+                __builtin_amdgcn_s_waitcnt(0);
+                acked = op;
+            }
+            const uint8_t* from = dst + op - off;
+            if (off >= M) {                                       // no overlap: all loads first, then the stores
+                for (int i = lane; i < M; i += 64) put(op + i, ld_l2_u8(from + i));
+            } else {
+                // overlapping by whole steps (off > LZ4_NEAR - 64 >= 64): each step's source was stored by an earlier step
+                for (int i0 = 0; i0 < M; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < M) put(op + i, ld_l2_u8(from + i));
+                    __builtin_amdgcn_s_waitcnt(0);
+                }
+                acked = op + M;
+            }
+        }
+        op += M;
+        {
+            const int a2 = p + lane;
+            w_next = src[a2 < csize ? a2 : csize - 1];
+        }
+    }
+    if (bad || op != dsize) {
+        if (lane == 0) atomicAdd(errors, 1);
+    }
+}
+
 // Blosc's byte shuffle undone (unshuffle_bytes in blosc1.c): out[i * ts + j] = tmp[j * n + i], n = bsize / ts; the
 // bsize % ts trailing bytes are copied as they are.  grid = (element tiles, blocks); a thread assembles one element.
 __global__ __launch_bounds__(256) void k_unshuffle_blocks(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ out,

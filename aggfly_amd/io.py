@@ -574,8 +574,12 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     if cb >= (64 << 20):
         per = 1          # big chunks decode block-parallel on the whole team: one per batch pipelines best with the upload
     idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
-    nstage = 2 if len(idxs) > per else 1
     gpu_dec = _gpu_decodable(za)
+    if gpu_dec:
+        # the decode kernel hides its L2 round trips behind other streams: a batch should hold thousands of them
+        batch_bytes = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "512")) << 20
+        per = max(1, min(batch_bytes // cb, 65535 // max(1, -(-cb // getattr(za, "_blosc_geometry", (65536, 1))[0])), 4096))
+    nstage = 2 if len(idxs) > per else 1
     if gpu_dec:
         # compressed bytes + the two record lists of a batch share one page-locked slot and one H2D copy
         cmax = (int(codec.load().afcodec_blosc_bound(cb, 0)) + 63) // 64 * 64
@@ -595,6 +599,9 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
     # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
     copy_stream.wait_stream(torch.cuda.current_stream(device))
+    # GPU decode: the kernels of batch b run on their own stream beside the H2D copy of batch b + 1
+    work_stream = torch.cuda.Stream(device=device) if gpu_dec else copy_stream
+    work_stream.wait_stream(torch.cuda.current_stream(device))
     done = [None, None]
     trace = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
     tt = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
@@ -635,13 +642,18 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], outs, threads=threads)
             tt["read"] += _time.perf_counter() - _t0
         _t0 = _time.perf_counter()
-        with torch.cuda.stream(copy_stream):
-            if gpu_dec:
+        if gpu_dec:
+            with torch.cuda.stream(copy_stream):
                 n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                    # compressed bytes + stream records: one copy
                 comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
                 if n_bl:
                     n2 = n_bl * codec.SHUFFLE_BLOCK.itemsize
                     comp_dev[k][bl0:bl0 + n2].copy_(host[k][bl0:bl0 + n2], non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            work_stream.wait_event(up)
+        with torch.cuda.stream(work_stream):
+            if gpu_dec:
                 if n_st:
                     hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev, dev[k], errors)
                 if n_bl:
@@ -663,13 +675,14 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
                     else:                               # packed integers: the cast happens in this copy
                         dst.copy_(blk[t0 - c0:t1 - c0, y0 - iy * yc:y1 - iy * yc, x0 - ix * xc:x1 - ix * xc])
             ev = torch.cuda.Event()
-            ev.record(copy_stream)
+            ev.record(work_stream)
             done[k] = ev
         tt["enqueue"] += _time.perf_counter() - _t0
-    with torch.cuda.stream(copy_stream):
+    with torch.cuda.stream(work_stream):
         if post is not None:
             post(cube)
     _t0 = _time.perf_counter()
+    work_stream.synchronize()
     copy_stream.synchronize()
     if trace:
         tt["drain"] = _time.perf_counter() - _t0
@@ -677,7 +690,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     if gpu_dec and int(errors.item()):
         raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
                                "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")
-    torch.cuda.current_stream(device).wait_stream(copy_stream)
+    torch.cuda.current_stream(device).wait_stream(work_stream)
     return cube
 
 

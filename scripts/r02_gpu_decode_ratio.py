@@ -9,14 +9,19 @@ import torch
 import aggfly_amd as af
 from aggfly_amd import synth
 
-T, ny, nx = 8760, 104, 236
+YEARS = int(os.environ.get("YEARS", "1"))            # YEARS=4: a 3.4 GB store, enough batches for the pipeline's steady state
+T, ny, nx = 8760 * YEARS, 104, 236
 k = np.arange(T)[:, None, None]; y = np.arange(ny)[None, :, None]; x = np.arange(nx)[None, None, :]
-smooth = 285 + 12 * np.sin(2 * np.pi * k / 8760) + 5 * np.sin(2 * np.pi * (k % 24) / 24) + 8 * np.sin(y / 17.0) * np.cos(x / 23.0)
+smooth = 285 + 12 * np.sin(2 * np.pi * k / 8760.0) + 5 * np.sin(2 * np.pi * (k % 24) / 24) + 8 * np.sin(y / 17.0) * np.cos(x / 23.0)
 rng = np.random.default_rng(1)
 fields = {"noisy (bench field)": synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=1) + np.float32(273.15),
           "smooth + N(0, 0.3), 0.01 K steps": (np.round((smooth + rng.normal(0, 0.3, smooth.shape)) * 100) / 100).astype(np.float32),
-          "smooth, 0.01 K steps": (np.round(smooth * 100) / 100).astype(np.float32),
-          "smooth, 0.1 K steps": (np.round(smooth * 10) / 10).astype(np.float32)}
+          "smooth, 0.01 K steps": (np.round(smooth * 100) / 100).astype(np.float32)}
+only = os.environ.get("FIELDS")                       # FIELDS=noisy: a substring selects the fields (with AGGFLY_HIP_INGEST_TRACE=1: the phases)
+if only:
+    fields = {k_: v for k_, v in fields.items() if only in k_}
+elif YEARS == 1:
+    fields["smooth, 0.1 K steps"] = (np.round(smooth * 10) / 10).astype(np.float32)
 out = {}
 base = "/dev/shm" if os.path.isdir("/dev/shm") else None
 for name, arr in fields.items():
@@ -41,4 +46,5 @@ for name, arr in fields.items():
             print(name, "|", lname, row, flush=True)
             import shutil; shutil.rmtree(store)
 os.makedirs("gpurun_out/r02", exist_ok=True)
-json.dump(out, open("gpurun_out/r02/gpu_decode_by_ratio.json", "w"), indent=1)
+if not only:
+    json.dump(out, open(f"gpurun_out/r02/gpu_decode_by_ratio{'' if YEARS == 1 else '_%dyr' % YEARS}.json", "w"), indent=1)
