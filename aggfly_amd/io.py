@@ -389,6 +389,7 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
     copy_stream.wait_stream(torch.cuda.current_stream(device))
     done = [None, None]
+    uploaded = [None, None]
     for i, k0 in enumerate(range(0, T, slab_steps)):
         k1 = min(T, k0 + slab_steps)
         b = i % nstage
@@ -517,13 +518,17 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
             pool.shutdown()
 
 
-def _gpu_decodable(za) -> bool:
+GPU_DECODE_AUTO_BYTES = 256 << 20
+
+
+def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
-    from the first chunk file's header.  The route is OPT-IN (``AGGFLY_HIP_GPU_DECODE=1``): measured on MI355X it moves
-    5-13 GB/s of decoded data where the host threads + page-locked staging move 25-37 GB/s, on fields of every
-    compressibility tried (`profiles/r02_gpu_decode_by_ratio.json`): one wave resolves LZ4 sequences one
-    after the other and the 64 KiB history ring leaves two waves per CU."""
-    if os.environ.get("AGGFLY_HIP_GPU_DECODE", "0") != "1" or za.native_kind != "blosc":
+    from the first chunk file's header.  ``AGGFLY_HIP_GPU_DECODE``: ``1`` always, ``0`` never, unset / ``auto``: for requests
+    of `GPU_DECODE_AUTO_BYTES` decoded bytes or more.  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
+    DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 41-77 GB/s this way against 25-46 GB/s with the decode on
+    16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
+    mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")
+    if mode == "0" or za.native_kind != "blosc" or (mode != "1" and request_bytes < GPU_DECODE_AUTO_BYTES):
         return False
     hit = getattr(za, "_gpu_decodable", None)
     if hit is not None:
@@ -574,12 +579,26 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     if cb >= (64 << 20):
         per = 1          # big chunks decode block-parallel on the whole team: one per batch pipelines best with the upload
     idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
-    gpu_dec = _gpu_decodable(za)
+    gpu_dec = _gpu_decodable(za, len(idxs) * cb)
     if gpu_dec:
-        # the decode kernel hides its L2 round trips behind other streams: a batch should hold thousands of them
+        # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), so a batch takes about
+        # that long whatever its size, and the kernels of neighbouring batches were not seen to overlap: few, large batches
+        # (swept 128 / 256 / 512 MB x 2 / 4 slots on 0.9 and 3.4 GB stores: profiles/r02_gpu_decode_sweep.txt)
+        nblk1 = max(1, -(-cb // getattr(za, "_blosc_geometry", (65536, 1))[0]))
         batch_bytes = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "512")) << 20
-        per = max(1, min(batch_bytes // cb, 65535 // max(1, -(-cb // getattr(za, "_blosc_geometry", (65536, 1))[0])), 4096))
-    nstage = 2 if len(idxs) > per else 1
+        per = max(1, min(batch_bytes // cb, 65535 // nblk1, 4096, len(idxs)))
+    # batch boundaries.  GPU decode: a quarter-size first and last batch — the upload starts after a short read, and less
+    # work is left when the host has run out of batches to overlap it with
+    cuts = list(range(0, len(idxs), per)) + [len(idxs)]
+    if gpu_dec and len(idxs) > 2 * per and per >= 8:
+        q = per // 4
+        cuts = sorted(set([0] + list(range(q, len(idxs) - q, per)) + [len(idxs) - q, len(idxs)]))
+    nstage = min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "3")) if gpu_dec else 2, len(cuts) - 1)
+    # a chunk of whole time steps of the window (full grid, same dtype) is a contiguous run of the cube
+    direct_ok = gpu_dec and same_dtype and (ya, xa) == (0, 0) and (yc, xc) == (yb, xb) == (ny, nx)
+    step_bytes = ny * nx * za.dtype.itemsize
+    cube_bytes = cube.view(torch.uint8).reshape(-1) if direct_ok else None
+    dev = [None] * nstage                                # decoded chunks before their placement (GPU decode: only batches that need it)
     if gpu_dec:
         # compressed bytes + the two record lists of a batch share one page-locked slot and one H2D copy
         cmax = (int(codec.load().afcodec_blosc_bound(cb, 0)) + 63) // 64 * 64
@@ -590,27 +609,33 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
         rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
         host = _pinned_stage(per * cmax + rec_bytes, nstage)
         comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
-        tmp_dev = torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device)
+        tmp_dev = [torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device) for _ in range(nstage)]
         errors = torch.zeros(1, dtype=torch.int32, device=device)
     else:
         host = _pinned_stage(per * cb, nstage)
-    dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
+        dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
     copy_stream = torch.cuda.Stream(device=device)
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
     # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
     copy_stream.wait_stream(torch.cuda.current_stream(device))
-    # GPU decode: the kernels of batch b run on their own stream beside the H2D copy of batch b + 1
-    work_stream = torch.cuda.Stream(device=device) if gpu_dec else copy_stream
-    work_stream.wait_stream(torch.cuda.current_stream(device))
-    done = [None, None]
+    # GPU decode: the kernels of batch b run on their slot's stream beside the uploads and kernels of the next batches
+    work_streams = [torch.cuda.Stream(device=device) for _ in range(nstage)] if gpu_dec else [copy_stream] * nstage
+    for ws in set(work_streams):
+        ws.wait_stream(torch.cuda.current_stream(device))
+    done = [None] * nstage
+    uploaded = [None] * nstage
     trace = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
     tt = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
     import time as _time
-    for b, lo in enumerate(range(0, len(idxs), per)):
-        batch = idxs[lo:lo + per]
+    for b, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        batch = idxs[lo:hi]
         k = b % nstage
+        work_stream = work_streams[k]
         _t0 = _time.perf_counter()
-        if done[k] is not None:
+        if gpu_dec:
+            if uploaded[k] is not None:
+                uploaded[k].synchronize()               # the page-locked slot is free once its upload is over; the device-side
+        elif done[k] is not None:                       # buffer is handed on between the streams (below)
             done[k].synchronize()                       # both staging buffers of slot k are free again
         tt["wait"] += _time.perf_counter() - _t0
         _t0 = _time.perf_counter()
@@ -627,13 +652,18 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             rec0 = int(offs[-1])
             streams = hall[rec0:rec0 + cap_streams * codec.LZ4_STREAM.itemsize].view(codec.LZ4_STREAM)
             blocks = hall[rec0 + streams.nbytes:rec0 + streams.nbytes + cap_blocks * codec.SHUFFLE_BLOCK.itemsize].view(codec.SHUFFLE_BLOCK)
-            n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], np.asarray(present, dtype=np.int64) * cb,
+            # chunks that hold whole time steps of the window decode straight into the cube (their bytes are one contiguous
+            # run of it): no staging copy, no placement launch per chunk
+            direct = direct_ok and all(ka <= it * tc and (it + 1) * tc <= kb for it, _, _ in batch)
+            out_offs = (np.array([batch[i][0] * tc - ka for i in present], dtype=np.int64) * step_bytes if direct
+                        else np.asarray(present, dtype=np.int64) * cb)
+            n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], out_offs,
                                                                         np.full(len(present), cb, dtype=np.int64), streams, blocks)
             if (pres != cb).any():
                 badc = [za.chunk_locator(batch[present[i]])[0] for i in np.nonzero(pres != cb)[0][:4]]
                 raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
                                        "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
-            assert tmp_bytes <= tmp_dev.numel()
+            assert tmp_bytes <= tmp_dev[k].numel()
             bl0 = rec0 + streams.nbytes
             tt["plan"] += _time.perf_counter() - _t0
         else:
@@ -644,6 +674,8 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
         _t0 = _time.perf_counter()
         if gpu_dec:
             with torch.cuda.stream(copy_stream):
+                if done[k] is not None:
+                    copy_stream.wait_event(done[k])     # the kernels of the slot's previous batch have read comp_dev[k]
                 n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                    # compressed bytes + stream records: one copy
                 comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
                 if n_bl:
@@ -651,16 +683,22 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
                     comp_dev[k][bl0:bl0 + n2].copy_(host[k][bl0:bl0 + n2], non_blocking=True)
                 up = torch.cuda.Event()
                 up.record(copy_stream)
+                uploaded[k] = up
             work_stream.wait_event(up)
         with torch.cuda.stream(work_stream):
             if gpu_dec:
+                if not direct and dev[k] is None:
+                    dev[k] = torch.empty(per * cb, dtype=torch.uint8, device=device)
+                target = cube_bytes if direct else dev[k]
                 if n_st:
-                    hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev, dev[k], errors)
+                    hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev[k], target, errors)
                 if n_bl:
-                    hip.unshuffle_blocks(tmp_dev, dev[k], comp_dev[k][bl0:], n_bl, int(blocks["bsize"][:n_bl].max()))
+                    hip.unshuffle_blocks(tmp_dev[k], target, comp_dev[k][bl0:], n_bl, int(blocks["bsize"][:n_bl].max()))
             else:
                 dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
             for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
+                if gpu_dec and direct and r != -100:
+                    continue                            # already in place
                 c0 = it * tc                            # first step of the chunk
                 t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
                 y0, y1 = max(iy * yc, ya), min((iy + 1) * yc, yb)
@@ -678,6 +716,9 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             ev.record(work_stream)
             done[k] = ev
         tt["enqueue"] += _time.perf_counter() - _t0
+    work_stream = work_streams[0]
+    for ws in work_streams[1:]:
+        work_stream.wait_stream(ws)
     with torch.cuda.stream(work_stream):
         if post is not None:
             post(cube)
@@ -686,7 +727,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     copy_stream.synchronize()
     if trace:
         tt["drain"] = _time.perf_counter() - _t0
-        print("ingest trace:", {"gpu_decode": gpu_dec, "batches": -(-len(idxs) // per), "chunks_per_batch": per, **{k_: round(v * 1e3, 2) for k_, v in tt.items()}}, flush=True)
+        print("ingest trace:", {"gpu_decode": gpu_dec, "batches": len(cuts) - 1, "chunks_per_batch": per, **{k_: round(v * 1e3, 2) for k_, v in tt.items()}}, flush=True)
     if gpu_dec and int(errors.item()):
         raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
                                "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")

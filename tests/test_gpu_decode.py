@@ -145,6 +145,12 @@ def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkey
     np.testing.assert_array_equal(dev.cube().cpu().numpy(), cube)
     win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-05", "2001-01-11"))
     np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[24 * 4:24 * 11])
+    # small batches, a window that starts and ends inside chunks: batches of whole chunks decode straight into the cube, the
+    # two edge batches go through the staging buffer
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "1")
+    win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-02 06:00", "2001-01-21 19:00"))
+    np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[30:500])
+    monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB")
     kinds.clear()
     monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "0")
     host = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
