@@ -315,66 +315,32 @@ extern "C" int afhip_lz4_decode_streams(const void* comp_dev, const afhip_lz4_st
     if (max_dsize < 0) return fail(AFHIP_E_INVALID, "lz4_decode_streams: negative max_dsize");
     if (n_streams == 0) return AFHIP_OK;
     if (n_streams > 0x7fffffff) return fail(AFHIP_E_INVALID, "lz4_decode_streams: too many streams for one launch");
-    // Three kernels while they are being compared (AFHIP_LZ4_KERNEL): "vec" (default) resolves the sequences of a 64-byte
-    // window in the lanes and produces 64 consecutive output bytes a round; "hbm" is its scalar, sequence-by-sequence
-    // predecessor (bound by the CU's one scalar unit); "lds" decodes inside a 64 KiB LDS history ring, one or two waves per CU.
-    static const int which = [] {
-        const char* e = getenv("AFHIP_LZ4_KERNEL");
-        if (e && !strcmp(e, "hbm")) return 1;
-        if ((e && !strcmp(e, "lds")) || (getenv("AFHIP_LZ4_LDS") && atoi(getenv("AFHIP_LZ4_LDS")) != 0)) return 2;
-        return 0;
-    }();
-    static const int near_bytes = [] { const char* e = getenv("AFHIP_LZ4_NEAR"); return e ? atoi(e) : 4096; }();
-    if (which == 0) {
-        const dim3 g((unsigned)n_streams), b(64);
-        hipStream_t st = (hipStream_t)stream;
-        const uint8_t* c = (const uint8_t*)comp_dev;
-        const Lz4Stream* sr = (const Lz4Stream*)streams_dev;
-        static const bool prof = [] { const char* e = getenv("AFHIP_LZ4_PROF"); return e && atoi(e) != 0; }();
-        if (prof) {      // measuring aid: cycles per phase, summed over the LZ4 streams of this launch, on stderr
-            long long* d = nullptr;
-            HIP_TRY(hipMalloc(&d, (size_t)n_streams * 8 * sizeof(long long)));
-            HIP_TRY(hipMemsetAsync(d, 0, (size_t)n_streams * 8 * sizeof(long long), st));
-            hipLaunchKernelGGL((k_lz4_streams_vec<4096, true>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, d);
-            std::vector<long long> h((size_t)n_streams * 8);
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            HIP_TRY(hipFree(d));
-            long long tot[8] = {0}, mx = 0;
-            for (int64_t i = 0; i < n_streams; ++i) {
-                long long sum = 0;
-                for (int j = 0; j < 7; ++j) { tot[j] += h[i * 8 + j]; sum += h[i * 8 + j]; }
-                tot[7] += h[i * 8 + 7];
-                mx = std::max(mx, sum);
-            }
-            fprintf(stderr, "lz4 prof (cycles of the 100 MHz counter, all streams): parse %lld walk %lld scan %lld owner %lld pending %lld store %lld "
-                            "generic %lld; windows %lld; longest stream %lld\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], tot[7], mx);
-            return AFHIP_OK;
+    const dim3 g((unsigned)n_streams), b(64);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* c = (const uint8_t*)comp_dev;
+    const Lz4Stream* sr = (const Lz4Stream*)streams_dev;
+    static const bool prof = [] { const char* e = getenv("AFHIP_LZ4_PROF"); return e && atoi(e) != 0; }();
+    if (prof) {      // measuring aid: cycles per phase, summed over the LZ4 streams of this launch, on stderr (synchronous)
+        long long* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)n_streams * 8 * sizeof(long long)));
+        HIP_TRY(hipMemsetAsync(d, 0, (size_t)n_streams * 8 * sizeof(long long), st));
+        hipLaunchKernelGGL((k_lz4_streams_vec<LZ4_NEAR, true>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, d);
+        std::vector<long long> h((size_t)n_streams * 8);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(d));
+        long long tot[8] = {0}, mx = 0;
+        for (int64_t i = 0; i < n_streams; ++i) {
+            long long sum = 0;
+            for (int j = 0; j < 7; ++j) { tot[j] += h[i * 8 + j]; sum += h[i * 8 + j]; }
+            tot[7] += h[i * 8 + 7];
+            mx = std::max(mx, sum);
         }
-        switch (near_bytes) {
-            case 2048: hipLaunchKernelGGL((k_lz4_streams_vec<2048, false>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, (long long*)nullptr); break;
-            case 8192: hipLaunchKernelGGL((k_lz4_streams_vec<8192, false>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, (long long*)nullptr); break;
-            case 16384: hipLaunchKernelGGL((k_lz4_streams_vec<16384, false>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, (long long*)nullptr); break;
-            default: hipLaunchKernelGGL((k_lz4_streams_vec<4096, false>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, (long long*)nullptr); break;
-        }
-        HIP_TRY(hipGetLastError());
+        fprintf(stderr, "lz4 prof (shader clock cycles, all streams): parse %lld walk %lld scan %lld owner %lld pending %lld store %lld "
+                        "generic %lld; windows %lld; longest stream %lld\n", tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], tot[7], mx);
         return AFHIP_OK;
     }
-    if (which == 1) {
-        hipLaunchKernelGGL(k_lz4_streams_hbm, dim3((unsigned)n_streams), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)comp_dev,
-                           (const Lz4Stream*)streams_dev, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev);
-        HIP_TRY(hipGetLastError());
-        return AFHIP_OK;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {      // more than 64 KiB of dynamic LDS per workgroup needs the attribute
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lz4_streams, hipFuncAttributeMaxDynamicSharedMemorySize, LZ4_LDS_MAX));
-        attr_set = true;
-    }
-    // output ring: the whole stream when it is short, else 64 KiB of history + the segment being written
-    const int ring = (int)std::min<int64_t>(LZ4_RING_MAX, std::max<int64_t>(LZ4_SEG, ((int64_t)max_dsize + LZ4_SEG - 1) / LZ4_SEG * LZ4_SEG));
-    hipLaunchKernelGGL(k_lz4_streams, dim3((unsigned)n_streams), dim3(64), (size_t)ring + LZ4_IN, (hipStream_t)stream, (const uint8_t*)comp_dev,
-                       (const Lz4Stream*)streams_dev, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, ring);
+    hipLaunchKernelGGL((k_lz4_streams_vec<LZ4_NEAR, false>), g, b, 0, st, c, sr, (uint8_t*)tmp_dev, (uint8_t*)out_dev, errors_dev, (long long*)nullptr);
     HIP_TRY(hipGetLastError());
     return AFHIP_OK;
 }

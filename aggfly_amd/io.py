@@ -509,7 +509,7 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np, t_range, yx_box), za
         if not whole_rows and za.native_kind is not None:
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
-        if za.native_kind == "blosc" and _gpu_decodable(za):
+        if za.native_kind == "blosc" and _gpu_decodable(za, T * ny * nx * za.dtype.itemsize):
             # Blosc-LZ4 chunks cross PCIe compressed and are decoded in HBM: the scatter route, whatever the chunk grid
             return _stream_chunks_scatter(za, device, threads, slab_bytes, post if need_post else None, out_np), za
         return stream_to_device(T, (ny, nx), za.dtype, read, slab, device, post if need_post else None, out_np), za
@@ -593,7 +593,7 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     if gpu_dec and len(idxs) > 2 * per and per >= 8:
         q = per // 4
         cuts = sorted(set([0] + list(range(q, len(idxs) - q, per)) + [len(idxs) - q, len(idxs)]))
-    nstage = min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "3")) if gpu_dec else 2, len(cuts) - 1)
+    nstage = max(1, min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "3")) if gpu_dec else 2, len(cuts) - 1))
     # a chunk of whole time steps of the window (full grid, same dtype) is a contiguous run of the cube
     direct_ok = gpu_dec and same_dtype and (ya, xa) == (0, 0) and (yc, xc) == (yb, xb) == (ny, nx)
     step_bytes = ny * nx * za.dtype.itemsize

@@ -143,10 +143,11 @@ int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_size,
 /* Chunk decode in HBM ("or GPU-side decode"; the reference decodes on host threads inside its dask
  * graph, aggfly/dataset/dataset.py:697-728).  Blosc-1 chunks whose streams are LZ4 cross PCIe compressed; the host parses
  * the containers (afcodec_blosc_lz4_plan, include/aggfly_codec.h) into the two record lists below, which travel to HBM with
- * the compressed bytes.  afhip_lz4_decode_streams: one wave per stream decodes it inside LDS (a 64 KiB history ring: streams
- * of any length) and writes dsize bytes to (to_out ? out_dev : tmp_dev) + dst_off; stored streams (csize == dsize) are
- * copied.  max_dsize = the longest dsize of the list (sizes the ring).  A malformed stream writes nothing outside its own
- * destination and adds 1 to *errors_dev (read it after the next synchronisation).
+ * the compressed bytes.  afhip_lz4_decode_streams: one wave per stream (any length) resolves the sequences of a 64-byte
+ * window in its lanes and writes dsize bytes straight to (to_out ? out_dev : tmp_dev) + dst_off — out_dev may be the data
+ * cube itself; stored streams (csize == dsize) are copied.  max_dsize = the longest dsize of the list (checked >= 0, not
+ * otherwise used since the decode left LDS).  A malformed stream writes nothing outside its own destination and adds 1 to
+ * *errors_dev (read it after the next synchronisation).
  * afhip_unshuffle_blocks: Blosc's byte shuffle undone, tmp_dev -> out_dev.  All pointers are device memory. */
 typedef struct afhip_lz4_stream { int64_t src_off, dst_off; int32_t csize, dsize, to_out, pad; } afhip_lz4_stream;
 typedef struct afhip_shuffle_block { int64_t tmp_off, out_off; int32_t bsize, typesize; } afhip_shuffle_block;

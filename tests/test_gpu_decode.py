@@ -127,9 +127,9 @@ def _store(tmp_path, name, cube, chunks, time=None):
 
 @pytest.mark.parametrize("layout", ["time_contiguous", "space_tiled", "whole_series_tiles"])
 def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkeypatch, layout):
-    """`dataset_from_path(device="cuda")` on Blosc-LZ4 stores: with the chunks decoded in HBM (default) or on the host threads
-    (the default; AGGFLY_HIP_GPU_DECODE=1 opts in) the cube is the same, bit for bit — whole store, a time window, a region box; the GPU route
-    never calls the host Blosc decoder."""
+    """`dataset_from_path(device="cuda")` on Blosc-LZ4 stores: with the chunks decoded in HBM (AGGFLY_HIP_GPU_DECODE=1; the
+    default for requests of 256 MB or more) or on the host threads (=0) the cube is the same, bit for bit — whole store,
+    time windows that start and end inside chunks; the GPU route never calls the host Blosc decoder."""
     T, ny, nx = 24 * 30, 40, 64
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=3, ocean_frac=0.1, scattered_nan=40) + np.float32(273.15)
     chunks = {"time_contiguous": {"time": 48, "latitude": ny, "longitude": nx}, "space_tiled": {"time": 100, "latitude": 16, "longitude": 24},
@@ -139,7 +139,7 @@ def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkey
     kinds = []
     real = codec.decode_ranges
     monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
-    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")                 # the route is opt-in
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")                 # (these stores are below the size the route starts at)
     dev = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
     assert set(kinds) == {"raw"}, kinds                              # files read as they are; no host decode
     np.testing.assert_array_equal(dev.cube().cpu().numpy(), cube)
@@ -164,3 +164,25 @@ def test_float64_stores_decode_in_hbm(torch_cuda, tmp_path, monkeypatch):
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=4, scattered_nan=10)
     path = _store(tmp_path, "d.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
     np.testing.assert_array_equal(af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda").cube().cpu().numpy(), cube)
+
+
+def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypatch):
+    """No environment switch: a 306 MB request (>= `io.GPU_DECODE_AUTO_BYTES`) reads its chunk files as they are and decodes them
+    on the GPU — several batches in flight, whole-step chunks straight into the cube — and gives the host route's cube."""
+    from aggfly_amd import io as afio
+    monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE", raising=False)
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "64")
+    T, ny, nx = 24 * 130, 104, 236
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=11) + np.float32(273.15)
+    assert cube.nbytes >= afio.GPU_DECODE_AUTO_BYTES
+    path = _store(tmp_path, "big.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
+    kinds = []
+    real = codec.decode_ranges
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
+    dev = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
+    assert set(kinds) == {"raw"} and len(kinds) >= 5, kinds
+    got = dev.cube().cpu().numpy()
+    np.testing.assert_array_equal(got, cube)
+    small = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-01-09"))
+    assert kinds[-1] == "blosc"                                      # a 16 MB window: host threads
+    np.testing.assert_array_equal(small.cube().cpu().numpy(), cube[48:216])

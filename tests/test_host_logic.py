@@ -226,6 +226,27 @@ def test_lat_and_time_windows_on_the_host_route(tmp_path):
         _band_of_box(("time", "latitude", "longitude"), (10, 6, 4), ("longitude", "latitude"), (1, 5, 0, 4), (0, 5))
 
 
+def test_gpu_decode_route_is_chosen_by_request_size(tmp_path, monkeypatch):
+    """`io._gpu_decodable`: Blosc-LZ4 stores take the decode-in-HBM route for requests of 256 MB or more, always with
+    AGGFLY_HIP_GPU_DECODE=1, never with =0; other codecs never do."""
+    from aggfly_amd import io as afio
+    arr, time, lat, lon = gi.dataset_360_inputs()
+    ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=True)
+    lz4, raw = str(tmp_path / "a.zarr"), str(tmp_path / "b.zarr")
+    af.dataset_to_zarr(ds, lz4, var="v")
+    af.dataset_to_zarr(ds, raw, var="v", compress=False)
+    monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE", raising=False)
+    za = afio.ZarrArray(os.path.join(lz4, "v"))
+    assert not afio._gpu_decodable(za, 1 << 20) and afio._gpu_decodable(za, afio.GPU_DECODE_AUTO_BYTES)
+    assert za._blosc_geometry[1] == arr.dtype.itemsize
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")
+    assert afio._gpu_decodable(za, 0)
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "0")
+    assert not afio._gpu_decodable(za, 1 << 40)
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")
+    assert not afio._gpu_decodable(afio.ZarrArray(os.path.join(raw, "v")), 1 << 40)
+
+
 def test_preprocess_and_unsorted_time():
     arr, time, lat, lon = gi.dataset_360_inputs()
     perm = [2, 0, 3, 1]
