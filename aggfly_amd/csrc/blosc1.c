@@ -503,6 +503,64 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
     int bad = 0;
     if (nthreads < 1) nthreads = 1;
     if ((kind & 15) == 2 && need_zstd()) return AFCODEC_E_UNSUPPORTED;
+    if (kind == 0 && n > 0) {
+        /* raw bytes (stores without a compressor; the compressed chunk files of the decode-in-HBM route): the files are
+         * cut into 1 MiB pieces and the PIECES are spread over the team — a batch of 14 files of 12.5 MB read one file
+         * per thread moved 22 GB/s out of the page cache, 227 files of 1.6 MB 60 GB/s */
+        enum { PIECE = 1 << 20 };
+        int* fds = (int*)malloc((size_t)n * sizeof(int));
+        int64_t* first = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));   /* first piece of file i */
+        int64_t* offs = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+        if (!fds || !first || !offs) { free(fds); free(first); free(offs); return fail(AFCODEC_E_SIZE, "out of memory"); }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+        for (int64_t i = 0; i < n; ++i) {
+            fds[i] = open(paths[i], O_RDONLY);
+            int64_t off = 0, sz = -1;
+            if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
+            if (fds[i] < 0) { results[i] = -100; offs[i] = 0; continue; }
+            struct stat stt;
+            if (fstat(fds[i], &stt) != 0) { results[i] = AFCODEC_E_FORMAT; close(fds[i]); fds[i] = -1; continue; }
+            if (sz < 0) sz = (int64_t)stt.st_size - off;
+            if (sz < 0 || off + sz > (int64_t)stt.st_size) { results[i] = AFCODEC_E_FORMAT; close(fds[i]); fds[i] = -1; continue; }
+            if (sz > dstsizes[i]) { results[i] = AFCODEC_E_SIZE; close(fds[i]); fds[i] = -1; continue; }
+            results[i] = sz;
+            offs[i] = off;
+        }
+        first[0] = 0;
+        for (int64_t i = 0; i < n; ++i) first[i + 1] = first[i] + (fds[i] >= 0 ? (results[i] + PIECE - 1) / PIECE : 0);
+        const int64_t npieces = first[n];
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (int64_t q = 0; q < npieces; ++q) {
+            int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
+            while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
+            while (first[lo + 1] <= q) ++lo;                      /* (files without pieces share a boundary) */
+            const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
+            int64_t done = 0;
+            while (done < len) {
+                const ssize_t got = pread(fds[lo], (uint8_t*)dsts[lo] + at + done, (size_t)(len - done), (off_t)(offs[lo] + at + done));
+                if (got <= 0) break;
+                done += got;
+            }
+            if (done != len) {
+#pragma omp atomic write
+                offs[lo] = -1;                                    /* marks the file as failed */
+            }
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            if (fds[i] >= 0) {
+                close(fds[i]);
+                if (offs[i] < 0) results[i] = AFCODEC_E_FORMAT;
+            }
+            if (results[i] < 0 && results[i] != -100) bad += 1;
+        }
+        free(fds); free(first); free(offs);
+        if (bad) {
+            for (int64_t i = 0; i < n; ++i)
+                if (results[i] == AFCODEC_E_SIZE) return fail(AFCODEC_E_CODEC, "raw chunk larger than its destination (see results[])");
+            return fail(AFCODEC_E_CODEC, "one or more chunk files could not be read (see results[])");
+        }
+        return AFCODEC_OK;
+    }
     if (kind == 1 && n * 2 <= nthreads) {
         /* fewer Blosc chunks than half the team: one chunk at a time, its blocks over the whole team, decoded
          * straight out of the page cache (mmap: no read() copy of a ~200 MB file in front of the decode) */

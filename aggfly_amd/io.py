@@ -525,7 +525,7 @@ def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
     from the first chunk file's header.  ``AGGFLY_HIP_GPU_DECODE``: ``1`` always, ``0`` never, unset / ``auto``: for requests
     of `GPU_DECODE_AUTO_BYTES` decoded bytes or more.  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
-    DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 41-77 GB/s this way against 25-46 GB/s with the decode on
+    DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 38-79 GB/s this way against 27-42 GB/s with the decode on
     16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
     mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")
     if mode == "0" or za.native_kind != "blosc" or (mode != "1" and request_bytes < GPU_DECODE_AUTO_BYTES):
@@ -585,7 +585,8 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
         # that long whatever its size, and the kernels of neighbouring batches were not seen to overlap: few, large batches
         # (swept 128 / 256 / 512 MB x 2 / 4 slots on 0.9 and 3.4 GB stores: profiles/r02_gpu_decode_sweep.txt)
         nblk1 = max(1, -(-cb // getattr(za, "_blosc_geometry", (65536, 1))[0]))
-        batch_bytes = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "512")) << 20
+        env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")     # default: a quarter of the request, 128-512 MB
+        batch_bytes = (int(env_mb) << 20) if env_mb else min(max(len(idxs) * cb // 4, 128 << 20), 512 << 20)
         per = max(1, min(batch_bytes // cb, 65535 // nblk1, 4096, len(idxs)))
     # batch boundaries.  GPU decode: a quarter-size first and last batch — the upload starts after a short read, and less
     # work is left when the host has run out of batches to overlap it with
@@ -627,6 +628,10 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     trace = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
     tt = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
     import time as _time
+    tl, t_origin = [], _time.perf_counter()             # trace: per-batch GPU timeline (GPU decode route)
+    if trace and gpu_dec:
+        ev_origin = torch.cuda.Event(enable_timing=True)
+        ev_origin.record(copy_stream)
     for b, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
         batch = idxs[lo:hi]
         k = b % nstage
@@ -676,6 +681,11 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             with torch.cuda.stream(copy_stream):
                 if done[k] is not None:
                     copy_stream.wait_event(done[k])     # the kernels of the slot's previous batch have read comp_dev[k]
+                if trace:
+                    tl.append({"batch": b, "chunks": len(batch), "host_read_done_ms": (_time.perf_counter() - t_origin) * 1e3,
+                               "h2d0": torch.cuda.Event(enable_timing=True), "h2d1": torch.cuda.Event(enable_timing=True),
+                               "k1": torch.cuda.Event(enable_timing=True)})
+                    tl[-1]["h2d0"].record(copy_stream)
                 n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                    # compressed bytes + stream records: one copy
                 comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
                 if n_bl:
@@ -684,6 +694,8 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
                 up = torch.cuda.Event()
                 up.record(copy_stream)
                 uploaded[k] = up
+                if trace:
+                    tl[-1]["h2d1"].record(copy_stream)
             work_stream.wait_event(up)
         with torch.cuda.stream(work_stream):
             if gpu_dec:
@@ -715,6 +727,8 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
             ev = torch.cuda.Event()
             ev.record(work_stream)
             done[k] = ev
+            if trace and gpu_dec:
+                tl[-1]["k1"].record(work_stream)
         tt["enqueue"] += _time.perf_counter() - _t0
     work_stream = work_streams[0]
     for ws in work_streams[1:]:
@@ -727,6 +741,10 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     copy_stream.synchronize()
     if trace:
         tt["drain"] = _time.perf_counter() - _t0
+        for e in tl:                                     # ms since the first copy could have started
+            print("ingest timeline: batch %2d  %4d chunks  host read done %7.2f | upload %7.2f .. %7.2f | kernels done %7.2f" % (
+                e["batch"], e["chunks"], e["host_read_done_ms"], ev_origin.elapsed_time(e["h2d0"]), ev_origin.elapsed_time(e["h2d1"]),
+                ev_origin.elapsed_time(e["k1"])), flush=True)
         print("ingest trace:", {"gpu_decode": gpu_dec, "batches": len(cuts) - 1, "chunks_per_batch": per, **{k_: round(v * 1e3, 2) for k_, v in tt.items()}}, flush=True)
     if gpu_dec and int(errors.item()):
         raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
