@@ -557,199 +557,269 @@ def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     return ok
 
 
+class _ScatterJob:
+    """What both routes of `_stream_chunks_scatter` share: the window, the chunks that touch it, the cube, and the
+    placement of decoded chunks into it."""
+
+    def __init__(self, za, device, out_dtype, t_range, yx_box):
+        import torch
+        self.za, self.device = za, device
+        T, ny, nx = za.shape
+        self.tc, self.yc, self.xc = za.chunks
+        self.tdt = _torch_dtype(za.dtype)
+        self.same_dtype = (out_dtype is None or np.dtype(out_dtype) == za.dtype) and za.dtype.itemsize in (2, 4, 8)
+        self.ka, self.kb = (0, T) if t_range is None else (max(0, int(t_range[0])), min(T, int(t_range[1])))   # time window [ka, kb)
+        self.ya, self.yb, self.xa, self.xb = (0, ny, 0, nx) if yx_box is None else yx_box                    # spatial box
+        self.cube = torch.empty((self.kb - self.ka, self.yb - self.ya, self.xb - self.xa),
+                                dtype=_torch_dtype(out_dtype) if out_dtype is not None else self.tdt, device=device)
+        self.cb = za.chunk_nbytes
+        tc, yc, xc = za.chunks
+        self.idxs = [(it, iy, ix) for it in range(self.ka // tc, -(-self.kb // tc)) for iy in range(self.ya // yc, -(-self.yb // yc))
+                     for ix in range(self.xa // xc, -(-self.xb // xc))]
+        # a chunk of whole time steps of the window (full grid, same dtype) is one contiguous run of the cube
+        self.whole_steps = self.same_dtype and (self.ya, self.xa) == (0, 0) and (yc, xc) == (self.yb, self.xb) == (ny, nx)
+        self.step_bytes = ny * nx * za.dtype.itemsize
+
+    def inside(self, it) -> bool:
+        """All time steps of chunk row ``it`` lie in the window."""
+        return self.ka <= it * self.tc and (it + 1) * self.tc <= self.kb
+
+    def place(self, batch, res, staged, skip_present=False):
+        """Queue (on the current stream) the placement of a batch: decoded chunk i sits at ``staged[i * cb:]``; absent
+        chunks (``res[i] == -100``) become the fill value.  ``skip_present``: the present chunks are in place already."""
+        from . import hip
+        tc, yc, xc, ka, kb, ya, yb, xa, xb, cb, cube = self.tc, self.yc, self.xc, self.ka, self.kb, self.ya, self.yb, self.xa, self.xb, self.cb, self.cube
+        for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
+            if skip_present and r != -100:
+                continue
+            c0 = it * tc                            # first step of the chunk
+            t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
+            y0, y1 = max(iy * yc, ya), min((iy + 1) * yc, yb)
+            x0, x1 = max(ix * xc, xa), min((ix + 1) * xc, xb)
+            dst = cube[t0 - ka:t1 - ka, y0 - ya:y1 - ya, x0 - xa:x1 - xa]
+            if r == -100:                           # absent chunk = fill value
+                dst.fill_(float(self.za._fill()))
+                continue
+            blk = staged[i * cb:(i + 1) * cb].view(self.tdt).view(tc, yc, xc)
+            if self.same_dtype:                     # one coalesced pass (torch's strided copy ran at 22 GB/s here)
+                hip.place_box(blk, cube, (t0 - c0, y0 - iy * yc, x0 - ix * xc, t1 - t0, y1 - y0, x1 - x0), (t0 - ka, y0 - ya, x0 - xa))
+            else:                                   # packed integers: the cast happens in this copy
+                dst.copy_(blk[t0 - c0:t1 - c0, y0 - iy * yc:y1 - iy * yc, x0 - ix * xc:x1 - ix * xc])
+
+
+class _IngestTrace:
+    """``AGGFLY_HIP_INGEST_TRACE=1``: host phases of a read (ms) and, on the decode-in-HBM route, a HIP-event timeline of
+    its batches.  Costs nothing when off."""
+
+    def __init__(self):
+        import time
+        self.on = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
+        self.clock = time.perf_counter
+        self.phase = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
+        self.batches, self.t0, self._mark = [], self.clock(), self.clock()
+
+    def lap(self, name):
+        now = self.clock()
+        self.phase[name] += now - self._mark
+        self._mark = now
+
+    def skip(self):
+        self._mark = self.clock()
+
+    def report(self, origin_event, **head):
+        if not self.on:
+            return
+        for e in self.batches:                       # ms since the first upload could have started
+            print("ingest timeline: batch %2d  %4d chunks  host read done %7.2f | upload %7.2f .. %7.2f | kernels done %7.2f" % (
+                e["batch"], e["chunks"], e["host_read_done_ms"], origin_event.elapsed_time(e["h2d0"]), origin_event.elapsed_time(e["h2d1"]),
+                origin_event.elapsed_time(e["k1"])), flush=True)
+        print("ingest trace:", {**head, **{k_: round(v * 1e3, 2) for k_, v in self.phase.items()}}, flush=True)
+
+
 def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: int, post=None, out_dtype=None, t_range=None, yx_box=None):
-    """Any chunk grid (e.g. the whole-time-series-per-spatial-tile layout `_auto_chunks` writes): the host
-    only ever decodes chunks CONTIGUOUSLY — a batch of Blosc chunk files is read and decoded by one OpenMP
-    team back to back into a cached page-locked buffer — the batch goes to HBM in one asynchronous copy,
-    and the GPU scatters every chunk into its (time, y, x) box of the cube (a strided device-to-device
-    copy at HBM speed).  The strided placement is the part a CPU is bad at (472-byte row pieces)."""
+    """Any chunk grid, any time / space window: batches of chunks reach HBM through page-locked staging and the GPU
+    places every chunk into its (time, y, x) box of the cube (a strided device-to-device copy at HBM speed — the part a
+    CPU is bad at: 472-byte row pieces).  Two routes: the chunks decoded by the host's OpenMP team
+    (`_scatter_host_decode`), or — Blosc-LZ4, larger requests — uploaded compressed and decoded in HBM
+    (`_scatter_gpu_decode`, `_gpu_decodable`)."""
+    job = _ScatterJob(za, device, out_dtype, t_range, yx_box)
+    if _gpu_decodable(za, len(job.idxs) * job.cb):
+        return _scatter_gpu_decode(job, threads, post)
+    return _scatter_host_decode(job, threads, slab_bytes, post)
+
+
+def _scatter_host_decode(job: _ScatterJob, threads: int, slab_bytes: int, post):
+    """The host only ever decodes chunks CONTIGUOUSLY — a batch of chunk files is read and decoded by one OpenMP team
+    back to back into a cached page-locked buffer — and the batch goes to HBM in one asynchronous copy, two buffers
+    taking turns."""
     import torch
-    from . import codec, hip
-    T, ny, nx = za.shape
-    tc, yc, xc = za.chunks
-    tdt = _torch_dtype(za.dtype)
-    same_dtype = (out_dtype is None or np.dtype(out_dtype) == za.dtype) and za.dtype.itemsize in (2, 4, 8)
-    ka, kb = (0, T) if t_range is None else (max(0, int(t_range[0])), min(T, int(t_range[1])))   # time window [ka, kb)
-    ya, yb, xa, xb = (0, ny, 0, nx) if yx_box is None else yx_box                                  # spatial box [ya, yb) x [xa, xb)
-    cube = torch.empty((kb - ka, yb - ya, xb - xa), dtype=_torch_dtype(out_dtype) if out_dtype is not None else tdt, device=device)
-    cb = za.chunk_nbytes
+    from . import codec
+    za, device, cb, idxs = job.za, job.device, job.cb, job.idxs
     # chunks per batch: ~slab_bytes, at least one per decode thread, but never more than 1 GiB of page-locked
     # staging per buffer (the reference's own converter writes ~256 MB chunks)
     per = max(1, min(max(threads, slab_bytes // cb), max(1, (1 << 30) // cb), 4096))
     if cb >= (64 << 20):
         per = 1          # big chunks decode block-parallel on the whole team: one per batch pipelines best with the upload
-    idxs = [(it, iy, ix) for it in range(ka // tc, -(-kb // tc)) for iy in range(ya // yc, -(-yb // yc)) for ix in range(xa // xc, -(-xb // xc))]
-    gpu_dec = _gpu_decodable(za, len(idxs) * cb)
-    if gpu_dec:
-        # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), so a batch takes about
-        # that long whatever its size, and the kernels of neighbouring batches were not seen to overlap: few, large batches
-        # (swept 128 / 256 / 512 MB x 2 / 4 slots on 0.9 and 3.4 GB stores: profiles/r02_gpu_decode_sweep.txt)
-        nblk1 = max(1, -(-cb // getattr(za, "_blosc_geometry", (65536, 1))[0]))
-        env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")     # default: a quarter of the request, 128-512 MB
-        batch_bytes = (int(env_mb) << 20) if env_mb else min(max(len(idxs) * cb // 4, 128 << 20), 512 << 20)
-        per = max(1, min(batch_bytes // cb, 65535 // nblk1, 4096, len(idxs)))
-    # batch boundaries.  GPU decode: a quarter-size first and last batch — the upload starts after a short read, and less
-    # work is left when the host has run out of batches to overlap it with
-    cuts = list(range(0, len(idxs), per)) + [len(idxs)]
-    if gpu_dec and len(idxs) > 2 * per and per >= 8:
-        q = per // 4
-        cuts = sorted(set([0] + list(range(q, len(idxs) - q, per)) + [len(idxs) - q, len(idxs)]))
-    nstage = max(1, min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "3")) if gpu_dec else 2, len(cuts) - 1))
-    # a chunk of whole time steps of the window (full grid, same dtype) is a contiguous run of the cube
-    direct_ok = gpu_dec and same_dtype and (ya, xa) == (0, 0) and (yc, xc) == (yb, xb) == (ny, nx)
-    step_bytes = ny * nx * za.dtype.itemsize
-    cube_bytes = cube.view(torch.uint8).reshape(-1) if direct_ok else None
-    dev = [None] * nstage                                # decoded chunks before their placement (GPU decode: only batches that need it)
-    if gpu_dec:
-        # compressed bytes + the two record lists of a batch share one page-locked slot and one H2D copy
-        cmax = (int(codec.load().afcodec_blosc_bound(cb, 0)) + 63) // 64 * 64
-        bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
-        nblk = -(-cb // bsz)
-        cap_streams = per * (nblk * tsz + cb // 65536 + 2)          # one stream per byte plane of a block; stored chunks in 64 KiB pieces
-        cap_blocks = per * nblk
-        rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
-        host = _pinned_stage(per * cmax + rec_bytes, nstage)
-        comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
-        tmp_dev = [torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device) for _ in range(nstage)]
-        errors = torch.zeros(1, dtype=torch.int32, device=device)
-    else:
-        host = _pinned_stage(per * cb, nstage)
-        dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
+    nstage = 2 if len(idxs) > per else 1
+    host = _pinned_stage(per * cb, nstage)
+    dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
     copy_stream = torch.cuda.Stream(device=device)
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
     # still be read by queued kernels (the previous HBM window's fused pass) — order the copies behind them
     copy_stream.wait_stream(torch.cuda.current_stream(device))
-    # GPU decode: the kernels of batch b run on their slot's stream beside the uploads and kernels of the next batches
-    work_streams = [torch.cuda.Stream(device=device) for _ in range(nstage)] if gpu_dec else [copy_stream] * nstage
-    for ws in set(work_streams):
-        ws.wait_stream(torch.cuda.current_stream(device))
     done = [None] * nstage
-    uploaded = [None] * nstage
-    trace = os.environ.get("AGGFLY_HIP_INGEST_TRACE") == "1"
-    tt = {"wait": 0.0, "read": 0.0, "plan": 0.0, "enqueue": 0.0}
-    import time as _time
-    tl, t_origin = [], _time.perf_counter()             # trace: per-batch GPU timeline (GPU decode route)
-    if trace and gpu_dec:
-        ev_origin = torch.cuda.Event(enable_timing=True)
-        ev_origin.record(copy_stream)
+    trace = _IngestTrace()
+    for b, lo in enumerate(range(0, len(idxs), per)):
+        batch = idxs[lo:lo + per]
+        k = b % nstage
+        trace.skip()
+        if done[k] is not None:
+            done[k].synchronize()                       # both staging buffers of slot k are free again
+        trace.lap("wait")
+        hbuf = host[k][:len(batch) * cb].numpy()
+        res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))],
+                                  threads=threads)
+        trace.lap("read")
+        with torch.cuda.stream(copy_stream):
+            dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
+            job.place(batch, res, dev[k])
+            done[k] = torch.cuda.Event()
+            done[k].record(copy_stream)
+        trace.lap("enqueue")
+    with torch.cuda.stream(copy_stream):
+        if post is not None:
+            post(job.cube)
+    trace.skip()
+    copy_stream.synchronize()
+    trace.phase["drain"] = trace.clock() - trace._mark
+    trace.report(None, gpu_decode=False, batches=-(-len(idxs) // per), chunks_per_batch=per)
+    torch.cuda.current_stream(device).wait_stream(copy_stream)
+    return job.cube
+
+
+def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
+    """Blosc-LZ4 chunks cross PCIe compressed: per batch the host reads the chunk files as they are into a
+    page-locked slot and parses the containers into the record lists (`codec.blosc_lz4_plan`); one upload carries the
+    compressed bytes and the records; `hip.lz4_decode_streams` + `hip.unshuffle_blocks` decode on the slot's stream —
+    straight into the cube when every chunk of the batch holds whole time steps of the window, else into a staging
+    buffer that `job.place` empties.  The page-locked slot is free again when its upload is over; the device-side one
+    is handed from the kernels to the slot's next upload by an event."""
+    import torch
+    from . import codec, hip
+    za, device, cb, idxs, cube = job.za, job.device, job.cb, job.idxs, job.cube
+    bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
+    nblk = max(1, -(-cb // bsz))
+    # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), so a batch takes about
+    # that long whatever its size, and the kernels of neighbouring batches were not seen to overlap: few, large batches
+    # (swept 128 / 256 / 512 MB x 2 / 4 slots on 0.9 and 3.4 GB stores: profiles/r02_gpu_decode_sweep.txt)
+    env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")     # default: a quarter of the request, 128-512 MB
+    batch_bytes = (int(env_mb) << 20) if env_mb else min(max(len(idxs) * cb // 4, 128 << 20), 512 << 20)
+    per = max(1, min(batch_bytes // cb, 65535 // nblk, 4096, len(idxs)))
+    # a quarter-size first and last batch: the upload starts after a short read, and less work is left when the host has
+    # run out of batches to overlap it with
+    cuts = list(range(0, len(idxs), per)) + [len(idxs)]
+    if len(idxs) > 2 * per and per >= 8:
+        q = per // 4
+        cuts = sorted(set([0] + list(range(q, len(idxs) - q, per)) + [len(idxs) - q, len(idxs)]))
+    nstage = max(1, min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "3")), len(cuts) - 1))
+    cube_bytes = cube.view(torch.uint8).reshape(-1) if job.whole_steps else None
+    # compressed bytes + the two record lists of a batch share one page-locked slot and one upload
+    cmax = (int(codec.load().afcodec_blosc_bound(cb, 0)) + 63) // 64 * 64
+    cap_streams = per * (nblk * tsz + cb // 65536 + 2)          # one stream per byte plane of a block; stored chunks in 64 KiB pieces
+    cap_blocks = per * nblk
+    rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
+    host = _pinned_stage(per * cmax + rec_bytes, nstage)
+    comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
+    tmp_dev = [torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device) for _ in range(nstage)]
+    staged = [None] * nstage                             # decoded chunks of batches that cannot go straight into the cube
+    errors = torch.zeros(1, dtype=torch.int32, device=device)
+    copy_stream = torch.cuda.Stream(device=device)
+    copy_stream.wait_stream(torch.cuda.current_stream(device))    # (as on the host route: order behind the allocator's stream)
+    work_streams = [torch.cuda.Stream(device=device) for _ in range(nstage)]
+    for ws in work_streams:
+        ws.wait_stream(torch.cuda.current_stream(device))
+    done, uploaded = [None] * nstage, [None] * nstage
+    trace = _IngestTrace()
+    origin = torch.cuda.Event(enable_timing=True)
+    if trace.on:
+        origin.record(copy_stream)
     for b, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
         batch = idxs[lo:hi]
         k = b % nstage
-        work_stream = work_streams[k]
-        _t0 = _time.perf_counter()
-        if gpu_dec:
-            if uploaded[k] is not None:
-                uploaded[k].synchronize()               # the page-locked slot is free once its upload is over; the device-side
-        elif done[k] is not None:                       # buffer is handed on between the streams (below)
-            done[k].synchronize()                       # both staging buffers of slot k are free again
-        tt["wait"] += _time.perf_counter() - _t0
-        _t0 = _time.perf_counter()
-        if gpu_dec:
-            # host: read the chunk files as they are, packed back to back; parse the containers into the record lists
-            locs = [za.chunk_locator(i) for i in batch]
-            sizes = np.array([-1 if l is None else (l[2] if l[2] >= 0 else os.path.getsize(l[0]) - l[1]) for l in locs], dtype=np.int64)
-            offs = np.concatenate([[0], np.cumsum((np.maximum(sizes, 0) + 63) // 64 * 64)])
-            hall = host[k].numpy()
-            res = codec.decode_ranges("raw", locs, [hall[offs[i]:offs[i] + max(int(sizes[i]), 0)] for i in range(len(batch))], threads=threads)
-            tt["read"] += _time.perf_counter() - _t0
-            _t0 = _time.perf_counter()
-            present = [i for i, r in enumerate(res) if r != -100]
-            rec0 = int(offs[-1])
-            streams = hall[rec0:rec0 + cap_streams * codec.LZ4_STREAM.itemsize].view(codec.LZ4_STREAM)
-            blocks = hall[rec0 + streams.nbytes:rec0 + streams.nbytes + cap_blocks * codec.SHUFFLE_BLOCK.itemsize].view(codec.SHUFFLE_BLOCK)
-            # chunks that hold whole time steps of the window decode straight into the cube (their bytes are one contiguous
-            # run of it): no staging copy, no placement launch per chunk
-            direct = direct_ok and all(ka <= it * tc and (it + 1) * tc <= kb for it, _, _ in batch)
-            out_offs = (np.array([batch[i][0] * tc - ka for i in present], dtype=np.int64) * step_bytes if direct
-                        else np.asarray(present, dtype=np.int64) * cb)
-            n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], out_offs,
-                                                                        np.full(len(present), cb, dtype=np.int64), streams, blocks)
-            if (pres != cb).any():
-                badc = [za.chunk_locator(batch[present[i]])[0] for i in np.nonzero(pres != cb)[0][:4]]
-                raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
-                                       "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
-            assert tmp_bytes <= tmp_dev[k].numel()
-            bl0 = rec0 + streams.nbytes
-            tt["plan"] += _time.perf_counter() - _t0
-        else:
-            hbuf = host[k][:len(batch) * cb].numpy()
-            outs = [hbuf[i * cb:(i + 1) * cb] for i in range(len(batch))]
-            res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in batch], outs, threads=threads)
-            tt["read"] += _time.perf_counter() - _t0
-        _t0 = _time.perf_counter()
-        if gpu_dec:
-            with torch.cuda.stream(copy_stream):
-                if done[k] is not None:
-                    copy_stream.wait_event(done[k])     # the kernels of the slot's previous batch have read comp_dev[k]
-                if trace:
-                    tl.append({"batch": b, "chunks": len(batch), "host_read_done_ms": (_time.perf_counter() - t_origin) * 1e3,
-                               "h2d0": torch.cuda.Event(enable_timing=True), "h2d1": torch.cuda.Event(enable_timing=True),
-                               "k1": torch.cuda.Event(enable_timing=True)})
-                    tl[-1]["h2d0"].record(copy_stream)
-                n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                    # compressed bytes + stream records: one copy
-                comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
-                if n_bl:
-                    n2 = n_bl * codec.SHUFFLE_BLOCK.itemsize
-                    comp_dev[k][bl0:bl0 + n2].copy_(host[k][bl0:bl0 + n2], non_blocking=True)
-                up = torch.cuda.Event()
-                up.record(copy_stream)
-                uploaded[k] = up
-                if trace:
-                    tl[-1]["h2d1"].record(copy_stream)
-            work_stream.wait_event(up)
-        with torch.cuda.stream(work_stream):
-            if gpu_dec:
-                if not direct and dev[k] is None:
-                    dev[k] = torch.empty(per * cb, dtype=torch.uint8, device=device)
-                target = cube_bytes if direct else dev[k]
-                if n_st:
-                    hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev[k], target, errors)
-                if n_bl:
-                    hip.unshuffle_blocks(tmp_dev[k], target, comp_dev[k][bl0:], n_bl, int(blocks["bsize"][:n_bl].max()))
-            else:
-                dev[k][:len(batch) * cb].copy_(host[k][:len(batch) * cb], non_blocking=True)
-            for i, ((it, iy, ix), r) in enumerate(zip(batch, res)):
-                if gpu_dec and direct and r != -100:
-                    continue                            # already in place
-                c0 = it * tc                            # first step of the chunk
-                t0, t1 = max(c0, ka), min(c0 + tc, kb)  # the part of it inside the window
-                y0, y1 = max(iy * yc, ya), min((iy + 1) * yc, yb)
-                x0, x1 = max(ix * xc, xa), min((ix + 1) * xc, xb)
-                dst = cube[t0 - ka:t1 - ka, y0 - ya:y1 - ya, x0 - xa:x1 - xa]
-                if r == -100:                           # absent chunk = fill value
-                    dst.fill_(float(za._fill()))
-                else:
-                    blk = dev[k][i * cb:(i + 1) * cb].view(tdt).view(tc, yc, xc)
-                    if same_dtype:                      # one coalesced pass (torch's strided copy ran at 22 GB/s here)
-                        hip.place_box(blk, cube, (t0 - c0, y0 - iy * yc, x0 - ix * xc, t1 - t0, y1 - y0, x1 - x0), (t0 - ka, y0 - ya, x0 - xa))
-                    else:                               # packed integers: the cast happens in this copy
-                        dst.copy_(blk[t0 - c0:t1 - c0, y0 - iy * yc:y1 - iy * yc, x0 - ix * xc:x1 - ix * xc])
-            ev = torch.cuda.Event()
-            ev.record(work_stream)
-            done[k] = ev
-            if trace and gpu_dec:
-                tl[-1]["k1"].record(work_stream)
-        tt["enqueue"] += _time.perf_counter() - _t0
-    work_stream = work_streams[0]
+        trace.skip()
+        if uploaded[k] is not None:
+            uploaded[k].synchronize()                    # the page-locked slot is free once its upload is over
+        trace.lap("wait")
+        # ---- host: the chunk files as they are, packed back to back; then the record lists ----
+        locs = [za.chunk_locator(i) for i in batch]
+        sizes = np.array([-1 if l is None else (l[2] if l[2] >= 0 else os.path.getsize(l[0]) - l[1]) for l in locs], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum((np.maximum(sizes, 0) + 63) // 64 * 64)])
+        hall = host[k].numpy()
+        res = codec.decode_ranges("raw", locs, [hall[offs[i]:offs[i] + max(int(sizes[i]), 0)] for i in range(len(batch))], threads=threads)
+        trace.lap("read")
+        present = [i for i, r in enumerate(res) if r != -100]
+        rec0 = int(offs[-1])
+        streams = hall[rec0:rec0 + cap_streams * codec.LZ4_STREAM.itemsize].view(codec.LZ4_STREAM)
+        bl0 = rec0 + streams.nbytes
+        blocks = hall[bl0:bl0 + cap_blocks * codec.SHUFFLE_BLOCK.itemsize].view(codec.SHUFFLE_BLOCK)
+        direct = job.whole_steps and all(job.inside(it) for it, _, _ in batch)
+        out_offs = (np.array([batch[i][0] * job.tc - job.ka for i in present], dtype=np.int64) * job.step_bytes if direct
+                    else np.asarray(present, dtype=np.int64) * cb)
+        n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], out_offs,
+                                                                    np.full(len(present), cb, dtype=np.int64), streams, blocks)
+        if (pres != cb).any():
+            badc = [za.chunk_locator(batch[present[i]])[0] for i in np.nonzero(pres != cb)[0][:4]]
+            raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
+                                   "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
+        assert tmp_bytes <= tmp_dev[k].numel()
+        trace.lap("plan")
+        # ---- upload (copy stream), then decode + placement (the slot's stream) ----
+        with torch.cuda.stream(copy_stream):
+            if done[k] is not None:
+                copy_stream.wait_event(done[k])          # the kernels of the slot's previous batch have read comp_dev[k]
+            if trace.on:
+                trace.batches.append({"batch": b, "chunks": len(batch), "host_read_done_ms": (trace.clock() - trace.t0) * 1e3,
+                                      **{n: torch.cuda.Event(enable_timing=True) for n in ("h2d0", "h2d1", "k1")}})
+                trace.batches[-1]["h2d0"].record(copy_stream)
+            n1 = rec0 + n_st * codec.LZ4_STREAM.itemsize                                        # compressed bytes + stream records: one copy
+            comp_dev[k][:n1].copy_(host[k][:n1], non_blocking=True)
+            if n_bl:
+                n2 = n_bl * codec.SHUFFLE_BLOCK.itemsize
+                comp_dev[k][bl0:bl0 + n2].copy_(host[k][bl0:bl0 + n2], non_blocking=True)
+            uploaded[k] = torch.cuda.Event()
+            uploaded[k].record(copy_stream)
+            if trace.on:
+                trace.batches[-1]["h2d1"].record(copy_stream)
+        work_streams[k].wait_event(uploaded[k])
+        with torch.cuda.stream(work_streams[k]):
+            if not direct and staged[k] is None:
+                staged[k] = torch.empty(per * cb, dtype=torch.uint8, device=device)
+            target = cube_bytes if direct else staged[k]
+            if n_st:
+                hip.lz4_decode_streams(comp_dev[k], comp_dev[k][rec0:], n_st, max_d, tmp_dev[k], target, errors)
+            if n_bl:
+                hip.unshuffle_blocks(tmp_dev[k], target, comp_dev[k][bl0:], n_bl, int(blocks["bsize"][:n_bl].max()))
+            job.place(batch, res, staged[k], skip_present=direct)
+            done[k] = torch.cuda.Event()
+            done[k].record(work_streams[k])
+            if trace.on:
+                trace.batches[-1]["k1"].record(work_streams[k])
+        trace.lap("enqueue")
+    last = work_streams[0]
     for ws in work_streams[1:]:
-        work_stream.wait_stream(ws)
-    with torch.cuda.stream(work_stream):
+        last.wait_stream(ws)
+    with torch.cuda.stream(last):
         if post is not None:
             post(cube)
-    _t0 = _time.perf_counter()
-    work_stream.synchronize()
+    trace.skip()
+    last.synchronize()
     copy_stream.synchronize()
-    if trace:
-        tt["drain"] = _time.perf_counter() - _t0
-        for e in tl:                                     # ms since the first copy could have started
-            print("ingest timeline: batch %2d  %4d chunks  host read done %7.2f | upload %7.2f .. %7.2f | kernels done %7.2f" % (
-                e["batch"], e["chunks"], e["host_read_done_ms"], ev_origin.elapsed_time(e["h2d0"]), ev_origin.elapsed_time(e["h2d1"]),
-                ev_origin.elapsed_time(e["k1"])), flush=True)
-        print("ingest trace:", {"gpu_decode": gpu_dec, "batches": len(cuts) - 1, "chunks_per_batch": per, **{k_: round(v * 1e3, 2) for k_, v in tt.items()}}, flush=True)
-    if gpu_dec and int(errors.item()):
+    trace.phase["drain"] = trace.clock() - trace._mark
+    trace.report(origin, gpu_decode=True, batches=len(cuts) - 1, chunks_per_batch=per)
+    if int(errors.item()):
         raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
                                "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")
-    torch.cuda.current_stream(device).wait_stream(work_stream)
+    torch.cuda.current_stream(device).wait_stream(last)
     return cube
 
 
