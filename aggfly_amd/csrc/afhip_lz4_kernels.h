@@ -50,8 +50,8 @@ __device__ __forceinline__ int ld_l2_u8(const uint8_t* p) {
 //   * the compressed bytes arrive a 64-byte line of the stream at a time, loaded three lines ahead (their addresses do
 //     not depend on the parse); a window = the 64 bytes at the read position, cut out of two lines by bpermute;
 //   * every lane parses the window AS IF a token started at its byte (token, one optional extension byte per length,
-//     offset: four bpermutes), which gives `next`, the lane of the following token; the only serial step left is the
-//     walk 0 -> next[0] -> next[next[0]] ... (one v_readlane per sequence) that marks the real tokens;
+//     offset: four bpermutes), which gives `next`, the lane of the following token; the real tokens are 0, next[0],
+//     next[next[0]], ...: lane t finds the t-th of them by binary lifting (token_walk_lifted);
 //   * a DPP prefix sum over the token lanes places every sequence in the output;
 //   * the output is then produced 64 CONSECUTIVE bytes a round, a byte per lane: the lane finds the sequence it belongs
 //     to (starts scattered through 256 B of LDS, prefix maximum), takes its literal from the window by bpermute or its
@@ -60,10 +60,11 @@ __device__ __forceinline__ int ld_l2_u8(const uint8_t* p) {
 //     that retires at least the first pending lane per pass).
 // Sequences that do not fit a window (literal runs of 60+ bytes, length extensions of more than one byte, the stream's
 // last sequence) take the generic path at the end of the loop, one at a time.
-// Measured (profiles/r02_lz4_vec_phase_cycles.txt, s_memtime per phase): ~7,400 cycles per window of ~18 sequences on the
-// noisy byte planes of the bench field — parse 12 %, token walk 29 %, scan 5 %, owner lookup + gathers 32 %, pending loop
-// 12 %, store 2 %, generic 8 % — i.e. 2.2 ms for a 64 KiB plane, start to end, whatever else the chip does: a launch takes
-// that long once it has fewer streams than wave slots, which is why the ingest path feeds it large batches.
+// Measured (profiles/r02_lz4_vec_phase_cycles.txt, s_memtime per phase): ~6,400 cycles per window of ~18 sequences on the
+// noisy byte planes of the bench field — parse 14 %, token walk 18 % (29 % of 7,400 with the serial walk), scan 5 %, owner
+// lookup + gathers 37 %, pending loop 14 %, store 3 %, generic 9 % — i.e. 1.9 ms for a 64 KiB plane, start to end, whatever
+// else the chip does: a launch takes that long once it has fewer streams than wave slots, which is why the ingest path
+// feeds it large batches.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_or0(int v) {                   // the DPP-selected lane's v, 0 where there is none / masked off
@@ -97,6 +98,47 @@ __device__ __forceinline__ int mod_small(int i, int m) {
     r += r < 0 ? m : 0;
     r -= r >= m ? m : 0;
     return r;
+}
+
+// The tokens of a window: 0, next[0], next[next[0]], ... while the sequence fits (next <= 64; 65 = it does not).
+// -> bit mask of the token lanes; c = the byte after the last of them.  Serial form: one v_readlane round trip per sequence
+// (2,100 of the 7,400 cycles a window took; kept as the reference of scripts/probe/dpp_scan_check.hip).
+__device__ __forceinline__ uint64_t token_walk_serial(int nextv, int& c) {
+    uint64_t tmask = 0;
+    c = 0;
+    for (int pos = 0; pos < 64;) {
+        const int t = __builtin_amdgcn_readlane(nextv, pos);
+        if (t > 64) break;
+        tmask |= 1ull << pos;
+        pos = c = t;
+    }
+    return tmask;
+}
+// Lifted form: lane t finds the t-th token by binary lifting (next^2, ^4, ^8, ^16 by bpermute; a window holds at most 21
+// sequences), then the token lanes are marked through LDS (mark: 64 ints).  Ten bpermutes, six of them in a dependent
+// chain.  Every lane takes every hop and keeps it or not: a bpermute inside a divergent branch reads 0 from the lanes the
+// branch switched off.
+__device__ __forceinline__ uint64_t token_walk_lifted(int nextv, int lane, volatile int* mark, int& c) {
+    auto hop = [&](int table, int x) { const int y = lane_get(table, x); return x < 64 ? y : 65; };
+    const int j2 = hop(nextv, nextv), j4 = hop(j2, j2), j8 = hop(j4, j4), j16 = hop(j8, j8);
+    const int next0 = __builtin_amdgcn_readlane(nextv, 0);       // (taken before the select: inside it, "first lane" is lane 1)
+    int pos = (lane & 1) ? next0 : 0;
+    const int h2 = hop(j2, pos);
+    pos = (lane & 2) ? h2 : pos;
+    const int h4 = hop(j4, pos);
+    pos = (lane & 4) ? h4 : pos;
+    const int h8 = hop(j8, pos);
+    pos = (lane & 8) ? h8 : pos;
+    const int h16 = hop(j16, pos);
+    pos = (lane & 16) ? h16 : pos;
+    const int nxt = hop(nextv, pos);                              // where the t-th token's sequence ends (65: it does not fit)
+    const bool valid = lane < 32 && nxt <= 64;
+    mark[lane] = 0;
+    if (valid) mark[pos] = 1;
+    const uint64_t tmask = __builtin_amdgcn_ballot_w64(mark[lane] != 0);
+    const int n = __builtin_popcountll(tmask);
+    c = n ? __builtin_amdgcn_readlane(nxt, n - 1) : 0;
+    return tmask;
 }
 
 constexpr int LZ4_NEAR = 4096;     // output bytes mirrored in LDS (2 / 8 / 16 KiB measured the same: profiles/r02_lz4_vec_near_ring_sizes.txt)
@@ -187,14 +229,8 @@ __global__ __launch_bounds__(64) void k_lz4_streams_vec(const uint8_t* __restric
         const bool fits = !(extL && b1 == 255) && !(extM && e == 255) && nx <= wl && p + nx < csize;
         const int nextv = fits ? nx : 65;
         if (PROF) { pc[6] += __builtin_amdgcn_readfirstlane(nextv) & 0; tick(0); }     // (the use makes the parse finish before the tick)
-        uint64_t tmask = 0;
         int c = 0;
-        for (int pos = 0; pos < 64;) {                            // the one serial step: token -> next token
-            const int t = __builtin_amdgcn_readlane(nextv, pos);
-            if (t > 64) break;
-            tmask |= 1ull << pos;
-            pos = c = t;
-        }
+        const uint64_t tmask = token_walk_lifted(nextv, lane, mark, c);
         tick(1);
         if (tmask) {
             if (PROF) pc[7] += 1;

@@ -63,12 +63,24 @@ def decode_stream(comp, src_off, csize, dsize, stats):
         nx = opos + np.where(extM, 3, 2)
         fits = ~(extL & (b1 == 255)) & ~(extM & (e == 255)) & (nx <= wl) & (p + nx < csize)
         nextv = np.where(fits, nx, 65)
-        tmask = np.zeros(64, bool); c = 0; pos = 0
-        while pos < 64:
-            t = int(nextv[pos])
+        # the t-th token of the window by binary lifting (lane t), then the token lanes marked through LDS
+        def hop(table, x):
+            return np.where(x < 64, lane_get(table, x), 65)
+        j2 = hop(nextv, nextv); j4 = hop(j2, j2); j8 = hop(j4, j4); j16 = hop(j8, j8)
+        pos = np.where(LANE & 1, nextv[0], 0)
+        for bit, tab in ((2, j2), (4, j4), (8, j8), (16, j16)):
+            pos = np.where(LANE & bit, hop(tab, pos), pos)
+        nxt = hop(nextv, pos)
+        valid = (LANE < 32) & (nxt <= 64)
+        tmask = np.zeros(64, bool); tmask[pos[valid]] = True
+        n = int(tmask.sum()); c = int(nxt[n - 1]) if n else 0
+        ref_mask = np.zeros(64, bool); rc = 0; rp = 0       # the serial walk it replaces
+        while rp < 64:
+            t = int(nextv[rp])
             if t > 64:
                 break
-            tmask[pos] = True; pos = c = t
+            ref_mask[rp] = True; rp = rc = t
+        assert (ref_mask == tmask).all() and rc == c, (ref_mask.nonzero(), tmask.nonzero(), rc, c)
         if tmask.any():
             ln = np.where(tmask, L + M, 0)
             incl = np.cumsum(ln); drel = incl - ln; tot = int(incl[63])
