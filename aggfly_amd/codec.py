@@ -62,13 +62,15 @@ def load():
         lib.afcodec_blosc_lz4_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                C.POINTER(C.c_int32), C.c_void_p]
+        lib.afcodec_read_packed.argtypes = [C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64,
+                                            C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
 
 EXPORTS = ("afcodec_last_error", "afcodec_have", "afcodec_blosc_info", "afcodec_blosc_decode", "afcodec_blosc_decode_mt", "afcodec_blosc_decode_many",
            "afcodec_blosc_decode_files", "afcodec_decode_files", "afcodec_decode_ranges",
-           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode", "afcodec_blosc_lz4_plan")
+           "afcodec_blosc_bound", "afcodec_blosc_encode_lz4", "afcodec_zstd_decode", "afcodec_zstd_bound", "afcodec_zstd_encode", "afcodec_lz4_decode", "afcodec_blosc_lz4_plan", "afcodec_read_packed")
 
 
 def _err(lib, what):
@@ -182,6 +184,23 @@ def decode_ranges(kind: str, locators, outs, threads: int = 8, exact: bool = Tru
     if exact:
         _require_full(f"decode_ranges({kind})", locators, outs, res)
     return [int(res[i]) for i in range(n)]
+
+
+def read_packed(locators, dst: np.ndarray, align: int = 64, threads: int = 8):
+    """`afcodec_read_packed`: the byte ranges ``locators[i] = (path, offset, nbytes)`` (nbytes < 0: the whole file; None: an
+    absent chunk) read back to back into the uint8 array ``dst`` -> (offsets int64[n + 1], sizes int64[n], -100 = missing).
+    The files are neither stat'ed nor opened from Python."""
+    lib = load()
+    n = len(locators)
+    pp = (C.c_char_p * n)(*[os.fsencode(l[0]) if l is not None else b"" for l in locators])
+    offs = (C.c_int64 * n)(*[int(l[1]) if l is not None else 0 for l in locators])
+    lens = (C.c_int64 * n)(*[int(l[2]) if l is not None else -1 for l in locators])
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    res = np.zeros(n, dtype=np.int64)
+    if lib.afcodec_read_packed(n, pp, offs, lens, dst.ctypes.data, dst.nbytes, int(align), int(threads), out_off.ctypes.data, res.ctypes.data):
+        bad = [locators[i] for i in range(n) if res[i] < 0 and res[i] != -100]
+        raise CodecError(f"read_packed: {bad[:4]} failed: {lib.afcodec_last_error().decode()}")
+    return out_off, res
 
 
 def blosc_decode_files(paths, outs, threads: int = 8):

@@ -623,6 +623,78 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
     }
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
 }
+/* Byte ranges of files packed back to back into ONE buffer (the compressed chunk files of the decode-in-HBM route):
+ * range i lands at dst + out_off[i], out_off[i + 1] = out_off[i] + its size rounded up to `align`; results[i] = its size,
+ * -100 for a missing file (or an empty path), which takes no room.  The sizes are found here (fstat on the team) — the
+ * caller does not stat the files first — and the bytes are read in 1 MiB pieces spread over the team. */
+int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths, void* dst, int64_t cap,
+                        int64_t align, int nthreads, int64_t* out_off, int64_t* results) {
+    enum { PIECE = 1 << 20 };
+    if (n < 0 || !dst || !out_off || !results || align < 1) return fail(AFCODEC_E_SIZE, "read_packed: bad arguments");
+    if (nthreads < 1) nthreads = 1;
+    out_off[0] = 0;
+    if (n == 0) return AFCODEC_OK;
+    int* fds = (int*)malloc((size_t)n * sizeof(int));
+    int64_t* first = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+    int64_t* foff = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+    if (!fds || !first || !foff) { free(fds); free(first); free(foff); return fail(AFCODEC_E_SIZE, "out of memory"); }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+    for (int64_t i = 0; i < n; ++i) {
+        fds[i] = (paths[i] && paths[i][0]) ? open(paths[i], O_RDONLY) : -1;
+        foff[i] = 0;
+        if (fds[i] < 0) { results[i] = -100; continue; }
+        int64_t off = 0, sz = -1;
+        if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
+        struct stat stt;
+        if (fstat(fds[i], &stt) != 0 || off > (int64_t)stt.st_size || (sz >= 0 && off + sz > (int64_t)stt.st_size)) {
+            results[i] = AFCODEC_E_FORMAT;
+            close(fds[i]);
+            fds[i] = -1;
+            continue;
+        }
+        results[i] = sz < 0 ? (int64_t)stt.st_size - off : sz;
+        foff[i] = off;
+    }
+    int bad = 0;
+    first[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t sz = fds[i] >= 0 ? results[i] : 0;
+        if (results[i] < 0 && results[i] != -100) bad += 1;
+        out_off[i + 1] = out_off[i] + (sz + align - 1) / align * align;
+        first[i + 1] = first[i] + (sz + PIECE - 1) / PIECE;
+    }
+    int too_big = !bad && out_off[n] > cap;
+    if (!bad && !too_big) {
+        const int64_t npieces = first[n];
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (int64_t q = 0; q < npieces; ++q) {
+            int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
+            while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
+            while (first[lo + 1] <= q) ++lo;
+            const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
+            int64_t done = 0;
+            while (done < len) {
+                const ssize_t got = pread(fds[lo], (uint8_t*)dst + out_off[lo] + at + done, (size_t)(len - done), (off_t)(foff[lo] + at + done));
+                if (got <= 0) break;
+                done += got;
+            }
+            if (done != len) {
+#pragma omp atomic write
+                foff[lo] = -1;                                    /* marks the file as failed */
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        if (fds[i] >= 0) {
+            close(fds[i]);
+            if (foff[i] < 0) { results[i] = AFCODEC_E_FORMAT; bad += 1; }
+        }
+    }
+    free(fds); free(first); free(foff);
+    if (too_big) return fail(AFCODEC_E_SIZE, "read_packed: the files do not fit the buffer");
+    return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files could not be read (see results[])") : AFCODEC_OK;
+}
+
 int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* const* dsts, const int64_t* dstsizes,
                          int nthreads, int64_t* results) {
     return afcodec_decode_ranges(kind, n, paths, NULL, NULL, dsts, dstsizes, nthreads, results);

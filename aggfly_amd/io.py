@@ -260,11 +260,12 @@ class ZarrArray:
         self._shard_index_cache[path] = idx
         return idx
 
-    def chunk_locator(self, idx):
-        """(file, offset, nbytes) of chunk ``idx`` — nbytes -1 = the whole file — or None when it is absent."""
+    def chunk_locator(self, idx, probe: bool = True):
+        """(file, offset, nbytes) of chunk ``idx`` — nbytes -1 = the whole file — or None when it is absent.  ``probe=False``
+        leaves the question whether an unsharded chunk's file exists to the reader (one system call less per chunk)."""
         if self.shard_shape is None:
             fn = self.chunk_path(idx)
-            return (fn, 0, -1) if os.path.exists(fn) else None
+            return (fn, 0, -1) if not probe or os.path.exists(fn) else None
         per = [s_ // c_ for s_, c_ in zip(self.shard_shape, self.chunks)]
         fn = self.chunk_path(tuple(i // p_ for i, p_ in zip(idx, per)))
         tab = self._shard_index(fn)
@@ -751,24 +752,22 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
             uploaded[k].synchronize()                    # the page-locked slot is free once its upload is over
         trace.lap("wait")
         # ---- host: the chunk files as they are, packed back to back; then the record lists ----
-        locs = [za.chunk_locator(i) for i in batch]
-        sizes = np.array([-1 if l is None else (l[2] if l[2] >= 0 else os.path.getsize(l[0]) - l[1]) for l in locs], dtype=np.int64)
-        offs = np.concatenate([[0], np.cumsum((np.maximum(sizes, 0) + 63) // 64 * 64)])
         hall = host[k].numpy()
-        res = codec.decode_ranges("raw", locs, [hall[offs[i]:offs[i] + max(int(sizes[i]), 0)] for i in range(len(batch))], threads=threads)
+        offs, sizes = codec.read_packed([za.chunk_locator(i, probe=False) for i in batch], hall[:per * cmax], 64, threads)
+        res = sizes.tolist()
         trace.lap("read")
-        present = [i for i, r in enumerate(res) if r != -100]
+        present = np.nonzero(sizes != -100)[0]
         rec0 = int(offs[-1])
         streams = hall[rec0:rec0 + cap_streams * codec.LZ4_STREAM.itemsize].view(codec.LZ4_STREAM)
         bl0 = rec0 + streams.nbytes
         blocks = hall[bl0:bl0 + cap_blocks * codec.SHUFFLE_BLOCK.itemsize].view(codec.SHUFFLE_BLOCK)
         direct = job.whole_steps and all(job.inside(it) for it, _, _ in batch)
         out_offs = (np.array([batch[i][0] * job.tc - job.ka for i in present], dtype=np.int64) * job.step_bytes if direct
-                    else np.asarray(present, dtype=np.int64) * cb)
-        n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[present], sizes[present], out_offs,
+                    else present.astype(np.int64) * cb)
+        n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[:-1][present], sizes[present], out_offs,
                                                                     np.full(len(present), cb, dtype=np.int64), streams, blocks)
         if (pres != cb).any():
-            badc = [za.chunk_locator(batch[present[i]])[0] for i in np.nonzero(pres != cb)[0][:4]]
+            badc = [za.chunk_locator(batch[int(present[i])])[0] for i in np.nonzero(pres != cb)[0][:4]]
             raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
                                    "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
         assert tmp_bytes <= tmp_dev[k].numel()

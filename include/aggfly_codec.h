@@ -65,6 +65,12 @@ int afcodec_decode_files(int kind, int64_t n, const char* const* paths, void* co
 int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths,
                           void* const* dsts, const int64_t* dstsizes, int nthreads, int64_t* results);
 
+/* Byte ranges of files packed back to back into one buffer (what the decode-in-HBM route uploads): range i lands at
+ * dst + out_off[i] (out_off has n + 1 entries, steps rounded up to `align`); results[i] = its size, -100 = missing file.
+ * Sizes are taken from the files here; lengths[i] < 0 or offsets == NULL = the whole file. */
+int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths, void* dst, int64_t cap,
+                        int64_t align, int nthreads, int64_t* out_off, int64_t* results);
+
 /* numcodecs' LZ4 codec (Zarr v2 compressor id "lz4"): int32 decoded size + one raw LZ4 block. */
 int64_t afcodec_lz4_decode(const void* src, int64_t n, void* dst, int64_t cap);
 

@@ -354,3 +354,34 @@ def test_gpu_decode_plan_refuses_damage_and_batches():
         codec.blosc_lz4_plan(base, offs[:1], [len(chunks[0])], [0], [100], streams, blocks)          # destination too small
     with pytest.raises(codec.CodecError):
         codec.blosc_lz4_plan(base, offs[:1], [len(chunks[0])], [0], nb[:1], streams[:2], blocks)     # record list too small
+
+
+def test_read_packed_packs_ranges_of_files_back_to_back(tmp_path):
+    """`afcodec_read_packed` (the decode-in-HBM route's reader): whole files and byte ranges land back to back at 64-byte steps,
+    missing files and absent chunks take no room and report -100, sizes come from the files; a buffer that is too small and a
+    range beyond its file are errors."""
+    rng = np.random.default_rng(3)
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in (1, 63, 64, 3_000_001, 0, 200_000)]
+    paths = []
+    for i, b in enumerate(blobs):
+        paths.append(str(tmp_path / f"c{i}"))
+        b.tofile(paths[-1])
+    locs = [(paths[0], 0, -1), (str(tmp_path / "absent"), 0, -1), (paths[1], 0, -1), None, (paths[2], 0, -1), (paths[3], 0, -1),
+            (paths[3], 1_000_000, 1_500_000), (paths[4], 0, -1), (paths[5], 7, 199_000)]
+    dst = np.full(6_000_000, 0xEE, dtype=np.uint8)
+    offs, sizes = codec.read_packed(locs, dst, 64, threads=5)
+    want = [blobs[0], None, blobs[1], None, blobs[2], blobs[3], blobs[3][1_000_000:2_500_000], blobs[4], blobs[5][7:199_007]]
+    assert sizes.tolist() == [-100 if w is None else len(w) for w in want]
+    assert offs[0] == 0 and (offs % 64 == 0).all() and len(offs) == len(locs) + 1
+    for i, w in enumerate(want):
+        room = 0 if w is None else (len(w) + 63) // 64 * 64
+        assert offs[i + 1] - offs[i] == room
+        if w is not None:
+            assert np.array_equal(dst[offs[i]:offs[i] + len(w)], w)
+    assert (dst[offs[-1]:] == 0xEE).all()
+    with pytest.raises(codec.CodecError, match="do not fit"):
+        codec.read_packed(locs, dst[:3_000_000], 64, threads=2)
+    with pytest.raises(codec.CodecError):
+        codec.read_packed([(paths[0], 0, 2)], dst, 64)
+    o, z = codec.read_packed([], dst, 64)
+    assert o.tolist() == [0] and len(z) == 0

@@ -137,11 +137,12 @@ def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkey
     path = _store(tmp_path, "s.zarr", cube, chunks)
     from aggfly_amd import io as afio
     kinds = []
-    real = codec.decode_ranges
+    real, real_packed = codec.decode_ranges, codec.read_packed
     monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
+    monkeypatch.setattr(codec, "read_packed", lambda locs, dst, align=64, threads=8: kinds.append("files as they are") or real_packed(locs, dst, align, threads))
     monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")                 # (these stores are below the size the route starts at)
     dev = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
-    assert set(kinds) == {"raw"}, kinds                              # files read as they are; no host decode
+    assert set(kinds) == {"files as they are"}, kinds                # no host decode
     np.testing.assert_array_equal(dev.cube().cpu().numpy(), cube)
     win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-05", "2001-01-11"))
     np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[24 * 4:24 * 11])
@@ -177,10 +178,11 @@ def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypat
     assert cube.nbytes >= afio.GPU_DECODE_AUTO_BYTES
     path = _store(tmp_path, "big.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
     kinds = []
-    real = codec.decode_ranges
+    real, real_packed = codec.decode_ranges, codec.read_packed
     monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
+    monkeypatch.setattr(codec, "read_packed", lambda locs, dst, align=64, threads=8: kinds.append("files as they are") or real_packed(locs, dst, align, threads))
     dev = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
-    assert set(kinds) == {"raw"} and len(kinds) >= 5, kinds
+    assert set(kinds) == {"files as they are"} and len(kinds) >= 5, kinds
     got = dev.cube().cpu().numpy()
     np.testing.assert_array_equal(got, cube)
     small = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-01-09"))
