@@ -28,7 +28,10 @@ for name, arr in fields.items():
     ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": pd.date_range("2001-01-01", periods=T, freq="h"),
                                                                            "latitude": np.arange(ny) * 0.25, "longitude": np.arange(nx) * 0.25}), lon_is_360=False)
     with tempfile.TemporaryDirectory(dir=base) as d:
-        for lname, chunks in (("rows 24 x grid", {"time": 24, "latitude": ny, "longitude": nx}), ("tiled 744x52x118", {"time": 744, "latitude": 52, "longitude": 118})):
+        layouts = [("rows 24 x grid", {"time": 24, "latitude": ny, "longitude": nx}), ("tiled 744x52x118", {"time": 744, "latitude": 52, "longitude": 118})]
+        if os.environ.get("CONVERTER_LAYOUT") == "1":      # what the reference's own converter writes: the whole series x 87 x 87 tiles (265 MB chunks a year)
+            layouts = [("whole series x 87x87 tiles", {"time": T, "latitude": 87, "longitude": 87})]
+        for lname, chunks in layouts:
             store = os.path.join(d, "s.zarr")
             af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks, compress="blosc")
             size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(store) for f in fs)
