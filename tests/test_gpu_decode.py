@@ -188,3 +188,24 @@ def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypat
     small = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-01-09"))
     assert kinds[-1] == "blosc"                                      # a 16 MB window: host threads
     np.testing.assert_array_equal(small.cube().cpu().numpy(), cube[48:216])
+
+
+@pytest.mark.parametrize("shards", [None, {"time": 96, "latitude": 24, "longitude": 64}])
+def test_format3_stores_and_shards_decode_in_hbm(torch_cuda, tmp_path, monkeypatch, shards):
+    """Zarr format 3 (``zarr.json``, ``c/`` keys), with and without ``sharding_indexed`` shards: the inner chunks of a shard are
+    byte ranges of the shard file — the packed reader takes them as such — and absent chunks stay the fill value."""
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")
+    T, ny, nx = 24 * 12, 24, 64
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=9, scattered_nan=25) + np.float32(273.15)
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": pd.date_range("2001-01-01", periods=T, freq="h"),
+                                                                            "latitude": 30 + 0.25 * np.arange(ny), "longitude": 250 + 0.25 * np.arange(nx)}), lon_is_360=True)
+    path = str(tmp_path / "v3.zarr")
+    af.dataset_to_zarr(ds, path, var="t2m", chunks={"time": 48, "latitude": 12, "longitude": 32}, shards=shards, zarr_format=3)
+    kinds = []
+    real_packed = codec.read_packed
+    monkeypatch.setattr(codec, "read_packed", lambda locs, dst, align=64, threads=8: kinds.append(len(locs)) or real_packed(locs, dst, align, threads))
+    got = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
+    assert kinds and sum(kinds) == (T // 48) * 2 * 2
+    np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)
+    win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03 05:00", "2001-01-09 11:00"))
+    np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[53:204])
