@@ -546,7 +546,8 @@ def _gpu_decodable(za, request_bytes: int = 0) -> bool:
             if len(h) == 16 and h[0] == 2:
                 flags, ts = h[2], h[3]
                 nbytes, blocksize = int.from_bytes(h[4:8], "little"), int.from_bytes(h[8:12], "little")
-                ok = bool(flags & 0x02) or (((flags >> 5) & 7) == 1 and not (flags & 0x04) and blocksize > 0 and nbytes == za.chunk_nbytes)
+                ok = bool(flags & 0x02) or (((flags >> 5) & 7) == 1 and not (flags & 0x04) and blocksize > 0 and nbytes == za.chunk_nbytes
+                                            and -(-nbytes // blocksize) <= 65535)      # (one launch unshuffles at most 65,535 blocks)
                 za._blosc_geometry = (max(blocksize, 1), max(ts, 1))
             break
     except OSError:
