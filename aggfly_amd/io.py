@@ -628,6 +628,10 @@ class _IngestTrace:
     def skip(self):
         self._mark = self.clock()
 
+    def drained(self):
+        """The wait for the GPU at the end of a read (since the last `skip`)."""
+        self.phase["drain"] = self.clock() - self._mark
+
     def report(self, origin_event, **head):
         if not self.on:
             return
@@ -693,7 +697,7 @@ def _scatter_host_decode(job: _ScatterJob, threads: int, slab_bytes: int, post):
             post(job.cube)
     trace.skip()
     copy_stream.synchronize()
-    trace.phase["drain"] = trace.clock() - trace._mark
+    trace.drained()
     trace.report(None, gpu_decode=False, batches=-(-len(idxs) // per), chunks_per_batch=per)
     torch.cuda.current_stream(device).wait_stream(copy_stream)
     return job.cube
@@ -815,7 +819,7 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     trace.skip()
     last.synchronize()
     copy_stream.synchronize()
-    trace.phase["drain"] = trace.clock() - trace._mark
+    trace.drained()
     trace.report(origin, gpu_decode=True, batches=len(cuts) - 1, chunks_per_batch=per)
     if int(errors.item()):
         raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
