@@ -35,7 +35,8 @@ The JSON line also carries
                  PMC-measured HBM bytes per launch from profiles/traffic.json with its provenance;
   cpu_baseline   the plain-C port of the reference's numba engine (oracle/c) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N = 1);
-  other_configs  (N = 1) the other four BASELINE configs, a few steps each, kernel time and roofline.
+  other_configs  (N = 1) the other four BASELINE configs, a few steps each, kernel time and roofline;
+  ingest         (N = 1) the configs[0] store read from RAM into HBM, chunks decoded in HBM / on the host threads.
 """
 import argparse
 import hashlib
@@ -209,6 +210,56 @@ def _valu_counts():
         return {}
 
 
+def run_ingest(torch):
+    """SURVEY §8f N2 beside the kernels: the BASELINE configs[0] store (one year of hourly f32 on 104 x 236 cells, Blosc-LZ4 +
+    shuffle, 24-step chunks, written to RAM) read into HBM through `dataset_from_path`, with the chunks decoded in HBM and on
+    the host threads — decoded GB/s, best of 3 after a warm read.  The product path only (no oracle)."""
+    import shutil, tempfile
+    import pandas as pd
+    import aggfly_amd as af
+    from aggfly_amd import synth
+    T, ny, nx = 8760, 104, 236
+    k = np.arange(T, dtype=np.float32)[:, None, None]
+    yy, xx = np.arange(ny, dtype=np.float32)[None, :, None], np.arange(nx, dtype=np.float32)[None, None, :]
+    fields = {      # how well a field compresses decides how many bytes cross PCIe: the noisy bench field and one quantised like reanalysis output
+        "bench field (N(0, 3) noise in the mantissa)": lambda: synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=1) + np.float32(273.15),
+        "smooth field in 0.01 K steps": lambda: (np.round((285 + 12 * np.sin(2 * np.pi * k / 8760) + 5 * np.sin(2 * np.pi * (k % 24) / 24)
+                                                            + 8 * np.sin(yy / 17) * np.cos(xx / 23)) * 100) / 100).astype(np.float32)}
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"workload": "BASELINE configs[0] store -> HBM: T=8760 hourly f32, 104x236 cells, Zarr v2, Blosc-LZ4 + shuffle, 365 chunks of 24 steps, store in RAM",
+           "unit": "GB/s decoded", "fields": {}}
+    saved = os.environ.get("AGGFLY_HIP_GPU_DECODE")
+    try:
+        for name, make in fields.items():
+            arr = make()
+            ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": pd.date_range("2001-01-01", periods=T, freq="h"),
+                                                                                   "latitude": 25 + 0.25 * np.arange(ny), "longitude": 235 + 0.25 * np.arange(nx)}),
+                            lon_is_360=True)
+            store = os.path.join(d, "c0.zarr")
+            af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 24, "latitude": ny, "longitude": nx}, compress="blosc")
+            size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(store) for f in fs)
+            ent = {"decoded_bytes": int(arr.nbytes), "store_bytes": size, "blosc_ratio": arr.nbytes / size}
+            for key, mode in (("chunks_decoded_in_hbm", "1"), ("chunks_decoded_on_host_threads", "0")):
+                os.environ["AGGFLY_HIP_GPU_DECODE"] = mode
+                fn = lambda: af.dataset_from_path(store, "t2m", lon_is_360=True, device="cuda")
+                got = fn(); torch.cuda.synchronize()
+                ok = bool(np.array_equal(got.cube()[:2].cpu().numpy(), arr[:2]) and np.array_equal(got.cube()[-2:].cpu().numpy(), arr[-2:]))
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter(); got = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+                ent[key] = {"GBps": arr.nbytes / 1e9 / best, "ms": best * 1e3, "first_and_last_steps_equal_the_source": ok}
+                del got
+            out["fields"][name] = ent
+            shutil.rmtree(store, ignore_errors=True)
+    finally:
+        if saved is None:
+            os.environ.pop("AGGFLY_HIP_GPU_DECODE", None)
+        else:
+            os.environ["AGGFLY_HIP_GPU_DECODE"] = saved
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def run_other_configs(torch, steps=5, warmup=2):
     from aggfly_amd import hip, synth
     out = []
@@ -298,6 +349,7 @@ def main():
                     help="N > 1: time = one year per GPU + all-gather (weak scaling); cells = latitude bands of one year + all-reduce (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the store -> HBM figure (N = 1, after other_configs)")
     args = ap.parse_args()
 
     import torch
@@ -504,6 +556,11 @@ def main():
             del cube
             torch.cuda.empty_cache()
             line["other_configs"] = run_other_configs(torch)
+            if not args.no_ingest:
+                try:
+                    line["ingest"] = run_ingest(torch)
+                except Exception as e:      # the ingest figure must never take the headline down with it
+                    line["ingest"] = {"failed": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
