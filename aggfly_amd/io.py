@@ -742,9 +742,13 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     errors = torch.zeros(1, dtype=torch.int32, device=device)
     copy_stream = torch.cuda.Stream(device=device)
     copy_stream.wait_stream(torch.cuda.current_stream(device))    # (as on the host route: order behind the allocator's stream)
-    work_streams = [torch.cuda.Stream(device=device) for _ in range(nstage)]
-    for ws in work_streams:
+    # two kernel streams whatever the number of slots: HIP maps streams onto a few hardware queues (4 by default), and an upload
+    # that shares its queue with a kernel stream waits for that stream's kernels — seen as uploads starting exactly when the
+    # previous batch's kernels ended (profiles/r02_ingest_timeline_queues.txt)
+    two = [torch.cuda.Stream(device=device) for _ in range(min(2, nstage))]
+    for ws in two:
         ws.wait_stream(torch.cuda.current_stream(device))
+    work_streams = [two[k % len(two)] for k in range(nstage)]
     done, uploaded = [None] * nstage, [None] * nstage
     trace = _IngestTrace()
     origin = torch.cuda.Event(enable_timing=True)
@@ -810,8 +814,8 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
             if trace.on:
                 trace.batches[-1]["k1"].record(work_streams[k])
         trace.lap("enqueue")
-    last = work_streams[0]
-    for ws in work_streams[1:]:
+    last = two[0]
+    for ws in two[1:]:
         last.wait_stream(ws)
     with torch.cuda.stream(last):
         if post is not None:
