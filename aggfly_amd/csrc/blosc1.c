@@ -32,6 +32,14 @@
 #include <sys/types.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <emmintrin.h>
+
+/* AFCODEC_NT_COPY=0 switches the non-temporal stores of the reader and of the byte unshuffle off (A/B knob) */
+static int nt_store_default(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("AFCODEC_NT_COPY"); v = e ? atoi(e) != 0 : 1; }
+    return v;
+}
 
 #define AFCODEC_OK 0
 #define AFCODEC_E_FORMAT (-1)
@@ -150,14 +158,49 @@ static int blosclz_decode(const uint8_t* ip, int length, uint8_t* out, int maxou
 }
 
 /* ---- shuffle filters, per block ---- */
+/* 4- and 8-byte elements: 16 elements a step with SSE2 byte / word / dword interleaves (every x86-64 CPU has them).  The planes
+ * come out of a cache-resident scratch block and the elements go to a destination nobody reads back soon (page-locked staging
+ * the GPU fetches by DMA): with a 16-byte-aligned destination the stores are non-temporal, so the destination lines are not
+ * read first. */
 static void unshuffle_bytes(int ts, int64_t bsize, const uint8_t* src, uint8_t* dst) {
     const int64_t n = bsize / ts, rem = bsize % ts;
     if (ts == 4) {
         const uint8_t *s0 = src, *s1 = src + n, *s2 = src + 2 * n, *s3 = src + 3 * n;
-        for (int64_t i = 0; i < n; ++i) { dst[4 * i] = s0[i]; dst[4 * i + 1] = s1[i]; dst[4 * i + 2] = s2[i]; dst[4 * i + 3] = s3[i]; }
+        const int nt = (((uintptr_t)dst) & 15) == 0 && nt_store_default();
+        int64_t i = 0;
+        for (; i + 16 <= n; i += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i*)(s0 + i)), b = _mm_loadu_si128((const __m128i*)(s1 + i));
+            const __m128i c = _mm_loadu_si128((const __m128i*)(s2 + i)), d = _mm_loadu_si128((const __m128i*)(s3 + i));
+            const __m128i ab0 = _mm_unpacklo_epi8(a, b), ab1 = _mm_unpackhi_epi8(a, b), cd0 = _mm_unpacklo_epi8(c, d), cd1 = _mm_unpackhi_epi8(c, d);
+            const __m128i o0 = _mm_unpacklo_epi16(ab0, cd0), o1 = _mm_unpackhi_epi16(ab0, cd0), o2 = _mm_unpacklo_epi16(ab1, cd1), o3 = _mm_unpackhi_epi16(ab1, cd1);
+            __m128i* out = (__m128i*)(dst + 4 * i);
+            if (nt) { _mm_stream_si128(out, o0); _mm_stream_si128(out + 1, o1); _mm_stream_si128(out + 2, o2); _mm_stream_si128(out + 3, o3); }
+            else { _mm_storeu_si128(out, o0); _mm_storeu_si128(out + 1, o1); _mm_storeu_si128(out + 2, o2); _mm_storeu_si128(out + 3, o3); }
+        }
+        for (; i < n; ++i) { dst[4 * i] = s0[i]; dst[4 * i + 1] = s1[i]; dst[4 * i + 2] = s2[i]; dst[4 * i + 3] = s3[i]; }
+        if (nt) _mm_sfence();
     } else if (ts == 8) {
-        for (int64_t i = 0; i < n; ++i)
+        const int nt = (((uintptr_t)dst) & 15) == 0 && nt_store_default();
+        int64_t i = 0;
+        for (; i + 16 <= n; i += 16) {
+            __m128i p[8], t[8], u[8];
+            for (int j = 0; j < 8; ++j) p[j] = _mm_loadu_si128((const __m128i*)(src + (int64_t)j * n + i));
+            for (int j = 0; j < 4; ++j) { t[2 * j] = _mm_unpacklo_epi8(p[2 * j], p[2 * j + 1]); t[2 * j + 1] = _mm_unpackhi_epi8(p[2 * j], p[2 * j + 1]); }
+            /* t[0], t[1]: bytes 0-1 of elements 0-7 / 8-15;  t[2], t[3]: bytes 2-3;  t[4], t[5]: bytes 4-5;  t[6], t[7]: bytes 6-7 */
+            u[0] = _mm_unpacklo_epi16(t[0], t[2]); u[1] = _mm_unpackhi_epi16(t[0], t[2]);      /* bytes 0-3 of elements 0-3 / 4-7 */
+            u[2] = _mm_unpacklo_epi16(t[1], t[3]); u[3] = _mm_unpackhi_epi16(t[1], t[3]);      /*              elements 8-11 / 12-15 */
+            u[4] = _mm_unpacklo_epi16(t[4], t[6]); u[5] = _mm_unpackhi_epi16(t[4], t[6]);      /* bytes 4-7 */
+            u[6] = _mm_unpacklo_epi16(t[5], t[7]); u[7] = _mm_unpackhi_epi16(t[5], t[7]);
+            __m128i* out = (__m128i*)(dst + 8 * i);
+            for (int q = 0; q < 4; ++q) {
+                const __m128i lo = _mm_unpacklo_epi32(u[q], u[q + 4]), hi = _mm_unpackhi_epi32(u[q], u[q + 4]);   /* elements 4q, 4q+1 / 4q+2, 4q+3 */
+                if (nt) { _mm_stream_si128(out + 2 * q, lo); _mm_stream_si128(out + 2 * q + 1, hi); }
+                else { _mm_storeu_si128(out + 2 * q, lo); _mm_storeu_si128(out + 2 * q + 1, hi); }
+            }
+        }
+        for (; i < n; ++i)
             for (int j = 0; j < 8; ++j) dst[8 * i + j] = src[(int64_t)j * n + i];
+        if (nt) _mm_sfence();
     } else {
         for (int64_t i = 0; i < n; ++i)
             for (int j = 0; j < ts; ++j) dst[i * ts + j] = src[(int64_t)j * n + i];
@@ -494,6 +537,50 @@ static int64_t decode_kind_plain(int kind, const uint8_t* buf, int64_t sz, void*
     }
 }
 
+/* dst <- src with non-temporal 16-byte stores (SSE2: every x86-64 CPU); head and tail up to alignment by memcpy */
+static void nt_memcpy(uint8_t* dst, const uint8_t* src, size_t n) {
+    size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+    if (head > n) head = n;
+    memcpy(dst, src, head);
+    dst += head; src += head; n -= head;
+    const size_t body = n & ~(size_t)63;
+    for (size_t i = 0; i < body; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+        _mm_stream_si128((__m128i*)(dst + i), a); _mm_stream_si128((__m128i*)(dst + i + 16), b);
+        _mm_stream_si128((__m128i*)(dst + i + 32), c); _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    memcpy(dst + body, src + body, n - body);
+    _mm_sfence();
+}
+
+/* len bytes of fd at file offset off -> dst; -> bytes read.  nt: through a cache-resident bounce buffer, then non-temporal
+ * stores — the destination lines are not read first (a third less DRAM traffic than the kernel's copy into the destination),
+ * which leaves an upload reading the same page-locked memory more of the host's bandwidth: store -> HBM 59 -> 67 GB/s on a
+ * 3.4 GB store, 43 -> 47 on 0.86 GB (profiles/r02_nt_copy_ab.txt).  AFCODEC_NT_COPY=0: the kernel copies straight into dst. */
+enum { BOUNCE = 128 << 10 };
+static int nt_copy_default(void) { return nt_store_default(); }
+static int64_t read_piece(int fd, uint8_t* dst, int64_t len, int64_t off, int nt) {
+    int64_t done = 0;
+    if (nt) {
+        static __thread uint8_t bounce[BOUNCE] __attribute__((aligned(64)));
+        while (done < len) {
+            const int64_t want = len - done < BOUNCE ? len - done : BOUNCE;
+            const ssize_t got = pread(fd, bounce, (size_t)want, (off_t)(off + done));
+            if (got <= 0) break;
+            nt_memcpy(dst + done, bounce, (size_t)got);
+            done += got;
+        }
+    } else {
+        while (done < len) {
+            const ssize_t got = pread(fd, dst + done, (size_t)(len - done), (off_t)(off + done));
+            if (got <= 0) break;
+            done += got;
+        }
+    }
+    return done;
+}
+
 /* Reads and decodes byte ranges of chunk files -> dsts[i] on an OpenMP team (no Python between chunks):
  * [offsets[i], offsets[i] + lengths[i]) of paths[i]; lengths[i] < 0 (or offsets == NULL) = the whole file.
  * Ranges serve the inner chunks of Zarr v3 shards.  A missing file leaves results[i] = -100 (the caller
@@ -535,12 +622,7 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
             while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
             while (first[lo + 1] <= q) ++lo;                      /* (files without pieces share a boundary) */
             const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            int64_t done = 0;
-            while (done < len) {
-                const ssize_t got = pread(fds[lo], (uint8_t*)dsts[lo] + at + done, (size_t)(len - done), (off_t)(offs[lo] + at + done));
-                if (got <= 0) break;
-                done += got;
-            }
+            const int64_t done = read_piece(fds[lo], (uint8_t*)dsts[lo] + at, len, offs[lo] + at, nt_copy_default());
             if (done != len) {
 #pragma omp atomic write
                 offs[lo] = -1;                                    /* marks the file as failed */
@@ -623,33 +705,14 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
     }
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunks failed to decode (see results[])") : AFCODEC_OK;
 }
-/* dst <- src with non-temporal 16-byte stores (SSE2: every x86-64 CPU); head and tail up to alignment by memcpy */
-#include <emmintrin.h>
-static void nt_memcpy(uint8_t* dst, const uint8_t* src, size_t n) {
-    size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
-    if (head > n) head = n;
-    memcpy(dst, src, head);
-    dst += head; src += head; n -= head;
-    const size_t body = n & ~(size_t)63;
-    for (size_t i = 0; i < body; i += 64) {
-        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
-        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
-        _mm_stream_si128((__m128i*)(dst + i), a); _mm_stream_si128((__m128i*)(dst + i + 16), b);
-        _mm_stream_si128((__m128i*)(dst + i + 32), c); _mm_stream_si128((__m128i*)(dst + i + 48), d);
-    }
-    memcpy(dst + body, src + body, n - body);
-    _mm_sfence();
-}
-
 /* Byte ranges of files packed back to back into ONE buffer (the compressed chunk files of the decode-in-HBM route):
  * range i lands at dst + out_off[i], out_off[i + 1] = out_off[i] + its size rounded up to `align`; results[i] = its size,
  * -100 for a missing file (or an empty path), which takes no room.  The sizes are found here (fstat on the team) — the
  * caller does not stat the files first — and the bytes are read in 1 MiB pieces spread over the team. */
 int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offsets, const int64_t* lengths, void* dst, int64_t cap,
                         int64_t align, int nthreads, int64_t* out_off, int64_t* results) {
-    enum { PIECE = 1 << 20, BOUNCE = 128 << 10 };
-    const char* nte = getenv("AFCODEC_NT_COPY");              /* =0: the kernel copies straight into dst (A/B knob) */
-    const int nt_copy = nte ? atoi(nte) != 0 : 1;
+    enum { PIECE = 1 << 20 };
+    const int nt_copy = nt_copy_default();
     if (n < 0 || !dst || !out_off || !results || align < 1) return fail(AFCODEC_E_SIZE, "read_packed: bad arguments");
     if (nthreads < 1) nthreads = 1;
     out_off[0] = 0;
@@ -692,28 +755,7 @@ int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offs
             while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
             while (first[lo + 1] <= q) ++lo;
             const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            int64_t done = 0;
-            if (nt_copy) {
-                /* through a cache-resident bounce buffer, then non-temporal stores: the destination lines are not read first
-                 * (a third less DRAM traffic than the kernel's copy into the destination), which leaves the upload that
-                 * reads the same page-locked memory more of the host's bandwidth: store -> HBM 59 -> 67 GB/s on a 3.4 GB
-                 * store, 43 -> 47 on 0.86 GB (profiles/r02_nt_copy_ab.txt) */
-                static __thread uint8_t bounce[BOUNCE] __attribute__((aligned(64)));
-                uint8_t* const out = (uint8_t*)dst + out_off[lo] + at;
-                while (done < len) {
-                    const int64_t want = len - done < BOUNCE ? len - done : BOUNCE;
-                    const ssize_t got = pread(fds[lo], bounce, (size_t)want, (off_t)(foff[lo] + at + done));
-                    if (got <= 0) break;
-                    nt_memcpy(out + done, bounce, (size_t)got);
-                    done += got;
-                }
-            } else {
-                while (done < len) {
-                    const ssize_t got = pread(fds[lo], (uint8_t*)dst + out_off[lo] + at + done, (size_t)(len - done), (off_t)(foff[lo] + at + done));
-                    if (got <= 0) break;
-                    done += got;
-                }
-            }
+            const int64_t done = read_piece(fds[lo], (uint8_t*)dst + out_off[lo] + at, len, foff[lo] + at, nt_copy);
             if (done != len) {
 #pragma omp atomic write
                 foff[lo] = -1;                                    /* marks the file as failed */

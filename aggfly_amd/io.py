@@ -526,7 +526,7 @@ def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
     from the first chunk file's header.  ``AGGFLY_HIP_GPU_DECODE``: ``1`` always, ``0`` never, unset / ``auto``: for requests
     of `GPU_DECODE_AUTO_BYTES` decoded bytes or more.  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
-    DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 48-90 GB/s this way against 28-43 GB/s with the decode on
+    DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 48-85 GB/s this way against 32-53 GB/s with the decode on
     16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
     mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")
     if mode == "0" or za.native_kind != "blosc" or (mode != "1" and request_bytes < GPU_DECODE_AUTO_BYTES):
