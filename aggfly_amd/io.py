@@ -519,17 +519,23 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
             pool.shutdown()
 
 
-GPU_DECODE_AUTO_BYTES = 256 << 20
+GPU_DECODE_AUTO_BYTES = 256 << 20                 # requests this large take the decode-in-HBM route ...
+GPU_DECODE_AUTO_BYTES_WHOLE_ROWS = 768 << 20      # ... or this large when every chunk holds whole time steps of the grid
 
 
 def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
     from the first chunk file's header.  ``AGGFLY_HIP_GPU_DECODE``: ``1`` always, ``0`` never, unset / ``auto``: for requests
-    of `GPU_DECODE_AUTO_BYTES` decoded bytes or more.  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
+    of `GPU_DECODE_AUTO_BYTES` decoded bytes or more — `GPU_DECODE_AUTO_BYTES_WHOLE_ROWS` for stores whose chunks hold whole time
+    steps of the grid: the host route is at its best on those (each chunk decodes straight into its rows of the slab; 40-53
+    GB/s), and the route's fixed ~6 ms (first read, last batch's kernels) only pay off on larger requests; on other chunk
+    grids it is ahead from 0.26 GB on (`profiles/r02_gpu_decode_small_requests.txt`).  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
     DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 48-85 GB/s this way against 32-53 GB/s with the decode on
     16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
     mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")
-    if mode == "0" or za.native_kind != "blosc" or (mode != "1" and request_bytes < GPU_DECODE_AUTO_BYTES):
+    whole_rows = len(za.shape) == 3 and tuple(za.chunks[1:]) == tuple(za.shape[1:])
+    if mode == "0" or za.native_kind != "blosc" or (mode != "1" and request_bytes < (GPU_DECODE_AUTO_BYTES_WHOLE_ROWS if whole_rows
+                                                                                      else GPU_DECODE_AUTO_BYTES)):
         return False
     hit = getattr(za, "_gpu_decodable", None)
     if hit is not None:

@@ -10,7 +10,7 @@ import aggfly_amd as af
 from aggfly_amd import synth
 
 YEARS = int(os.environ.get("YEARS", "1"))            # YEARS=4: a 3.4 GB store, enough batches for the pipeline's steady state
-T, ny, nx = 8760 * YEARS, 104, 236
+T, ny, nx = int(os.environ.get("HOURS", 8760 * YEARS)), 104, 236      # HOURS=3500: a 0.34 GB store (where the route starts by default)
 k = np.arange(T)[:, None, None]; y = np.arange(ny)[None, :, None]; x = np.arange(nx)[None, None, :]
 smooth = 285 + 12 * np.sin(2 * np.pi * k / 8760.0) + 5 * np.sin(2 * np.pi * (k % 24) / 24) + 8 * np.sin(y / 17.0) * np.cos(x / 23.0)
 rng = np.random.default_rng(1)
@@ -50,4 +50,4 @@ for name, arr in fields.items():
             import shutil; shutil.rmtree(store)
 os.makedirs("gpurun_out/r02", exist_ok=True)
 if not only:
-    json.dump(out, open(f"gpurun_out/r02/gpu_decode_by_ratio{'' if YEARS == 1 else '_%dyr' % YEARS}.json", "w"), indent=1)
+    json.dump(out, open(f"gpurun_out/r02/gpu_decode_by_ratio{'' if YEARS == 1 else '_%dyr' % YEARS}{'_%dh' % T if 'HOURS' in os.environ else ''}.json", "w"), indent=1)

@@ -168,15 +168,16 @@ def test_float64_stores_decode_in_hbm(torch_cuda, tmp_path, monkeypatch):
 
 
 def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypatch):
-    """No environment switch: a 306 MB request (>= `io.GPU_DECODE_AUTO_BYTES`) reads its chunk files as they are and decodes them
-    on the GPU — several batches in flight, whole-step chunks straight into the cube — and gives the host route's cube."""
+    """No environment switch: a 306 MB request on a space-tiled store (>= `io.GPU_DECODE_AUTO_BYTES`) reads its chunk files as they
+    are and decodes them on the GPU — several batches in flight — and gives the source cube; the same cube in chunks of whole
+    time steps stays on the host threads up to `io.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS`; small windows do in either layout."""
     from aggfly_amd import io as afio
     monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE", raising=False)
     monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "64")
     T, ny, nx = 24 * 130, 104, 236
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=11) + np.float32(273.15)
-    assert cube.nbytes >= afio.GPU_DECODE_AUTO_BYTES
-    path = _store(tmp_path, "big.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
+    assert afio.GPU_DECODE_AUTO_BYTES <= cube.nbytes < afio.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS
+    path = _store(tmp_path, "big.zarr", cube, {"time": 240, "latitude": 52, "longitude": 118})
     kinds = []
     real, real_packed = codec.decode_ranges, codec.read_packed
     monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
@@ -186,8 +187,13 @@ def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypat
     got = dev.cube().cpu().numpy()
     np.testing.assert_array_equal(got, cube)
     small = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-01-09"))
-    assert kinds[-1] == "blosc"                                      # a 16 MB window: host threads
+    assert kinds[-1] == "blosc"                                      # a window of one row of chunks (24 MB): host threads
     np.testing.assert_array_equal(small.cube().cpu().numpy(), cube[48:216])
+    rows = _store(tmp_path, "rows.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
+    kinds.clear()
+    got = af.dataset_from_path(rows, "t2m", lon_is_360=True, device="cuda")
+    assert set(kinds) == {"blosc"}, kinds
+    np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)
 
 
 @pytest.mark.parametrize("shards", [None, {"time": 96, "latitude": 24, "longitude": 64}])
