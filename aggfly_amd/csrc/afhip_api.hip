@@ -657,6 +657,10 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         // two cells per lane, unless the plan carries many accumulators (register pressure):
         // one cell per lane measured 1.6x faster on the 13-bin plan (profiles/r01_kbench_c4_f32.json)
         if (C_ % 2 == 0 && pl->nthr < 4 && pl->K < 8) want_vec = 2;
+        // ... and unless it is a light one (one or two mean / sum columns, no threshold slots): one cell per lane then keeps
+        // more waves resident and measured 6.6 % faster on configs[0] at 215x1440 (6,534 -> 6,966 GB/s), level on the 104x236
+        // window (profiles/r02_kbench_light_f32_plans.txt)
+        if (pl->stat <= 1 && pl->nthr == 0 && pl->K <= 2) want_vec = 1;
     }
     // short inner groups: the direct path keeps DEPTH rows in flight only INSIDE a group, the LDS-DMA ring
     // prefetches across group ends.  Measured (mean plan, 721x1440 / 1801x3600): 2-step groups f64 4.5 vs
