@@ -652,7 +652,8 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     const int64_t C_ = desc->n_cells;
     int want_pipe = 0, want_vec = 1;
     if (desc->dtype == AFHIP_F64) {
-        if (C_ % 2 == 0 && C_ < 131072) { want_pipe = 1; want_vec = 2; }     // small grid: LDS-DMA ring
+        // one cell per lane, direct loads — on small grids too: round 1 had the LDS-DMA ring ahead there (6.1 vs 5.4 TB/s on
+        // 104x236), the re-sweep on round 2's kernel has it behind (5.99 vs 6.67 TB/s; profiles/r02_kbench_resweep.txt)
     } else {
         // two cells per lane, unless the plan carries many accumulators (register pressure):
         // one cell per lane measured 1.6x faster on the 13-bin plan (profiles/r01_kbench_c4_f32.json)
