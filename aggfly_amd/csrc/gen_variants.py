@@ -43,7 +43,7 @@ def menu(kind):
         for (stat, nthr, kmax) in shapes_all:
             # production menu, chosen by measurement on MI355X (profiles/r01_sweep_load_arms.txt):
             #   f64: direct 8-byte nt loads, one cell per lane, 4 rows in flight (6.5 TB/s on
-            #        configs[1]); small grids: LDS-DMA ring, 2 cells per lane (6.1 TB/s)
+            #        configs[1]); the LDS-DMA ring with 2 cells per lane is kept for short inner groups (and as an arm)
             #   f32: direct 8-byte nt loads, two cells per lane, 8 rows in flight; odd row
             #        lengths fall back to one cell per lane
             if dtype == 1:
