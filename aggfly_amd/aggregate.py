@@ -403,8 +403,8 @@ class SpatialAggregator:
         self.zero_weight = getattr(weights, "zero_weight", "area")
 
     def compute(self, npartitions: int = None) -> pd.DataFrame:
-        csr, region_ids = eng.get_csr(self.weights_obj, self.dataset[0])
         x, labels = _aligned_cells(self.dataset)                      # [K, n_cells, P] float64 in HBM, P = union of the labels
+        csr, region_ids = eng.get_csr(self.weights_obj, self.dataset[0], device=x.device)
         _, _, res = csr.wavg(x)
         return _assemble_frame(res, self.names, region_ids, labels, self.weights_obj)
 
@@ -451,7 +451,7 @@ def panel_arrays(weights, dataset: Dataset, aggregator_dict, engine: str = "auto
     tindex = _labels_of(dataset)
     order, fused_cols, staged, names = _lower_all(aggregator_dict)
     _guard_week(fused_cols, tindex)
-    csr, region_ids = eng.get_csr(weights, dataset)
+    csr, region_ids = eng.get_csr(weights, dataset, device=eng.dataset_device(dataset))
     if not staged:
         groups = eng.plan_groups(tindex, fused_cols)
         if len(groups) == 1 and [c.key for c in groups[0][0]] == names:

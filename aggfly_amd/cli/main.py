@@ -183,21 +183,14 @@ def run(config, output, engine, years, project_dir, backend, n_workers, verbose,
 
 def _maybe_init_distributed():
     import os
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on some hosts
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch
         import torch.distributed as dist
         if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            ndev = torch.cuda.device_count()
-            if ndev:
-                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
-            from aggfly_amd.distributed import choose_backend
-            backend = choose_backend(ndev, os.environ.get("AGGFLY_DIST_BACKEND"))
+            from aggfly_amd.distributed import init_local_rank
+            info = init_local_rank(os.environ.get("AGGFLY_DIST_BACKEND"))     # this rank's card + nccl (RCCL) or a gloo rehearsal
             if int(os.environ.get("RANK", "0")) == 0:
-                click.echo(f"torch.distributed backend: {backend} ({ndev} GPU(s) visible on this node, "
+                click.echo(f"torch.distributed backend: {info['backend']} ({info['devices_visible']} GPU(s) visible on this node, "
                            f"{os.environ.get('LOCAL_WORLD_SIZE', os.environ['WORLD_SIZE'])} local rank(s))", err=True)
-            dist.init_process_group(backend)
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,17 +49,100 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-int g_cu_count_cache = -1;
-int cu_count() {
-    if (g_cu_count_cache < 0) {
-        int dev = 0;
+// ---- per-device state ----
+// A handle (CSR, plan) belongs to the device that was current when it was created; every entry point that allocates or
+// launches for a handle makes that device current for the duration of the call (DeviceGuard) — a caller's worker thread
+// starts on device 0 whatever device its parent thread had selected (the reference runs its kernels from dask's pool,
+// aggfly/aggregate/nb_kernels.py:271-305), and with one process per GPU on an 8-GPU node rank r's tables must live on card r.
+constexpr int MAX_DEVICES = 64;
+struct DevState {
+    int cus = -1;                  // compute units (hipDeviceProp_t::multiProcessorCount)
+    double* sine_tab = nullptr;    // acos table of the sine_dd closed forms (afhip_kernels.h: sine_theta), uploaded on first use
+};
+DevState g_dev[MAX_DEVICES];
+std::mutex g_dev_mu;
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return dev;
+}
+
+int cu_count(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return 256;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    DevState& d = g_dev[dev];
+    if (d.cus < 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_cu_count_cache = p.multiProcessorCount;
-        else
-            g_cu_count_cache = 256;
+        d.cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     }
-    return g_cu_count_cache;
+    return d.cus;
+}
+
+// Makes `dev` the calling thread's current device and puts the previous one back on scope exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (dev >= 0 && dev != prev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define GUARD_DEVICE(dev)                                                                                  \
+    DeviceGuard guard__(dev);                                                                              \
+    if (guard__.err != hipSuccess)                                                                         \
+        return fail(AFHIP_E_HIP, "hipSetDevice(%d) failed: %s", (int)(dev), hipGetErrorString(guard__.err))
+
+// Device that owns a device pointer (-1: not a device allocation the runtime knows, e.g. NULL or host memory).
+int pointer_device(const void* p) {
+    if (!p) return -1;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) return -1;
+    return at.device;
+}
+
+// The acos table of sine_theta (afhip_kernels.h), in the layout the kernel copies into LDS: 2 halves x SINE_ROWS rows of
+// (C, S, TH, 0).  Row k of either half belongs to phi_k = asin(k / 256):
+//   half 0 (a <= g: theta = pi/2 - asin(u)):  (-cos phi_k, +sin phi_k, pi/2 - phi_k)
+//   half 1 (a >  g: theta = asin(u)):         (+cos phi_k, -sin phi_k, phi_k)
+std::vector<double> sine_table_host() {
+    std::vector<double> t((size_t)2 * SINE_ROWS * 4, 0.0);
+    for (int k = 0; k < SINE_ROWS; ++k) {
+        const double sn = std::min(1.0, (double)k / (double)SINE_SCALE);
+        const double cs = std::sqrt((1.0 - sn) * (1.0 + sn));
+        const double phi = std::asin(sn);
+        double* lo = &t[(size_t)k * 4];
+        double* hi = &t[((size_t)SINE_ROWS + k) * 4];
+        lo[0] = -cs; lo[1] = sn; lo[2] = 1.57079632679489661923 - phi;
+        hi[0] = cs; hi[1] = -sn; hi[2] = phi;
+    }
+    return t;
+}
+
+int sine_table_dev(int dev, const double** out) {
+    *out = nullptr;
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(AFHIP_E_INVALID, "device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    DevState& d = g_dev[dev];
+    if (!d.sine_tab) {
+        const std::vector<double> h = sine_table_host();
+        static_assert(SINE_TAB_BYTES == 2 * SINE_ROWS * 4 * sizeof(double), "table layout");
+        double* p = nullptr;
+        HIP_TRY(hipMalloc((void**)&p, h.size() * sizeof(double)));
+        hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return fail(AFHIP_E_HIP, "sine table upload failed: %s", hipGetErrorString(e)); }
+        d.sine_tab = p;            // lives as long as the process (one 11.5 KB table per device)
+    }
+    *out = d.sine_tab;
+    return AFHIP_OK;
 }
 
 template <typename T>
@@ -88,6 +172,7 @@ struct DevBuf {
 constexpr int64_t SPMM_SEG_MIN = 64, SPMM_SEG_MAX = 1024, SPMM_TARGET_SEGS = 4096, SPMM_MAX_PIECES = 128;
 
 struct afhip_csr {
+    int device = 0;                // the device the tables live on (current device at afhip_csr_create)
     int64_t R = 0, nnz = 0, n_cells = 0, max_row = 0;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> cols;
@@ -102,6 +187,8 @@ struct afhip_csr {
 };
 
 struct afhip_plan {
+    int device = 0;                       // the device the plan's tables and scratch live on (current device at afhip_plan_create)
+    bool has_sine = false;                // a column is sine_dd: launches carry the acos table and its LDS
     afhip_plan_desc desc{};
     std::vector<int64_t> ib, ob;          // host copies
     std::vector<afhip_column> columns;
@@ -140,7 +227,7 @@ struct afhip_plan {
     // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
     std::vector<hipEvent_t> prof_ev;
     int64_t prof_count = 0;
-    ~afhip_plan() {
+    ~afhip_plan() {      // run with `device` current (afhip_plan_destroy): the members below free their buffers after this body
         if (own_ws) (void)hipFree(own_ws);
         if (sums) (void)hipFree(sums);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -192,6 +279,7 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
         c32[(size_t)j] = (int32_t)cols[j];
     }
     auto* h = new afhip_csr();
+    h->device = current_device();
     h->R = R; h->nnz = nnz; h->n_cells = n_cells;
     std::vector<int64_t> seg_ptr;
     std::vector<int32_t> seg_dst, split_row, split_ptr(1, 0);
@@ -233,7 +321,13 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
     return AFHIP_OK;
 }
 
-extern "C" void afhip_csr_destroy(afhip_csr* csr) { delete csr; }
+extern "C" void afhip_csr_destroy(afhip_csr* csr) {
+    if (!csr) return;
+    DeviceGuard g(csr->device);
+    delete csr;
+}
+
+extern "C" int afhip_csr_device(const afhip_csr* csr) { return csr ? csr->device : -1; }
 
 // AGGFLY_HIP_EXACT_ORDER=1 (read once): the standalone spatial entry points then sum in table order like the plans
 // created with exact_order.  AFHIP_SPMM_SERIAL=1 (experiment knob): the serial kernel for every route.
@@ -281,6 +375,7 @@ static int launch_spmm(const afhip_csr* csr, const double* X, double* out, int64
 extern "C" int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t nt,
                                    double* out_dev, void* stream) {
     if (!csr || !block_dev || !out_dev || nt < 0) return fail(AFHIP_E_INVALID, "scatter_block: bad arguments");
+    GUARD_DEVICE(csr->device);
     // the drop-in for _scatter_block: always the table-order sum (out_dev holds exactly R rows)
     return launch_spmm(csr, block_dev, out_dev, nt, (hipStream_t)stream, true);
 }
@@ -295,6 +390,7 @@ extern "C" int afhip_place_box(const void* chunk_dev, void* cube_dev, int elem_s
     const int64_t n = nt * ny * nx;
     if (n == 0) return AFHIP_OK;
     if (n > (int64_t)0x7fffffff * WG) return fail(AFHIP_E_INVALID, "place_box: box too large for one launch");
+    GUARD_DEVICE(pointer_device(cube_dev));
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((n + WG - 1) / WG)), block(WG);
     switch (elem_size) {
@@ -315,6 +411,7 @@ extern "C" int afhip_lz4_decode_streams(const void* comp_dev, const afhip_lz4_st
     if (max_dsize < 0) return fail(AFHIP_E_INVALID, "lz4_decode_streams: negative max_dsize");
     if (n_streams == 0) return AFHIP_OK;
     if (n_streams > 0x7fffffff) return fail(AFHIP_E_INVALID, "lz4_decode_streams: too many streams for one launch");
+    GUARD_DEVICE(pointer_device(comp_dev));
     const dim3 g((unsigned)n_streams), b(64);
     hipStream_t st = (hipStream_t)stream;
     const uint8_t* c = (const uint8_t*)comp_dev;
@@ -350,6 +447,7 @@ extern "C" int afhip_unshuffle_blocks(const void* tmp_dev, void* out_dev, const 
     if (!tmp_dev || !out_dev || !blocks_dev || n_blocks < 0 || max_bsize < 0) return fail(AFHIP_E_INVALID, "unshuffle_blocks: bad arguments");
     if (n_blocks == 0) return AFHIP_OK;
     if (n_blocks > 65535) return fail(AFHIP_E_INVALID, "unshuffle_blocks: more than 65535 blocks in one call");
+    GUARD_DEVICE(pointer_device(out_dev));
     const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)max_bsize / 2 + 255) / 256));
     hipLaunchKernelGGL(k_unshuffle_blocks, dim3(tiles, (unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)tmp_dev,
                        (uint8_t*)out_dev, (const ShufBlock*)blocks_dev);
@@ -362,6 +460,7 @@ extern "C" int afhip_panel_divide(const double* num_dev, const double* den_dev, 
     if (!num_dev || !den_dev || !res_dev || K < 0 || R < 0 || P < 0) return fail(AFHIP_E_INVALID, "panel_divide: bad arguments");
     const int64_t n = K * R * P;
     if (n == 0) return AFHIP_OK;
+    GUARD_DEVICE(pointer_device(res_dev));
     hipLaunchKernelGGL(k_divide_num_den, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, num_dev, den_dev, res_dev, n, R * P);
     HIP_TRY(hipGetLastError());
     return AFHIP_OK;
@@ -389,6 +488,7 @@ extern "C" int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int tr
         default: return fail(AFHIP_E_INVALID, "transform: unknown transform %d", transform);
     }
     if (n == 0) return AFHIP_OK;
+    GUARD_DEVICE(pointer_device(out_dev));
     const int64_t per_block = (int64_t)WG * TRANSFORM_PER_THREAD;
     const int64_t blocks = (n + per_block - 1) / per_block;
     if (blocks > 0x7fffffff) return fail(AFHIP_E_INVALID, "transform: array too large for one launch");
@@ -401,6 +501,7 @@ extern "C" int afhip_spatial_wavg(const afhip_csr* csr, const double* x_dev, int
                                   double* num_dev, double* den_dev, double* res_dev, void* stream) {
     if (!csr || !x_dev || !res_dev || K <= 0 || nt < 0) return fail(AFHIP_E_INVALID, "spatial_wavg: bad arguments");
     if (nt == 0) return AFHIP_OK;
+    GUARD_DEVICE(csr->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t C = csr->n_cells, Q = (K + 1) * nt;
     double *panel = nullptr, *sums = nullptr;
@@ -452,6 +553,7 @@ static int lower_columns(afhip_plan* pl) {
     const int K = pl->desc.K;
     int stat = 0;
     pl->thr.clear(); pl->cols.clear();
+    pl->has_sine = false;
     for (int j = 0; j < K; ++j) {
         const afhip_column& c = pl->columns[j];
         ColOp co{};
@@ -468,6 +570,12 @@ static int lower_columns(afhip_plan* pl) {
                 co.src = SRC_SINE; stat = std::max(stat, 2);
                 co.s0 = c.inner_args[0]; co.s1 = c.inner_args[1];
                 co.s0x2 = 2.0 * co.s0; co.s1x2 = 2.0 * co.s1;
+                {   // the pair-mode window tests on float data compare in float: s rounded down / up (afhip_kernels.h: ColOp)
+                    auto dn = [](double t) { float f = (float)t; return (double)f > t ? std::nextafterf(f, -INFINITY) : f; };
+                    auto up = [](double t) { float f = (float)t; return (double)f < t ? std::nextafterf(f, INFINITY) : f; };
+                    co.s0dn = dn(co.s0); co.s0up = up(co.s0); co.s1dn = dn(co.s1); co.s1up = up(co.s1);
+                }
+                pl->has_sine = true;
                 if (c.inner_args[2] != 0.0 && c.inner_args[2] != 1.0)
                     return fail(AFHIP_E_INVALID, "column %d: sine_dd flag must be 0 or 1 (temporal.py:324)", j);
                 co.skind = (int)c.inner_args[2];
@@ -521,7 +629,7 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const auto& ob = pl->ob;
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
     // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
-    pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count()) ? 64 : WG;
+    pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count(pl->device)) ? 64 : WG;
     // the LDS-histogram kernel keeps more waves per CU as 4-wave workgroups (configs[3] f32: 3.97 ms with
     // single-wave workgroups, 3.57 ms with 256 threads; f64 unchanged)
     if (pl->variant && pl->variant->hb) pl->wg = WG;
@@ -530,7 +638,7 @@ static int build_chunks(afhip_plan* pl, int vec) {
     // aim for ~4 workgroups per CU over the whole grid, never streaming fewer than 64 steps
     int per_cu = 4;      // measured (profiles/r01_sweep_chunks.txt): the fewer time chunks the better once every CU has ~4 workgroups
     if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
-    const int64_t want_wgs = (int64_t)cu_count() * per_cu * (WG / pl->wg);
+    const int64_t want_wgs = (int64_t)cu_count(pl->device) * per_cu * (WG / pl->wg);
     const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
     const int64_t target_len = std::max<int64_t>(64, T / want_chunks);
     // splitting a period adds partial traffic (16 B per extra slot, column and cell, write +
@@ -640,6 +748,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     int rc = validate_desc(desc);
     if (rc) return rc;
     auto* pl = new afhip_plan();
+    pl->device = current_device();
     pl->desc = *desc;
     pl->ib.assign(desc->inner_bounds, desc->inner_bounds + desc->G1 + 1);
     pl->ob.assign(desc->outer_bounds, desc->outer_bounds + desc->P + 1);
@@ -745,10 +854,14 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     const bool partition = pl->hb_n > 0 && want_pipe == 0;
     const bool arith = partition && pl->hb_arith;
     pairs = pairs && want_pipe == 0;
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs);
+    // pair plans whose columns are all  sine_dd -> sum | mean  (no transform, no float32 rounding): the lean group end
+    bool sine_sum = pairs && pl->K <= 2 && !getenv("AFHIP_NO_SINE_SUM");
+    for (const ColOp& c : pl->cols)
+        sine_sum = sine_sum && c.src == SRC_SINE && c.tf == TF_NONE && c.rounding == 0 && (c.outer == OUT_SUM || c.outer == OUT_MEAN);
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs, sine_sum);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
-        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs);
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs);
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs, sine_sum);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs, sine_sum);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
@@ -801,7 +914,13 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     return AFHIP_OK;
 }
 
-extern "C" void afhip_plan_destroy(afhip_plan* plan) { delete plan; }
+extern "C" void afhip_plan_destroy(afhip_plan* plan) {
+    if (!plan) return;
+    DeviceGuard g(plan->device);
+    delete plan;
+}
+
+extern "C" int afhip_plan_device(const afhip_plan* plan) { return plan ? plan->device : -1; }
 
 extern "C" int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* inter_dev, int dtype) {
     if (!plan || column < 0 || column >= plan->K) return fail(AFHIP_E_INVALID, "plan_bind_inter: no such column");
@@ -835,6 +954,16 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     return n + 1;
 }
 
+// A plan's tables and scratch live on plan->device: a cube on another card would be read across xGMI at best and, with peer
+// access off, fault.  Refuse it before anything is launched (pointers the runtime cannot classify are let through).
+static int check_cube_device(const afhip_plan* pl, const void* cube_dev, const char* who) {
+    const int dev = pointer_device(cube_dev);
+    if (dev >= 0 && dev != pl->device)
+        return fail(AFHIP_E_INVALID, "%s: the cube lives on device %d but the plan was created on device %d "
+                    "(create the plan with the cube's device current)", who, dev, pl->device);
+    return AFHIP_OK;
+}
+
 static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st) {
     if (pl->chunks.empty()) return AFHIP_OK;
     for (int j = 0; j < pl->K; ++j)
@@ -846,6 +975,11 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     fa.partial = partial; fa.K = pl->K; fa.nthr = pl->nthr;
     fa.n_tiles = (int32_t)pl->tiles;
     fa.xcd_remap = pl->xcd_remap;
+    fa.sine_tab = nullptr;
+    if (pl->has_sine) {
+        int rc = sine_table_dev(pl->device, &fa.sine_tab);
+        if (rc) return rc;
+    }
     for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];
     for (int i = pl->nthr; i < MAX_THR; ++i) {       // padded slots never fire
         fa.thr[i] = ThrSlot{};
@@ -859,6 +993,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
+    if (pl->has_sine) lds += SINE_TAB_BYTES;            // the acos table, behind the ring (variants with stat >= 2 carry the code)
     if (pl->variant->hb) {
         fa.hb_n = pl->hb_n; fa.hb_c1 = pl->hb_c1; fa.hb_c0 = pl->hb_c0;
         fa.hb_c1f = (float)pl->hb_c1; fa.hb_c0f = (float)pl->hb_c0;
@@ -916,6 +1051,9 @@ static int ensure_ws(afhip_plan* pl, int64_t bytes, void* user_ws, char** base) 
 extern "C" int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cells_dev,
                                        void* workspace_dev, void* stream) {
     if (!plan || !cube_dev || !cells_dev) return fail(AFHIP_E_INVALID, "plan_run_temporal: NULL argument");
+    int rcd = check_cube_device(plan, cube_dev, "plan_run_temporal");
+    if (rcd) return rcd;
+    GUARD_DEVICE(plan->device);
     hipStream_t st = (hipStream_t)stream;
     char* base;
     int rc = ensure_ws(plan, plan->ws_partial, workspace_dev, &base);
@@ -931,6 +1069,11 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if (!plan || !cube_dev || !csr || !res_dev) return fail(AFHIP_E_INVALID, "plan_run: NULL argument");
     if (csr->n_cells != plan->desc.n_cells)
         return fail(AFHIP_E_INVALID, "plan_run: CSR has %lld cells, plan has %lld", (long long)csr->n_cells, (long long)plan->desc.n_cells);
+    if (csr->device != plan->device)
+        return fail(AFHIP_E_INVALID, "plan_run: the CSR lives on device %d, the plan on device %d", csr->device, plan->device);
+    int rcd = check_cube_device(plan, cube_dev, "plan_run");
+    if (rcd) return rcd;
+    GUARD_DEVICE(plan->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = plan->K, P = plan->desc.P, Q = (K + 1) * P;
     // partial + panel live in the caller's workspace when given; the small [R][Q] sums
@@ -993,6 +1136,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
 
 extern "C" int afhip_plan_profile_begin(afhip_plan* plan, int64_t max_launches) {
     if (!plan || max_launches < 0) return fail(AFHIP_E_INVALID, "plan_profile_begin: bad arguments");
+    GUARD_DEVICE(plan->device);
     for (auto& e : plan->prof_ev) if (e) (void)hipEventDestroy(e);
     plan->prof_ev.assign((size_t)(2 * max_launches), nullptr);
     for (auto& e : plan->prof_ev) HIP_TRY(hipEventCreate(&e));
@@ -1002,6 +1146,7 @@ extern "C" int afhip_plan_profile_begin(afhip_plan* plan, int64_t max_launches) 
 
 extern "C" int64_t afhip_plan_profile_end(afhip_plan* plan, float* ms_out, int64_t cap) {
     if (!plan) return 0;
+    DeviceGuard guard__(plan->device);
     const int64_t n = plan->prof_count;
     for (int64_t i = 0; i < n && i < cap; ++i) {
         if (hipEventSynchronize(plan->prof_ev[(size_t)(2 * i + 1)]) != hipSuccess ||
@@ -1024,6 +1169,7 @@ static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells
     if (!cube_dev || !bounds || !out_dev) return fail(AFHIP_E_INVALID, "group kernel: NULL argument");
     if (G < 0 || D <= 0) return fail(AFHIP_E_INVALID, "group kernel: bad G/D");
     if (G == 0) return AFHIP_OK;
+    GUARD_DEVICE(pointer_device(cube_dev));          // the temporary plan is created, run and freed on the cube's device
     hipStream_t st = (hipStream_t)stream;
     // D can exceed one pass's slot/column budget: run passes of <= MAX_COLS columns
     const int64_t per_pass = std::min<int64_t>(MAX_COLS, MAX_THR);

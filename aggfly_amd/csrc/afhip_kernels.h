@@ -65,6 +65,7 @@ struct ColOp {
     const void* inter;         // TF_INTER: the second cube [G1][C] (one value per inner group and cell), else null
     double s0, s1;             // sine_dd thresholds
     double s0x2, s1x2;         // 2 * s0, 2 * s1 (exact): the cooling form's 2 thr - tmax - tmin starts from them
+    float s0dn, s0up, s1dn, s1up;  // s0 / s1 rounded down / up to float: for float tmin, tmax   tmin < s <=> tmin < up,  s < tmax <=> tmax > dn
     double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
     double o0, o1, obase;      // outer dd/bins thresholds
 };
@@ -84,6 +85,7 @@ struct FusedArgs {
     double* partial;               // device [n_slots][K][C]
     int32_t K, nthr;
     int32_t xcd_remap, n_tiles;    // 1: give each XCD a contiguous range of cell tiles (speed only)
+    const double* sine_tab;        // device [2][SINE_ROWS][4]: rows of the acos table (sine_theta), or null when no column is sine_dd
     // LDS-histogram bins (FEAT bit 5): the threshold slots form a contiguous partition of equal
     // width with edges hb_edge[0..hb_n]; hb_bin_of_slot[slot] = position of that slot's bin.
     // guess bin (shifted by one guard bin) = floor(v * hb_c1 + hb_c0); hb_dn / hb_up are the edges
@@ -191,91 +193,134 @@ __device__ __forceinline__ double div_by_finite(double a, double b, double y) { 
 __device__ __forceinline__ double div_by(double a, double b, double y) {
     return __builtin_amdgcn_div_fixup(div_by_finite(a, b, y), b, a);
 }
-// d = a * b + c as ONE three-address v_fma_f64 with the (wave-uniform) addend c in a scalar register pair.  For a Horner
-// chain hipcc otherwise emits v_mov_b64 + v_fmac_f64 per term (the two-address form clobbers the coefficient), doubling
-// the polynomial's VALU cost; with a "v" constraint the coefficients pin 2 VGPRs each (30 for the degree-14 asin).
-__device__ __forceinline__ double fma3(double a, double b, double c) {
+// d = a * b + c as ONE three-address v_fma_f64 with the (wave-uniform) factor b in a scalar register pair and the addend in a
+// vector register: hipcc otherwise emits v_mov_b64 + v_fmac_f64 (the two-address form clobbers its addend).
+__device__ __forceinline__ double fma_vsv(double a, double b, double c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 #else
     return __builtin_fma(a, b, c);
 #endif
 }
-// asin(u) for 0 <= u <= 0.7072 (t = u^2 <= 1/2): u + u^3 p(t), p of degree 14 through Chebyshev nodes of [0, 0.7072^2]
-// (scripts/fit/asin_fit.py: max abs error 1.2e-14, evaluated in double).
-__device__ __forceinline__ double asin_core_wide(double u, double t) {
-    double p = 0.3379097149030259;
-    p = fma3(p, t, -0.9032914986427146);
-    p = fma3(p, t, 1.1675177613361616);
-    p = fma3(p, t, -0.890631195996176);
-    p = fma3(p, t, 0.4674407127226085);
-    p = fma3(p, t, -0.15540291391580394);
-    p = fma3(p, t, 0.05097480101568288);
-    p = fma3(p, t, 0.0042099716965424624);
-    p = fma3(p, t, 0.014879304155047953);
-    p = fma3(p, t, 0.0172753040904813);
-    p = fma3(p, t, 0.022376412991636434);
-    p = fma3(p, t, 0.030381804553144803);
-    p = fma3(p, t, 0.0446428595401402);
-    p = fma3(p, t, 0.07499999998385828);
-    p = fma3(p, t, 0.16666666666668462);
-    return __fma_rn(u * t, p, u);
+// (k << n) + base in one instruction
+__device__ __forceinline__ uint32_t lshl_add(uint32_t base, uint32_t k, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(k), "n"(n), "v"(base));
+    return d;
+#else
+    return (k << n) + base;
+#endif
+}
+// max(x, 0) / max(-x, 0) as one v_max_f64: the builtin first canonicalises an operand it cannot prove quiet (v_max x, x);
+// a NaN operand gives 0 either way (callers replace the value of a NaN window afterwards)
+__device__ __forceinline__ double max0(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_max_f64 %0, %1, 0" : "=v"(d) : "v"(x));
+    return d;
+#else
+    return x > 0.0 ? x : 0.0;
+#endif
+}
+__device__ __forceinline__ double max0_neg(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_max_f64 %0, -%1, 0" : "=v"(d) : "v"(x));
+    return d;
+#else
+    return -x > 0.0 ? -x : 0.0;
+#endif
 }
 
-// Single-sine degree days (nb_kernels.py:224-249).  Both of the reference's closed forms are one function,
+// ---- single-sine degree days (nb_kernels.py:202-251) ----
+// Both of the reference's closed forms are one function,
 //   arc(d, x) = d * acos(x) + alpha * sqrt(1 - x^2),            alpha = (tmax - tmin) / 2:
 //   cooling part, tmin < thr < tmax:  ((tavg - thr) * acos(z) + rng * sin(acos(z)) / 2) / pi,  z = (2 thr - tmax - tmin) / rng
 //                                     = arc(tavg - thr, z) / pi                       since sin(acos z) = sqrt(1 - z^2)
 //   heating part:  ((thr - tavg) * (atan(r / sqrt(1 - r^2)) + pi/2) + alpha * cos(atan(...))) / pi,  r = (thr - tavg) / alpha
 //                                     = arc(thr - tavg, -r) / pi                      since atan(r / sqrt(1 - r^2)) = asin(r),
 //                                       asin(r) + pi/2 = acos(-r) and cos(asin r) = sqrt(1 - r^2)
-// (|x| > 1 gives NaN in both forms, as in the reference).  arc needs ONE square root and ONE polynomial:
-//   g = sqrt((1 - |x|)(1 + |x|));  u = min(|x|, g) <= 0.7072;  asin(|x|) = |x| <= 0.7072 ? asin(u) : pi/2 - asin(u)
-// — where the previous form took a square root for acos's half-angle reduction, a second one for the sine term, and the
-// reciprocal-corrected quotient per threshold: ~40 fp64 VALU instructions per evaluation instead of ~65 (C5 is bound by them).
-// The quotients are products with ONE reciprocal of (tmax - tmin) per window (rcp_newton1: within 10 ulp of the reference's
-// division); results agree with the reference's acos / sin / atan / cos form to ~1e-14 absolute on values of order 1-30,
-// inside the 1e-10 contract for sine_dd (scripts/sine_accuracy.py).
-__device__ __forceinline__ double sine_arc(double d, double x, double alpha) {
+// (|x| > 1 gives NaN in both forms, as in the reference).
+//
+// acos comes from a table instead of a polynomial (round 2 evaluated a degree-14 asin: 25 of the arc's 44 fp64 instructions;
+// C5 is bound by them).  With a = |x| and g = sqrt(1 - a^2) the smaller of the two, u = min(a, g) <= 0.7072, has
+//   asin(u) = phi_k + asin(delta),   k = round(256 u),  phi_k = asin(k / 256),  delta = sin(asin u - phi_k) = u cos(phi_k) - w sin(phi_k),
+//   w = max(a, g) = cos(asin u),  |delta| <= 0.0028   ->   asin(delta) = delta + delta^3 (1/6 + 3/40 delta^2)   (next term 5e-20)
+// and theta = acos(a) is asin(u) when g is the smaller one, pi/2 - asin(u) otherwise.  Both cases are one table row
+// (C, S, TH) per (half, k):  theta = TH + asin(u C + w S)   with
+//   a <= g:  C = -cos(phi_k), S = +sin(phi_k), TH = pi/2 - phi_k          a > g:  C = +cos(phi_k), S = -sin(phi_k), TH = phi_k
+// (host: afhip_api.hip:sine_table_host; 2 x 184 rows of 32 bytes, copied into LDS by every workgroup of a sine_dd plan).
+// 11 fp64 + 3 integer instructions and two LDS reads.  Checked on the host against the reference's libm form by
+// scripts/fit/arc_table_emulation.py (1.9e-13 absolute on values of order 1-30) and on the device by scripts/sine_accuracy.py.
+constexpr int SINE_SCALE = 256;
+constexpr int SINE_ROWS = 184;                  // rows per half: k <= 181 for u <= 0.70711; the last rows are guards
+constexpr int SINE_TAB_BYTES = 2 * SINE_ROWS * 32;
+struct alignas(32) SineRow { double C, S, TH, pad; };
+typedef const __attribute__((address_space(3))) SineRow* sine_tab_t;
+
+// sqrt(q) for q in {0} U [2^-53, 1]: adding DBL_MIN leaves every q > 0 as it is, keeps q < 0 negative (rsq -> NaN: |x| > 1) and
+// makes the rsq of q = 0 finite, so that g = q * y = 0 needs no select.  v_rsq_f64 seed (2^-24.4 on gfx950,
+// scripts/probe/rcp_rsq_probe.py) + one coupled Goldschmidt step: 3e-15 relative — the arc's other terms carry more.
+__device__ __forceinline__ double sqrt_unit(double q) {
+    const double y = __builtin_amdgcn_rsq(q + 2.2250738585072014e-308);
+    const double g = q * y, h = 0.5 * y;
+    const double r = __fma_rn(-h, g, 0.5);
+    return __fma_rn(g, r, g);
+}
+// acos(a) for 0 <= a <= 1 given g = sqrt(1 - a^2)
+__device__ __forceinline__ double sine_theta(double a, double g, sine_tab_t tab) {
+    static_assert(SINE_SCALE == 256, "the index trick below adds 2^44 = 2^52 / 256");
+    const double u = __builtin_fmin(a, g), w = __builtin_fmax(a, g);
+    const double t = u + 17592186044416.0;                                      // + 2^44 (ulp 2^-8): the sum's low word is round(256 u)
+    uint32_t k = (uint32_t)__double2loint(t);
+    k = k < (uint32_t)(SINE_ROWS - 1) ? k : (uint32_t)(SINE_ROWS - 1);          // NaN / out-of-range operands stay inside the table
+    // row address = base of the half + 32 k: one v_cndmask between the two bases (loop-invariant) and one v_lshl_add_u32
+    const uint32_t lo_base = (uint32_t)(uintptr_t)tab, hi_base = lo_base + (uint32_t)(SINE_ROWS * sizeof(SineRow));
+    sine_tab_t row = (sine_tab_t)(uintptr_t)lshl_add((a <= g) ? lo_base : hi_base, k, 5);
+    const double C = row->C, S = row->S, TH = row->TH;
+    const double delta = __fma_rn(u, C, w * S);
+    const double t2 = delta * delta;
+    const double p = fma_vsv(t2, 0.075, 0.16666666666666666);
+    return TH + __fma_rn(delta * t2, p, delta);
+}
+__device__ __forceinline__ double sine_arc(double d, double x, double alpha, sine_tab_t tab) {
     const double HALF_PI = 1.57079632679489661923;
     const double a = fabs(x);
-    const double q = (1.0 - a) * (1.0 + a);                  // 1 - a is exact for a >= 1/2
-    // sqrt(q) for q in {0} U [2^-53, 1]: adding DBL_MIN leaves every q > 0 as it is, keeps q < 0 negative (rsq -> NaN: |x| > 1)
-    // and makes the rsq of q = 0 finite, so that g = q * y = 0 needs no select.  rsq seed, one coupled Goldschmidt step,
-    // one residual correction (the library's second correction only settles the last bit).
-    const double y = __builtin_amdgcn_rsq(q + 2.2250738585072014e-308);
-    double g = q * y, h = 0.5 * y;
-    const double r = __fma_rn(-h, g, 0.5);
-    g = __fma_rn(g, r, g);
-    h = __fma_rn(h, r, h);
-    const double e = __fma_rn(-g, g, q);
-    g = __fma_rn(e, h, g);
-    const bool small = a <= 0.70710678118654752;
-    const double u = small ? a : g;
-    const double as = asin_core_wide(u, u * u);
-    const double v = small ? as : HALF_PI - as;              // asin(|x|)
-    const double ac = HALF_PI - copysign(v, x);              // acos(x)
+    const double g = sqrt_unit(__fma_rn(-a, a, 1.0));          // 1 - a^2 with ONE rounding
+    const double th = sine_theta(a, g, tab);                   // acos(|x|)
+    const double ac = HALF_PI - copysign(HALF_PI - th, x);     // acos(x)
     return __fma_rn(d, ac, alpha * g);
 }
-// cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful)
-__device__ __forceinline__ double sine_cool(double thr, double thr2, double tmin, double tmax, double tavg, double alpha, double inv_rng) {
+// (tmin, tmax) pairs: tavg is the mid-range, so z = r = (thr - tavg) / alpha =: d / alpha in both forms and, with a = |d| / alpha,
+//   cooling part = max(tavg - thr, 0) + [tmin < thr < tmax] alpha F(a),     heating part = max(thr - tavg, 0) + [..] alpha F(a),
+//   F(a) = (sqrt(1 - a^2) - a acos(a)) / pi        (F(-a) = F(a) + a folds the sign of z into the max() term;
+// the max() term alone is the reference's value on either side of the window).  -> pi F(a)
+__device__ __forceinline__ double sine_pair_f(double a, sine_tab_t tab) {
+    const double g = sqrt_unit(__fma_rn(-a, a, 1.0));
+    return __fma_rn(-a, sine_theta(a, g, tab), g);
+}
+// cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
+__device__ __forceinline__ double sine_cool(double thr, double thr2, bool inside, double tmin, double tmax, double tavg, double alpha,
+                                            double inv_rng, sine_tab_t tab) {
     const double INV_PI = 0.31830988618379067154;
     if (thr <= tmin) return tavg - thr;
-    if (thr < tmax && tmin < thr) {
+    if (inside) {
         const double z = (thr2 - tmax - tmin) * inv_rng;         // thr2 = 2 thr; inf / NaN operands give NaN here too
-        return sine_arc(tavg - thr, z, alpha) * INV_PI;
+        return sine_arc(tavg - thr, z, alpha, tab) * INV_PI;
     }
     return 0.0;
 }
 // heating part (nb_kernels.py:238-249); inv_alpha ~ 2 / rng
-__device__ __forceinline__ double sine_heat(double thr, double tmin, double tmax, double tavg, double alpha, double inv_alpha) {
+__device__ __forceinline__ double sine_heat(double thr, bool inside, double tmin, double tmax, double tavg, double alpha, double inv_alpha,
+                                            sine_tab_t tab) {
     const double INV_PI = 0.31830988618379067154;
     if (thr >= tmax) return thr - tavg;
-    if (thr < tmax && tmin < thr) {
+    if (inside) {
         const double d = thr - tavg;
-        return sine_arc(d, -(d * inv_alpha), alpha) * INV_PI;
+        return sine_arc(d, -(d * inv_alpha), alpha, tab) * INV_PI;
     }
     return 0.0;
 }
@@ -410,6 +455,14 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //             statistics are min / max / sum of the pair, taken in the input precision, without the per-row accumulators.
     constexpr bool PAIR = (FEAT & 128) != 0;
     static_assert(!PAIR || (PIPE == 0 && STAT == 2 && NTHR == 0 && DEPTH % 2 == 0), "pair mode: direct loads, sum + min + max, no threshold slots");
+    // FEAT bit 8: pair mode in which EVERY column is  sine_dd -> (no transform, no float32 rounding) -> sum | mean  (configs[4]):
+    //             the group end is the sine closed forms and one add per column — no per-group walk through the column
+    //             records' source / transform / reducer switches (that walk is ~90 scalar instructions per wave and group,
+    //             as many as the vector ones that do the arithmetic: profiles/r03_pmc_c5.txt); the records are loop-invariant
+    //             kernel arguments and stay in scalar registers; a NaN pair is remembered in a lane mask (scalar OR) and
+    //             applied when the period's sum leaves the kernel, since NaN is sticky under + anyway.
+    constexpr bool SINESUM = (FEAT & 256) != 0;
+    static_assert(!SINESUM || (PAIR && (FEAT & 1) && KMAX <= 2), "the sine -> sum fast path is a pair-mode form with at most two columns");
     static_assert(!HA || HB, "arithmetic edges are a mode of the LDS histogram");
     static_assert(!HB || (TKI && PIPE == 0), "the LDS histogram replaces the integer bin counters of the direct-load path");
     static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
@@ -445,13 +498,15 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     int cnt[VEC];
     unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
     bool pnan[VEC];                                 // pair mode: this lane's pair holds a NaN
+    TIn plo[VEC], phi[VEC];                         // pair mode: the pair's min / max in the input precision
+    unsigned long long nanacc[VEC];                 // SINESUM: lanes that met a NaN pair since the last emitted slot
     double acc[(NTHR > 0 && !TKI) ? NTHR : 1][VEC];
     int cthr[(NTHR > 0 && TKI && !HB) ? NTHR : 1][VEC];
     double os[SL ? 1 : KMAX][VEC];
 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull;
+        s[i] = 0.0; mn[i] = inf64(); mx[i] = -inf64(); cnt[i] = 0; nanmask[i] = 0ull; nanacc[i] = 0ull;
 #pragma unroll
         for (int j = 0; j < NTHR; ++j) { if (HB) {} else if (TKI) cthr[j][i] = 0; else acc[j][i] = 0.0; }
     }
@@ -462,11 +517,23 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //   etab_b[g] = {E[g].up, E[g+1].dn}   only for lanes that leave the guessed bin: is v ON the edge?
     // then the counters [(hb_n + 2) * VEC][blockDim].
     struct EdgeT { TIn lo, hi; };
-    extern __shared__ __attribute__((aligned(16))) unsigned char dynlds[];
+    extern __shared__ __attribute__((aligned(32))) unsigned char dynlds[];
     EdgeT* etab_a = (EdgeT*)dynlds;
     EdgeT* etab_b = (EdgeT*)(dynlds + HB_TABLE_BYTES / 2);
     int* hcnt = (int*)(dynlds + HB_TABLE_BYTES);
     const int bd = blockDim.x, tid = threadIdx.x;
+    // sine_dd plans: every workgroup copies the acos table (sine_theta) into LDS, behind the LDS-DMA ring if there is one
+    static_assert(!(HB && (FEAT & 1)), "histogram variants carry no sine_dd code");
+    sine_tab_t sine_tab = nullptr;
+    if constexpr ((FEAT & 1) != 0) {
+        unsigned char* base = dynlds + (PIPE == 1 ? (size_t)(bd >> 6) * DEPTH * 1024 : (size_t)0);
+        if (a.sine_tab != nullptr) {            // uniform: the host sets it iff a column is sine_dd (and then sizes the LDS for it)
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            for (int e = tid; e < SINE_TAB_BYTES / 16; e += bd) ((d2*)base)[e] = ((const d2*)a.sine_tab)[e];
+            __syncthreads();
+        }
+        sine_tab = (sine_tab_t)(lds_ptr_t)base;
+    }
     const int hb_bins = a.hb_n + 2;
     TIn hb_c1 = 0, hb_c0 = 0, hb_top = 0;
     TIn ha_w = 0, ha_lo0 = 0, ha_e0 = 0, ha_gl = 0, ha_gh = 0;
@@ -613,15 +680,94 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         const bool empty = nsteps == 0;
         const double dn = (double)nsteps;
         bool hasnan[VEC];
-        double mean[VEC], inv_rng[VEC], alpha[VEC];
+        double mean[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             if constexpr (PAIR) hasnan[i] = pnan[i];
             else hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
             if constexpr (PAIR) mean[i] = s[i] * 0.5;                  // == s / 2 bit for bit
             else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
-            inv_rng[i] = ((FEAT & 1) && STAT >= 2) ? rcp_newton1(mx[i] - mn[i]) : 0.0;
-            alpha[i] = (mx[i] - mn[i]) * 0.5;
+        }
+        // single-sine degree days of one column (nb_kernels.py:218-251).  The reciprocal of the window's range and the arcs are
+        // only evaluated where a threshold lies strictly inside (tmin, tmax): a branch on a lane condition skips the whole wave
+        // when no lane needs it (coherent real data: most wave-days), and the other two cases are one subtraction.
+        auto sine_column = [&](const ColOp& co, double (&x)[VEC]) {
+            const double INV_PI = 0.31830988618379067154;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const double tavg = mean[i];
+                bool in0, in1;
+                if constexpr (PAIR && sizeof(TIn) == 4) {       // float data: exact float compares against the rounded thresholds
+                    in0 = (plo[i] < co.s0up) && (phi[i] > co.s0dn);
+                    in1 = (plo[i] < co.s1up) && (phi[i] > co.s1dn);
+                } else {
+                    in0 = (mn[i] < co.s0) && (co.s0 < mx[i]);
+                    in1 = (mn[i] < co.s1) && (co.s1 < mx[i]);
+                }
+                double xv;
+                if constexpr (PAIR) {
+                    // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_f)
+                    // thr - tavg = thr - s / 2 (s / 2 is exact: one rounding either way)
+                    const double d0 = __fma_rn(s[i], -0.5, co.s0), d1 = __fma_rn(s[i], -0.5, co.s1);
+                    if (co.skind == 0) { KEEP_BRANCH(); xv = max0_neg(d0) - max0_neg(d1); }
+                    else xv = max0(d1) - max0(d0);
+                    if (in0 || in1) {
+                        const double alpha = (mx[i] - mn[i]) * 0.5;
+                        const double y = rcp_newton1(alpha);
+                        const double api = alpha * (co.skind == 0 ? INV_PI : -INV_PI);       // cooling: + part(s0) - part(s1); heating: the reverse
+                        if (in0) xv = __fma_rn(api, sine_pair_f(fabs(d0) * y, sine_tab), xv);
+                        if (in1) xv = __fma_rn(-api, sine_pair_f(fabs(d1) * y, sine_tab), xv);
+                    }
+                } else {
+                    const double rng = mx[i] - mn[i], alpha = rng * 0.5;
+                    double inv_rng = 0.0;
+                    if (in0 || in1) inv_rng = rcp_newton1(rng);
+                    if (co.skind == 0) {
+                        KEEP_BRANCH();
+                        xv = sine_cool(co.s0, co.s0x2, in0, mn[i], mx[i], tavg, alpha, inv_rng, sine_tab)
+                           - sine_cool(co.s1, co.s1x2, in1, mn[i], mx[i], tavg, alpha, inv_rng, sine_tab);
+                    } else {
+                        xv = -sine_heat(co.s0, in0, mn[i], mx[i], tavg, alpha, 2.0 * inv_rng, sine_tab)
+                           + sine_heat(co.s1, in1, mn[i], mx[i], tavg, alpha, 2.0 * inv_rng, sine_tab);
+                    }
+                }
+                if constexpr (SINESUM) {
+                    x[i] = xv;                                  // the NaN pairs are kept in nanacc (below)
+                } else {
+                    // a NaN window: any NaN will do — only the high word is replaced (one v_cndmask instead of two)
+                    const int hi = (hasnan[i] || empty) ? 0x7ff80000 : __double2hiint(xv);
+                    x[i] = __hiloint2double(hi, __double2loint(xv));
+                }
+            }
+        };
+        if constexpr (SINESUM) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) nanacc[i] |= __builtin_amdgcn_ballot_w64(pnan[i]);
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                if (j < K) {
+                    double x[VEC];
+                    sine_column(a.cols[j], x);                  // a.cols[j]: loop-invariant kernel argument, scalar registers
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) os[j][i] += x[i];
+                }
+            }
+            if (emit_slot) {
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    if (j < K) {
+                        double* dst = a.partial + ((int64_t)slot * K + j) * C + c0;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (active) dst[i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) nanacc[i] = 0ull;
+                ++slot;
+                reset_outer();
+            }
+            return;
         }
         uint64_t pk[VEC][4];
         if constexpr (SL && TKI) {
@@ -643,6 +789,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 // float round trip, 1/x for negative exponents) and runs them on every group end.
                 double x[VEC];
                 const int src = co.src;
+                if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {
+                    KEEP_BRANCH();
+                    if constexpr ((FEAT & 1) && STAT >= 2) sine_column(co, x);
+                } else
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const bool bad = hasnan[i] || empty;
@@ -664,14 +814,6 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                                 poisons = a.thr[q].nan_poisons != 0;
                             }
                         x[i] = (empty || (poisons && hasnan[i])) ? nan64() : t;
-                    } else if ((FEAT & 1) && STAT >= 2 && src == SRC_SINE) {   // nb_kernels.py:218-251
-                        if (!bad) {
-                            const double tavg = mean[i];
-                            if (co.skind == 0)
-                                x[i] = sine_cool(co.s0, co.s0x2, mn[i], mx[i], tavg, alpha[i], inv_rng[i]) - sine_cool(co.s1, co.s1x2, mn[i], mx[i], tavg, alpha[i], inv_rng[i]);
-                            else
-                                x[i] = -sine_heat(co.s0, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]) + sine_heat(co.s1, mn[i], mx[i], tavg, alpha[i], 2.0 * inv_rng[i]);
-                        }
                     }
                 }
                 if (co.rounding & 1) {                                // the reference stored this step in float32
@@ -828,6 +970,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(u), "v"(v));
                     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(u), "v"(v));
                 }
+                plo[i] = lo; phi[i] = hi;
                 mn[i] = (double)lo; mx[i] = (double)hi;
                 s[i] = mn[i] + mx[i];
             }
@@ -844,6 +987,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 const int row = (kk + d) < last ? (kk + d) : last;
                 r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)row * C);
             }
+#ifdef AFHIP_PAIR_ROLLED
 #pragma unroll 1
             for (int q = 0; q < ng; ++q) {
                 const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
@@ -852,6 +996,18 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                 for (int d = 0; d + 2 < DEPTH; ++d) r[d] = r[d + 2];
             }
+#else
+            // one copy of the group end per group of the block: since the arcs come from a table (sine_theta) the copies fit
+            // the instruction cache, and the rows need not be shifted down two registers per group (4 VALU per cell-day)
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                if (q < ng) {
+                    const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
+                    pair_stats(r[2 * q], r[2 * q + 1]);
+                    group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63), g + q);
+                }
+            }
+#endif
             g += ng;
             kk += 2 * ng;
         }

@@ -18,11 +18,11 @@ def menu(kind):
     out = []
     vec16 = {0: 4, 1: 2}
 
-    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0):
+    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0, ss=0):
         # sine degree days ride on the min/max accumulators; generic pow() only in the
         # all-purpose (STAT 3) variants; bit 2 = nt cache policy on the streaming loads;
         # bit 3 = integer bin counters; bit 4 = single-level plan (no outer accumulators)
-        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0)
+        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0)
         key = (dtype, pipe, vec, stat, nthr, kmax, depth, feat)
         for i, v in enumerate(out):
             if v[:8] == key:
@@ -85,13 +85,21 @@ def menu(kind):
                 add(dtype, 0, 2, stat, nthr, kmax, depth, prod=0)
                 if dtype == 0:
                     add(dtype, 0, 4, stat, nthr, kmax, depth, prod=0)
+    # round 3 arms (appended, so that the translation units above keep their contents): the arithmetic-edge histogram with
+    # deeper bursts and with two cells per lane — the C4 kernel is short of bytes in flight (profiles/r03_c4_bound_pmc.txt)
+    for dtype in (() if kind == "dev" else (0, 1)):
+        for (vec, depth) in (((1, 8), (1, 16), (2, 4), (2, 8)) if dtype == 1 else ((1, 12), (1, 16), (1, 24), (2, 8), (2, 16))):
+            add(dtype, 0, vec, 0, 16, 16, depth, tki=1, sl=1, hb=1, ha=1, prod=0)
+        # (tmin, tmax) pairs whose columns are all sine_dd -> sum: the lean group end (FEAT bit 8)
+        for (vec, depth) in (((1, 4), (1, 8)) if dtype == 1 else ((2, 8), (1, 8), (2, 4))):
+            add(dtype, 0, vec, 2, 0, 2, depth, pair=1, ss=1, prod=1 if (vec, depth) in ((1, 4), (2, 8), (1, 8)) and not (dtype == 1 and depth == 8) else 0)
     return out
 
 
 def name_of(v):
     dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
     return (f"{'f32' if dtype == 0 else 'f64'}_p{pipe}_v{vec}_s{stat}_t{nthr}_k{kmax}_d{depth}" + ("_nt" if feat & 4 else "")
-            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else ""))
+            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 256 else ""))
 
 
 def inst(v):
@@ -154,7 +162,7 @@ def main():
             f.write(f"int register_variants_{idx:02d}(Variant* out) {{\n    int n = 0;\n")
             for v in group:
                 dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
-                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
+                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {1 if feat & 256 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
             f.write("    return n;\n}\n}\n")
         files.append(fn)
     with _KeepIfSame(os.path.join(outdir, "variants_table.hip")) as f:

@@ -49,6 +49,56 @@ def choose_backend(n_devices: int, override=None) -> str:
     return "nccl" if n_devices >= local else "gloo"
 
 
+def init_local_rank(backend=None) -> dict:
+    """One process per GPU (torchrun's RANK / LOCAL_RANK / WORLD_SIZE in the environment): select this rank's card —
+    ``LOCAL_RANK`` modulo the visible devices, so only a rehearsal on fewer cards ever shares one — choose the backend
+    against this NODE's device count (`choose_backend`: "nccl" = RCCL over xGMI when every local rank has its own GPU) and
+    initialise the process group.  ``backend`` (e.g. from ``AGGFLY_DIST_BACKEND``) overrides the choice.  Does nothing but
+    report when WORLD_SIZE is 1 or the group already exists.  -> {"backend", "device", "devices_visible", "world_size"}.
+
+    Everything the engine allocates afterwards (cubes, weight tables, plans) follows the selected device; the handles are
+    bound to it (include/aggfly_hip.h "Devices")."""
+    import torch
+    dist = _dist()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this pool's hosts
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    dev = int(os.environ.get("LOCAL_RANK", "0")) % ndev if ndev else None
+    if dev is not None:
+        torch.cuda.set_device(dev)
+    info = {"backend": None, "device": dev, "devices_visible": ndev, "world_size": ws}
+    if dist.is_available() and dist.is_initialized():
+        info["backend"] = dist.get_backend()
+        return info
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        info["backend"] = choose_backend(ndev, backend)
+        if info["backend"] == "nccl" and dev is not None:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(info["backend"])
+    return info
+
+
+def devices_used(group=None) -> dict:
+    """Which cards do the ranks of the group really sit on?  -> {"ranks", "devices_used" (distinct (host, GPU uuid) pairs),
+    "devices": [...]}: N ranks on RCCL must report N distinct devices; a rehearsal on one card reports 1."""
+    import torch
+    dist = _dist()
+    rank, ws = world(group)
+    if torch.cuda.is_available():
+        d = torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(d)
+        ident = (os.uname().nodename, str(getattr(props, "uuid", "")) or f"index{d}", props.name)
+    else:
+        ident = (os.uname().nodename, "cpu", "cpu")
+    idents = [ident]
+    if ws > 1:
+        idents = [None] * ws
+        dist.all_gather_object(idents, ident, group=group)
+    return {"ranks": ws, "devices_used": len({i[:2] for i in idents}), "devices": [list(i) for i in idents]}
+
+
 def split_even(n: int, rank: int, world_size: int):
     """Contiguous balanced split of range(n): -> (lo, hi)."""
     base, extra = divmod(n, world_size)
@@ -195,7 +245,7 @@ def _cells_band_panel(weights, grid_ds, cube_band, y0, y1, tindex, aggregator_di
     iy, ixs = np.divmod(wcols, nx)
     wcols_mem = iy * nx + lon_order[ixs]
     br, bc, bw = band_csr_triplets(wrows, wcols_mem, wv, ny, nx, y0, y1)
-    csr = hip.CSR(br, bc, bw, len(region_ids), (y1 - y0) * nx)
+    csr = hip.CSR(br, bc, bw, len(region_ids), (y1 - y0) * nx, device=cube_band.device)
     pr = eng.run_fused_pass(cube_band, cols, ib, ob, csr=csr, want_cells=False)
     if len(pr) != 1:
         raise hip.HipUnsupported("cell sharding needs the spec to fit one fused pass")
@@ -224,7 +274,7 @@ def aggregate_dataset_sharded(weights, dataset=None, aggregator_dict=None, engin
         local = dataset.deepcopy()
         local.da = dataset.da.isel(time=slice(k_lo, k_hi))
         _, fused_cols, _, names = agg._lower_all(aggregator_dict)
-        csr, region_ids = eng.get_csr(weights, dataset)
+        csr, region_ids = eng.get_csr(weights, dataset, device=eng.dataset_device(dataset))
         if k_hi > k_lo:
             res, names, region_ids, local_labels = agg.panel_arrays(weights, local, aggregator_dict, engine)
         else:
@@ -346,7 +396,7 @@ def aggregate_store_sharded(weights_of, path, var, aggregator_dict, engine="auto
             res, names, region_ids, local_labels = agg.panel_arrays(weights, local, aggregator_dict, engine)
         else:
             from . import engine as eng
-            _, region_ids = eng.get_csr(weights, local)
+            _, region_ids = eng.get_csr(weights, local, device=eng.dataset_device(local))
             res, local_labels = torch.empty((len(names), len(region_ids), 0), dtype=torch.float64, device="cuda"), labels[:0]
         # by label: a window that starts or ends on empty resample bins has fewer local periods than q_hi - q_lo
         parts.append(place_by_label(res, local_labels, labels, q_lo, q_hi))

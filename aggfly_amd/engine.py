@@ -179,6 +179,15 @@ def device_cube(dataset: Dataset):
     return d.contiguous()
 
 
+def dataset_device(dataset) -> int:
+    """Index of the GPU that holds (or, for a host array, will receive: the calling thread's current device) the dataset's
+    cube: the device its plans and weight tables must be created on."""
+    d = getattr(getattr(dataset, "da", None), "data", None)
+    if d is not None and _is_torch(d) and d.is_cuda:
+        return hip._device_index(d)
+    return hip._device_index(None)
+
+
 def _hash(*arrs) -> str:
     h = hashlib.sha1()
     for a in arrs:
@@ -191,14 +200,18 @@ _PLAN_CACHE_MAX = 32
 _PLAN_CACHE_BYTES = 16 << 30        # plans own their scratch in HBM: bound what the cache pins
 
 
-def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=None) -> hip.FusedPlan:
+def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=None, device=None) -> hip.FusedPlan:
+    """``device``: the GPU of the cube the plan will run on (its tables and scratch live there: a plan is bound to the device
+    it was created on, include/aggfly_hip.h "Devices"); part of the cache key, so that rank r / a worker thread on card r
+    never picks up card 0's plan."""
     exact = config.exact_order if exact_order is None else exact_order
     tune = config.tuning if tuning is None else tuning
+    dev = hip._device_index(device)
     # the second cube of an 'inter' column is bound per run (hip.FusedPlan.bind_inter), so it is not part of the key
-    ckey = (T, n_cells, dtype_code, _hash(ib, ob), repr([{k: v for k, v in c.items() if k != "inter"} for c in columns]), exact, tune)
+    ckey = (dev, T, n_cells, dtype_code, _hash(ib, ob), repr([{k: v for k, v in c.items() if k != "inter"} for c in columns]), exact, tune)
     p = _PLAN_CACHE.get(ckey)
     if p is None:
-        p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune)
+        p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune, device=dev)
         held = sum(q.workspace_bytes() for q in _PLAN_CACHE.values())
         while _PLAN_CACHE and (len(_PLAN_CACHE) >= _PLAN_CACHE_MAX or held + p.workspace_bytes() > _PLAN_CACHE_BYTES):
             old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
@@ -231,8 +244,9 @@ def weight_triplets(wdf: pd.DataFrame, cell_ids: np.ndarray):
 _CSR_CACHE: dict = {}
 
 
-def get_csr(weights, dataset: Dataset):
-    """CSR for ``weights`` laid over ``dataset``'s grid, cached per (table, grid).
+def get_csr(weights, dataset: Dataset, device=None):
+    """CSR for ``weights`` laid over ``dataset``'s grid, cached per (device, table, grid); ``device``: the GPU that holds the
+    cube (default: the calling thread's current device).
 
     The weights' ``cell_id`` lives on the +-180-sorted grid.  A 0-360 dataset is NOT
     re-sorted in memory (the reference does, `spatial.py:60`): the longitude permutation is
@@ -247,7 +261,8 @@ def get_csr(weights, dataset: Dataset):
     # so a recycled id() can never serve a stale CSR
     ck = getattr(weights.grid, "_cell_key", None)
     cell_key = ck[1:] if ck is not None and ck[0] == id(weights.grid.cell_id) else _hash(np.asarray(weights.grid.cell_id))
-    ckey = (id(wdf), len(wdf), ny, nx, _hash(order), cell_key)
+    dev = hip._device_index(device)
+    ckey = (dev, id(wdf), len(wdf), ny, nx, _hash(order), cell_key)
     hit = _CSR_CACHE.get(ckey)
     if hit is not None:
         return hit
@@ -262,7 +277,7 @@ def get_csr(weights, dataset: Dataset):
     rows, cols, w, region_ids = weight_triplets(wdf, cell_ids)
     iy, ixs = np.divmod(cols, nx)
     cols_mem = iy * nx + order[ixs]            # sorted-grid position -> position in the stored cube
-    csr = hip.CSR(rows, cols_mem, w, len(region_ids), ny * nx)
+    csr = hip.CSR(rows, cols_mem, w, len(region_ids), ny * nx, device=dev)
     if ckey is not None:
         if len(_CSR_CACHE) >= 8:
             _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
@@ -398,7 +413,7 @@ def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=N
     f32_rules = config.match_reference_f32 and code == hip.F32
     cdicts = [_column_dict(c, f32_rules) for c in cols]
     try:
-        plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order)
+        plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order, device=cube.device)
     except hip.HipUnsupported:
         if len(cols) == 1:
             raise

@@ -33,7 +33,7 @@ EXPORTS = (
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
     "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
-    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_transform", "afhip_panel_divide", "afhip_lz4_decode_streams", "afhip_unshuffle_blocks",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_csr_device", "afhip_plan_device", "afhip_transform", "afhip_panel_divide", "afhip_lz4_decode_streams", "afhip_unshuffle_blocks",
 )
 
 
@@ -108,6 +108,8 @@ def load():
     lib.afhip_plan_profile_begin.argtypes = [vp, i64]
     lib.afhip_plan_profile_end.argtypes = [vp, C.POINTER(C.c_float), i64]
     lib.afhip_plan_profile_end.restype = i64
+    lib.afhip_csr_device.argtypes = [vp]
+    lib.afhip_plan_device.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -139,7 +141,7 @@ def place_box(chunk, cube, box_in_chunk, at):
     ingestion route's device-side scatter.  Both tensors contiguous, same dtype (2 / 4 / 8-byte elements)."""
     (st, sy, sx, nt, ny, nx), (t0, y0, x0) = box_in_chunk, at
     _check(load().afhip_place_box(chunk.data_ptr(), cube.data_ptr(), chunk.element_size(), chunk.shape[1], chunk.shape[2],
-                                  st, sy, sx, nt, ny, nx, cube.shape[1], cube.shape[2], t0, y0, x0, _stream_ptr()))
+                                  st, sy, sx, nt, ny, nx, cube.shape[1], cube.shape[2], t0, y0, x0, _stream_ptr(cube)))
 
 
 def lz4_decode_streams(comp, streams, n_streams: int, max_dsize: int, tmp, out, errors):
@@ -147,12 +149,12 @@ def lz4_decode_streams(comp, streams, n_streams: int, max_dsize: int, tmp, out, 
     by `codec.blosc_lz4_plan`) of the compressed bytes ``comp`` into ``tmp`` / ``out`` on the current stream; malformed
     streams bump the int32 HBM counter ``errors``."""
     _check(load().afhip_lz4_decode_streams(comp.data_ptr(), streams.data_ptr(), int(n_streams), int(max_dsize),
-                                           tmp.data_ptr() if tmp is not None else None, out.data_ptr(), errors.data_ptr(), _stream_ptr()))
+                                           tmp.data_ptr() if tmp is not None else None, out.data_ptr(), errors.data_ptr(), _stream_ptr(comp)))
 
 
 def unshuffle_blocks(tmp, out, blocks, n_blocks: int, max_bsize: int):
     """`afhip_unshuffle_blocks`: Blosc's byte shuffle undone per block (records in the uint8 HBM tensor ``blocks``)."""
-    _check(load().afhip_unshuffle_blocks(tmp.data_ptr(), out.data_ptr(), blocks.data_ptr(), int(n_blocks), int(max_bsize), _stream_ptr()))
+    _check(load().afhip_unshuffle_blocks(tmp.data_ptr(), out.data_ptr(), blocks.data_ptr(), int(n_blocks), int(max_bsize), _stream_ptr(out)))
 
 
 def require_gpu():
@@ -169,8 +171,45 @@ def _torch():
     return torch
 
 
-def _stream_ptr():
-    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+def _stream_ptr(t=None):
+    """The current stream of the device that holds tensor ``t`` (of the current device when ``t`` is None).  A worker thread
+    starts on device 0 whatever its parent had selected; work on a tensor must go to a stream of the tensor's own device."""
+    torch = _torch()
+    dev = t.device if t is not None and getattr(t, "is_cuda", False) else None
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _device_index(device=None) -> int:
+    """Index of a torch device / tensor's device / int; None -> the calling thread's current device."""
+    torch = _torch()
+    if device is None:
+        return int(torch.cuda.current_device())
+    if hasattr(device, "device"):
+        device = device.device
+    if isinstance(device, int):
+        return device
+    device = torch.device(device)
+    return int(torch.cuda.current_device()) if device.index is None else int(device.index)
+
+
+class _on_device:
+    """`with _on_device(i):` makes device ``i`` current for the calling thread (handles belong to the device that is current
+    when the library creates them, include/aggfly_hip.h "Devices") and restores the previous one."""
+
+    def __init__(self, index: int):
+        self.index, self.ctx = int(index), None
+
+    def __enter__(self):
+        torch = _torch()
+        if int(torch.cuda.current_device()) != self.index:
+            self.ctx = torch.cuda.device(self.index)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _dtype_code(t) -> int:
@@ -209,7 +248,7 @@ def _group(fn_name, cube, bounds, code=None, ddargs=None):
         out = torch.empty((G,) + spatial, dtype=cube.dtype, device=cube.device)
         if G:
             _check(lib.afhip_group_stat(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
-                                        int(code), out.data_ptr(), _stream_ptr()))
+                                        int(code), out.data_ptr(), _stream_ptr(cube)))
         return out
     dda = np.ascontiguousarray(np.atleast_2d(np.asarray(ddargs, dtype=np.float64)))
     D = dda.shape[0]
@@ -218,13 +257,13 @@ def _group(fn_name, cube, bounds, code=None, ddargs=None):
     if G:
         if D <= MAXD:
             _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
-                                         dda.ctypes.data, D, out.data_ptr(), _stream_ptr()))
+                                         dda.ctypes.data, D, out.data_ptr(), _stream_ptr(cube)))
         else:  # more thresholds than one pass holds: run passes of 16 and interleave
             for d0 in range(0, D, MAXD):
                 sub = np.ascontiguousarray(dda[d0:d0 + MAXD])
                 tmp = torch.empty((G,) + spatial + (len(sub),), dtype=cube.dtype, device=cube.device)
                 _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
-                                             sub.ctypes.data, len(sub), tmp.data_ptr(), _stream_ptr()))
+                                             sub.ctypes.data, len(sub), tmp.data_ptr(), _stream_ptr(cube)))
                 out[..., d0:d0 + len(sub)] = tmp
     return out
 
@@ -248,7 +287,7 @@ def transform(x, kind: str, arg: float = 0.0, other=None, out_dtype=None):
         other = other.contiguous()
         optr, ocode = other.data_ptr(), _dtype_code(other)
     _check(lib.afhip_transform(x.data_ptr(), _dtype_code(x), x.numel(), code, float(arg), optr, ocode,
-                               out.data_ptr(), _dtype_code(out), _stream_ptr()))
+                               out.data_ptr(), _dtype_code(out), _stream_ptr(x)))
     return out
 
 
@@ -261,7 +300,7 @@ def panel_divide(num, den, out=None):
         raise ValueError("panel_divide: num [K, R, P] and den [R, P] must be float64 HBM tensors")
     res = torch.empty_like(num) if out is None else out
     K, R, P = (int(v) for v in num.shape)
-    _check(load().afhip_panel_divide(num.data_ptr(), den.data_ptr(), res.data_ptr(), K, R, P, _stream_ptr()))
+    _check(load().afhip_panel_divide(num.data_ptr(), den.data_ptr(), res.data_ptr(), K, R, P, _stream_ptr(num)))
     return res
 
 
@@ -292,9 +331,12 @@ class CSR:
     entry order inside each row, which is the order `np.add.at` sums in.
     """
 
-    def __init__(self, region_idx, cell_idx, w_vals, n_regions: int, n_cells: int):
+    def __init__(self, region_idx, cell_idx, w_vals, n_regions: int, n_cells: int, device=None):
+        """``device``: the GPU the tables are uploaded to (torch device / index / a tensor on it; default: the calling
+        thread's current device).  Only arrays of that device may be multiplied with this handle."""
         lib = load()
         require_gpu()
+        self.device_index = _device_index(device)
         region_idx = _i64(region_idx)
         cell_idx = _i64(cell_idx)
         w = np.ascontiguousarray(np.asarray(w_vals, dtype=np.float64))
@@ -309,8 +351,9 @@ class CSR:
         self.w = np.ascontiguousarray(w[order])
         self.R, self.nnz, self.n_cells = int(n_regions), int(len(w)), int(n_cells)
         h = C.c_void_p()
-        _check(lib.afhip_csr_create(self.indptr.ctypes.data, self.cols.ctypes.data, self.w.ctypes.data,
-                                    self.R, self.nnz, self.n_cells, C.byref(h)))
+        with _on_device(self.device_index):
+            _check(lib.afhip_csr_create(self.indptr.ctypes.data, self.cols.ctypes.data, self.w.ctypes.data,
+                                        self.R, self.nnz, self.n_cells, C.byref(h)))
         self._h = h
 
     @property
@@ -336,7 +379,7 @@ class CSR:
             raise ValueError("block must be float64 [n_cells, t]")
         nt = int(block.shape[1])
         out = torch.empty((self.R, nt), dtype=torch.float64, device=block.device)
-        _check(load().afhip_scatter_block(self._h, block.data_ptr(), nt, out.data_ptr(), _stream_ptr()))
+        _check(load().afhip_scatter_block(self._h, block.data_ptr(), nt, out.data_ptr(), _stream_ptr(block)))
         return out
 
     def wavg(self, x):
@@ -351,7 +394,7 @@ class CSR:
         den = torch.empty((self.R, nt), dtype=torch.float64, device=x.device)
         res = torch.empty((K, self.R, nt), dtype=torch.float64, device=x.device)
         _check(load().afhip_spatial_wavg(self._h, x.data_ptr(), K, nt, num.data_ptr(), den.data_ptr(),
-                                         res.data_ptr(), _stream_ptr()))
+                                         res.data_ptr(), _stream_ptr(x)))
         return num, den, res
 
 
@@ -363,9 +406,12 @@ class FusedPlan:
     """
 
     def __init__(self, T, n_cells, dtype_code, inner_bounds, outer_bounds, columns,
-                 exact_order=False, tuning=0):
+                 exact_order=False, tuning=0, device=None):
+        """``device``: the GPU the plan's tables and scratch live on (default: the calling thread's current device); the
+        cubes and the CSR it is run with must live there too (the library refuses others)."""
         lib = load()
         require_gpu()
+        self.device_index = _device_index(device)
         self.ib = _i64(inner_bounds)
         self.ob = _i64(outer_bounds)
         self.K = len(columns)
@@ -394,7 +440,8 @@ class FusedPlan:
         d.exact_order = 1 if exact_order else 0
         d.tuning = int(tuning)
         h = C.c_void_p()
-        _check(lib.afhip_plan_create(C.byref(d), C.byref(h)))
+        with _on_device(self.device_index):
+            _check(lib.afhip_plan_create(C.byref(d), C.byref(h)))
         self._h = h
         self.G1 = len(self.ib) - 1
         self._inter = {}               # column -> the bound second cube (kept alive while bound)
@@ -426,7 +473,7 @@ class FusedPlan:
         torch = _torch()
         cube = self._check_cube(cube)
         cells = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=cube.device)
-        _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), None, _stream_ptr()))
+        _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), None, _stream_ptr(cube)))
         return cells
 
     def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None, workspace=None):
@@ -450,7 +497,7 @@ class FusedPlan:
             ws_ptr = workspace.data_ptr()
         _check(load().afhip_plan_run(self._h, cube.data_ptr(), csr.handle, out["num"].data_ptr(),
                                      out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, ws_ptr,
-                                     _stream_ptr(), ms))
+                                     _stream_ptr(cube), ms))
         if timed:
             out["kernel_ms"] = (float(ms[0]), float(ms[1]))
         return out

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AFHIP_ABI_VERSION 2
+#define AFHIP_ABI_VERSION 3
 
 /* status codes */
 #define AFHIP_OK            0
@@ -113,6 +113,15 @@ typedef struct afhip_csr afhip_csr;
 int afhip_csr_create(const int64_t* indptr, const int64_t* cols, const double* w, int64_t R,
                      int64_t nnz, int64_t n_cells, afhip_csr** out);
 void afhip_csr_destroy(afhip_csr* csr);
+/* Devices.  A handle (afhip_csr, afhip_plan) belongs to the device that was current (hipGetDevice) on the calling thread
+ * when it was created; its tables and scratch live there.  Every entry point that takes a handle makes that device current
+ * for the duration of the call and restores the caller's afterwards, so a worker thread that still sits on device 0 (the
+ * reference calls its kernels from dask's thread pool, nb_kernels.py:271-305) drives a handle of device r correctly.  What
+ * must match is the data: afhip_plan_run / _run_temporal refuse (AFHIP_E_INVALID) a cube or a CSR that lives on another
+ * device than the plan.  Entry points without a handle (afhip_group_*, afhip_transform, afhip_place_box, ...) run on the
+ * device that owns their array argument.  `stream` must be a stream of that device (or NULL).
+ * afhip_csr_device / afhip_plan_device: the device a handle was created on (-1 for NULL). */
+int afhip_csr_device(const afhip_csr* csr);
 
 /* Replaces _scatter_block(block, region_idx, cell_idx, w_vals, n_regions)
  * (spatial.py:181-186): out[r, t] = sum_j w[j] * block[col[j], t], float64, entries in
@@ -212,6 +221,7 @@ typedef struct afhip_plan_desc {
 typedef struct afhip_plan afhip_plan;
 int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out);
 void afhip_plan_destroy(afhip_plan* plan);
+int afhip_plan_device(const afhip_plan* plan);
 /* AFHIP_TF_INTER columns: bind column `column`'s second cube before the plan runs.  inter_dev [G1, n_cells] of `dtype`
  * (AFHIP_F32 / AFHIP_F64), time-major like the cube: the value the column's inner reducer gives inner group g at a cell
  * is multiplied by inter_dev[g * n_cells + cell] (np.multiply(block, other), dataset.py:563, on the inner level's

@@ -645,6 +645,59 @@ def test_concurrent_host_threads_share_cached_plans(torch_cuda):
     assert not alone[0].drop(columns=["geoid", "time"]).equals(alone[1].drop(columns=["geoid", "time"]))     # the cubes do differ
 
 
+def test_handles_are_bound_to_the_cubes_device_from_a_fresh_thread(torch_cuda):
+    """Handles belong to a device (include/aggfly_hip.h "Devices").  A fresh host thread starts on device 0 whatever card
+    its parent selected — the threaded caller the reference supports (`nb_kernels.py:271-305` under dask's pool) would, on
+    rank r > 0 of an 8-GPU node, otherwise build its tables on card 0 and launch on a cube that lives on card r.  Here the
+    cube sits on the LAST visible device (device 0 on a one-GPU box), the main thread's current device stays 0, and the
+    call is made from a new thread: the cached plan and CSR must report the cube's device, the result must equal the oracle,
+    a cube of another device must be refused, and the calling thread's current device must come back unchanged."""
+    import threading
+    from aggfly_amd import engine as eng, hip, synth
+    torch = torch_cuda
+    dev = torch.cuda.device_count() - 1
+    T, ny, nx = 24 * 40, 12, 16
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=77, ocean_frac=0.1, scattered_nan=5)
+    time = pd.date_range("2001-01-01", periods=T, freq="h")
+    lat, lon = 30 + 0.25 * np.arange(ny), 250 + 0.25 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, 5, seed=9)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "month"})],
+                s=[("aggregate", {"calc": "sine_dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "month"})])
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}),
+                    lon_is_360=True).to_device(f"cuda:{dev}")
+    assert eng.dataset_device(ds) == dev
+    w = af.weights_from_objects(ds, gr, table=tab)
+    eng._PLAN_CACHE.clear(); eng._CSR_CACHE.clear()
+    box = {}
+
+    def job():
+        box["before"] = torch.cuda.current_device()
+        box["df"] = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+        box["after"] = torch.cuda.current_device()
+
+    t = threading.Thread(target=job)
+    t.start(); t.join()
+    assert box["before"] == box["after"]                              # the library restores the caller's device
+    lib = hip.load()
+    plans, csrs = list(eng._PLAN_CACHE.items()), list(eng._CSR_CACHE.items())
+    assert plans and csrs
+    for key, plan in plans:
+        assert key[0] == dev and plan.device_index == dev and lib.afhip_plan_device(plan._h) == dev
+    for key, (csr, _) in csrs:
+        assert key[0] == dev and csr.device_index == dev and lib.afhip_csr_device(csr.handle) == dev
+    ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
+    want = ra.aggregate_dataset(ow, ra.ODataset(cube, time, lat, lon, True), engine="numba", **spec)
+    cols = [c for c in want.columns if c not in ("geoid", "time")]
+    assert list(box["df"].columns) == list(want.columns) and len(box["df"]) == len(want)
+    np.testing.assert_allclose(box["df"][cols].values, want[cols].values, rtol=1e-10, atol=1e-10, equal_nan=True)
+    if torch.cuda.device_count() >= 2:                                # a cube on another card than the plan: refused before any launch
+        plan = plans[0][1]
+        other = torch.zeros((plan.T, ny, nx), dtype=torch.float64, device=f"cuda:{(dev + 1) % torch.cuda.device_count()}")
+        with pytest.raises(ValueError, match="lives on device"):
+            plan.run_temporal(other)
+
+
 def _reference_cache_feather(project_dir, table, module_dict, obj_dict):
     """Write ``table`` where the reference's ProjectCache would (`aggfly/cache/project_cache.py:46-47,207-226`):
     ``{project_dir}/tmp/GridWeights/mod-<sha>/<sha>.feather`` (+ the mod.yaml beside it), Feather V2 = the Arrow IPC file

@@ -1,5 +1,7 @@
-"""aggregate_dataset_sharded on the GPU box: two ranks (sharing the card, gloo exchange) must
-reproduce the single-process panel for both sharding modes."""
+"""The N > 1 path on the GPU box.  Every job script selects its rank's card and its backend the way the CLI does
+(`distributed.init_local_rank`): with a GPU per rank the ranks sit on DISTINCT cards and exchange over RCCL ("nccl"); on a
+one-GPU box they share card 0 and rehearse the same code over gloo.  Each job reports which it was and the tests assert it
+(`_check_backend`), so the day these tests run on a multi-GPU node they measure RCCL, not card 0."""
 import os
 import socket
 import subprocess
@@ -17,8 +19,9 @@ import aggfly_amd as af
 from aggfly_amd import synth, distributed as D
 
 mode, out = sys.argv[1], sys.argv[2]
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    dist.init_process_group("gloo")
+# one process per GPU: this rank's card and the backend are chosen exactly as the CLI does (aggfly_amd/cli/main.py):
+# RCCL when the node has a GPU per local rank, a gloo rehearsal on one card otherwise; the test reads back which it was
+info = D.init_local_rank(os.environ.get("AGGFLY_DIST_BACKEND"))
 T, ny, nx = 24 * 400, 10, 12
 cube = synth.temperature_cube(T, ny, nx, seed=61, ocean_frac=0.1, scattered_nan=30)
 time = pd.date_range("2003-03-01", periods=T, freq="h")
@@ -35,8 +38,11 @@ if dist.is_initialized():
     df = D.aggregate_dataset_sharded(w, ds, spec, shard=mode)
 else:
     df = af.aggregate_dataset(dataset=ds, weights=w, aggregator_dict=spec)
+used = D.devices_used()
 if D.world()[0] == 0:
     df.to_csv(out, index=False)
+    import json
+    json.dump(dict(info, **used), open(out + ".dist.json", "w"))
 if dist.is_initialized():
     dist.destroy_process_group()
 '''
@@ -44,6 +50,24 @@ if dist.is_initialized():
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _check_backend(out_csv, ranks):
+    """The job wrote which backend and which cards its ranks used: with a GPU per rank the exchange must have gone over RCCL
+    between `ranks` DISTINCT devices; on fewer cards it is a gloo rehearsal (ranks share card 0 — the only way this
+    one-GPU box can run the N > 1 code path at all)."""
+    import json
+    import torch
+    d = json.load(open(out_csv + ".dist.json"))
+    ndev = torch.cuda.device_count()
+    assert d["ranks"] == ranks and d["devices_visible"] == ndev
+    if os.environ.get("AGGFLY_DIST_BACKEND"):
+        assert d["backend"] == os.environ["AGGFLY_DIST_BACKEND"]
+    elif ndev >= ranks:
+        assert d["backend"] == "nccl" and d["devices_used"] == ranks, d
+    else:
+        assert d["backend"] == "gloo" and d["devices_used"] == min(ndev, ranks), d
+    return d
 
 
 @pytest.mark.parametrize("mode", ["time", "cells"])
@@ -60,6 +84,7 @@ def test_sharded_equals_single(torch_cuda, tmp_path, mode):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script), mode, two], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_backend(two, 2)
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, rtol=1e-12 if mode == "cells" else 0, atol=0, check_exact=(mode == "time"))
@@ -72,8 +97,9 @@ import aggfly_amd as af
 from aggfly_amd import synth, distributed as D
 
 store, out = sys.argv[1], sys.argv[2]
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    dist.init_process_group("gloo")
+# one process per GPU: this rank's card and the backend are chosen exactly as the CLI does (aggfly_amd/cli/main.py):
+# RCCL when the node has a GPU per local rank, a gloo rehearsal on one card otherwise; the test reads back which it was
+info = D.init_local_rank(os.environ.get("AGGFLY_DIST_BACKEND"))
 ny, nx = 10, 12
 tab = synth.weights_table(ny, nx, 6, seed=62, secondary=True)
 gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
@@ -112,8 +138,11 @@ elif os.environ.get("WINDOW_BYTES"):
 else:
     ds = af.dataset_from_path(store, "t2m", lon_is_360=True, preprocess=lambda x: x - 273.15, device="cuda")
     df = af.aggregate_dataset(dataset=ds, weights=weights_of(ds), aggregator_dict=spec)
+used = D.devices_used()
 if D.world()[0] == 0:
     df.to_csv(out, index=False)
+    import json
+    json.dump(dict(info, **used), open(out + ".dist.json", "w"))
 if dist.is_initialized():
     dist.destroy_process_group()
 '''
@@ -142,6 +171,7 @@ def test_store_sharded_streams_each_ranks_window(torch_cuda, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script), store, two], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_backend(two, 2)
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, check_exact=True)
@@ -178,6 +208,7 @@ def test_store_cell_sharding_reads_only_its_band(torch_cuda, tmp_path):
                         "--master-port", str(_free_port()), str(script), store, two], capture_output=True, text=True, timeout=300,
                        env=dict(env, SHARD="cells", CHUNKS_PER_RANK="6"))
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_backend(two, 2)
     a, b = pd.read_csv(one), pd.read_csv(two)
     assert list(a.columns) == list(b.columns) and len(a) == len(b) > 0
     pd.testing.assert_frame_equal(a, b, rtol=1e-12, atol=0)
@@ -190,8 +221,9 @@ import aggfly_amd as af
 from aggfly_amd import synth, distributed as D
 
 store, out = sys.argv[1], sys.argv[2]
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    dist.init_process_group("gloo")
+# one process per GPU: this rank's card and the backend are chosen exactly as the CLI does (aggfly_amd/cli/main.py):
+# RCCL when the node has a GPU per local rank, a gloo rehearsal on one card otherwise; the test reads back which it was
+info = D.init_local_rank(os.environ.get("AGGFLY_DIST_BACKEND"))
 ny, nx = 6, 8
 tab = synth.weights_table(ny, nx, 5, seed=72, secondary=True)
 gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
@@ -209,8 +241,11 @@ if os.environ.get("RESIDENT_SHARDED"):
     ds = af.dataset_from_path(store, "t2m", lon_is_360=True, device="cuda")
     df2 = D.aggregate_dataset_sharded(weights_of(ds), ds, spec, shard="time")
     pd.testing.assert_frame_equal(df, df2, check_exact=True)
+used = D.devices_used()
 if D.world()[0] == 0:
     df.to_csv(out, index=False)
+    import json
+    json.dump(dict(info, **used), open(out + ".dist.json", "w"))
 if dist.is_initialized():
     dist.destroy_process_group()
 '''
@@ -243,6 +278,7 @@ def test_seasonal_store_gaps_on_shard_and_window_boundaries(torch_cuda, tmp_path
     r = subprocess.run(launch + ["--master-port", str(_free_port()), str(script), store, three], capture_output=True, text=True,
                        timeout=300, env=dict(env, RESIDENT_SHARDED="1"))
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_backend(three, 3)
     pd.testing.assert_frame_equal(a, pd.read_csv(three), check_exact=True)
     # windows of at most 40 days of steps: (June), (July), (August + the nine empty months), ...
     wb = str(40 * ny * nx * 4)
@@ -283,3 +319,26 @@ def test_bench_two_rank_rehearsal_reports_backend_and_devices(torch_cuda, tmp_pa
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["backend"].startswith("none") and line["devices_used"] == 1 and line["scaling"] == "strong"
+
+
+def test_bench_two_ranks_on_two_gpus_use_rccl(torch_cuda, tmp_path):
+    """With two (or more) GPUs visible, `bench.py --gpus 2` must run on RCCL with one card per rank in both sharding arms:
+    backend nccl, two distinct devices, no rehearsal warning.  (Skipped on one-GPU boxes, where the test above covers the
+    refusal and the labelled gloo rehearsal.)"""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]
+    small = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--ny", "40", "--nx", "64", "--T", "720", "--regions", "30"]
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "AGGFLY_DIST_BACKEND")}
+    for shard, scaling in (("time", "weak"), ("cells", "strong")):
+        r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small + ["--shard", shard], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["backend"] == "nccl" and line["ranks"] == 2 and line["devices_used"] == 2 and "warning" not in line, line
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and "RCCL" in line["config"]["sharding"]
+        assert line["value"] > 0 and line["roofline"]["frac"] > 0

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.afhip_abi_version() == 2
+    assert lib.afhip_abi_version() == 3
     assert isinstance(hip.device_count(), int)
 
 
@@ -390,3 +390,52 @@ def test_bench_refuses_ranks_without_their_own_gpu():
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr and "AGGFLY_BENCH_BACKEND=gloo" in r.stderr
     assert r.stdout.strip() == ""                                     # no JSON line from a refused run
+
+
+def test_plan_and_csr_caches_are_keyed_by_device(monkeypatch):
+    """A handle lives on ONE device (include/aggfly_hip.h "Devices"): with a process (or a worker thread) per GPU the
+    caches must never serve card 0's plan / weight table for a cube on card r.  The library calls are replaced by
+    recorders here (no GPU in this suite); what is checked is the host logic: the device index is part of both cache keys
+    and reaches the constructors."""
+    made = []
+
+    class FakePlan:
+        def __init__(self, *a, device=None, **k):
+            self.device_index = device
+            made.append(("plan", device))
+
+        def workspace_bytes(self):
+            return 0
+
+    class FakeCSR:
+        def __init__(self, rows, cols, w, R, n_cells, device=None):
+            self.device_index = device
+            made.append(("csr", device))
+
+    current = {"dev": 0}
+    monkeypatch.setattr(hip, "FusedPlan", FakePlan)
+    monkeypatch.setattr(hip, "CSR", FakeCSR)
+    monkeypatch.setattr(hip, "_device_index", lambda d=None: current["dev"] if d is None else int(d))
+    monkeypatch.setattr(eng, "_PLAN_CACHE", {})
+    monkeypatch.setattr(eng, "_CSR_CACHE", {})
+    ib, ob = np.arange(0, 49, 24), np.array([0, 2])
+    cols = [dict(inner="mean", outer="sum")]
+    p0 = eng.get_plan(48, 12, hip.F64, ib, ob, cols)                  # the calling thread's current device: 0
+    assert eng.get_plan(48, 12, hip.F64, ib, ob, cols) is p0          # cached
+    p3 = eng.get_plan(48, 12, hip.F64, ib, ob, cols, device=3)        # the same plan for a cube on card 3: a new handle there
+    assert p3 is not p0 and p3.device_index == 3 and p0.device_index == 0
+    current["dev"] = 5                                                # a thread whose current device is 5
+    assert eng.get_plan(48, 12, hip.F64, ib, ob, cols).device_index == 5
+    assert [k[0] for k in eng._PLAN_CACHE] == [0, 3, 5]
+
+    arr = np.zeros((4, 3, 4))
+    ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"],
+                                 {"time": pd.date_range("2000-01-01", periods=4, freq="D"), "latitude": [1.0, 2.0, 3.0],
+                                  "longitude": [10.0, 11.0, 12.0, 13.0]}))
+    tab = pd.DataFrame({"cell_id": [0, 1, 5], "index_right": [0, 0, 1], "weight": [0.5, 0.5, 1.0]})
+    w = af.weights_from_objects(ds, af.GeoRegions(pd.DataFrame({"geoid": ["a", "b"]})), table=tab)
+    c5, _ = eng.get_csr(w, ds)
+    c2, _ = eng.get_csr(w, ds, device=2)
+    assert c5.device_index == 5 and c2.device_index == 2 and eng.get_csr(w, ds, device=2)[0] is c2
+    assert eng.dataset_device(ds) == 5                                # a host array goes to the current device
+    assert made.count(("csr", 2)) == 1 and made.count(("plan", 3)) == 1
