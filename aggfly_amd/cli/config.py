@@ -155,22 +155,29 @@ class RunConfig:
 # field-level helpers
 # --------------------------------------------------------------------------------------
 def _parse_years(spec, errors):
-    """``"1980:1990"`` (inclusive) | list | int | None -> list of ints."""
+    """``"1980:1990"`` (inclusive) | list | int | None -> list of ints; the reference's message per kind of mistake
+    (`cli/config.py:116-143`)."""
     if spec is None:
         return None
-    try:
-        if isinstance(spec, bool):
-            raise TypeError
-        if isinstance(spec, int):
-            return [spec]
-        if isinstance(spec, list):
+    problem = None
+    if isinstance(spec, bool):                      # YAML `true` is an int subclass
+        problem = "must be a range 'start:end', a list, or an int"
+    elif isinstance(spec, int):
+        return [spec]
+    elif isinstance(spec, list):
+        try:
             return [int(y) for y in spec]
-        if isinstance(spec, str):
-            lo, sep, hi = spec.partition(":")
+        except (TypeError, ValueError):
+            problem = f"list must contain integers, got {spec!r}"
+    elif isinstance(spec, str):
+        lo, sep, hi = spec.partition(":")
+        try:
             return list(range(int(lo), int(hi) + 1)) if sep else [int(lo)]
-    except (TypeError, ValueError):
-        pass
-    errors.append(f"years: could not parse {spec!r} (use a range 'start:end', a list, or an int)")
+        except ValueError:
+            problem = f"could not parse {spec!r} (use 'start:end' or an int)"
+    else:
+        problem = f"unsupported type {type(spec).__name__}"
+    errors.append(f"years: {problem}")
     return None
 
 
@@ -229,17 +236,72 @@ def _secondary(raw, errors):
 # --------------------------------------------------------------------------------------
 # the walker
 # --------------------------------------------------------------------------------------
+def _after_preprocess(values, raw, errors):
+    if values["preprocess"] is not None and values["preprocess_from"] is not None:
+        errors.append("dataset: set at most one of 'preprocess' and 'preprocess_from'")
+    if values["preprocess_from"] is not None and ":" not in str(values["preprocess_from"]):
+        errors.append("dataset.preprocess_from must be 'path/to/file.py:function'")
+
+
+def _after_xycoords(values, raw, errors):
+    xy = values["xycoords"]
+    if not (isinstance(xy, list) and len(xy) == 2):
+        errors.append("dataset.xycoords must be a 2-item list [lon_name, lat_name]")
+        xy = ["longitude", "latitude"]
+    values["xycoords"] = (xy[0], xy[1])
+
+
+def _after_secondary(values, raw, errors):
+    values["secondary"] = _secondary(values["secondary"], errors)
+
+
+def _after_variables(values, raw, errors):
+    variables = values["variables"]
+    if not isinstance(variables, dict) or not variables:
+        errors.append("aggregate.variables must be a non-empty mapping of name -> steps")
+        values["variables"] = {}
+    else:
+        for name, steps in variables.items():
+            _check_steps(name, steps, errors)
+    values["years"] = _parse_years(raw.get("years"), errors)      # job control follows the pipeline stages, as in the reference's report
+
+
+def _after_output(values, raw, errors):
+    out_path, fmt = values["output_path"], values["output_format"]
+    if fmt is None and out_path:
+        ext = os.path.splitext(str(out_path))[1].lstrip(".").lower()
+        fmt = {"pq": "parquet"}.get(ext, ext)
+    if fmt not in ALLOWED_FORMAT:
+        errors.append(f"output.format {fmt!r} not in {sorted(ALLOWED_FORMAT)} "
+                      "(set output.format or use a .parquet/.feather/.csv extension)")
+    values["output_format"] = fmt
+    if values["dataset_path"] and "{year}" in str(values["dataset_path"]) and not values["years"]:
+        errors.append("dataset.path contains '{year}' but no 'years' were given (add years: 'start:end')")
+
+
+# cross-field rules, run right after the field they belong to so that the messages come out in the order of the file's
+# sections — the order the reference reports them in (`cli/config.py:214-386`; pinned by tests/golden/cli_fixtures.json)
+AFTER = {("dataset", "preprocess_from"): _after_preprocess, ("dataset", "xycoords"): _after_xycoords,
+         ("weights", "secondary"): _after_secondary, ("aggregate", "variables"): _after_variables, ("output", "format"): _after_output}
+
+
 def parse_config(raw) -> RunConfig:
     """Validate a parsed YAML mapping; raise ConfigError listing EVERY problem found."""
     if not isinstance(raw, dict) or not raw:
         raise ConfigError(["config must be a non-empty YAML mapping"])
     errors: List[str] = []
     values: Dict[str, Any] = {}
-    for section, rules in SCHEMA.items():
-        body = raw.get(section) or {}
+    bodies = {}
+    for section in SCHEMA:                              # malformed sections first, then the fields section by section
+        body = raw.get(section)
+        if body is None:
+            body = {}
         if not isinstance(body, dict):
             errors.append(f"{section}: must be a mapping")
             body = {}
+        bodies[section] = body
+    for section, rules in SCHEMA.items():
+        body = bodies[section]
         for key, rule in rules.items():
             val = body.get(key, rule.default)
             if rule.required and not val:
@@ -253,38 +315,9 @@ def parse_config(raw) -> RunConfig:
             if val is not None and rule.cast is not None:
                 val = rule.cast(val)
             values[rule.attr] = val
-
-    # cross-field rules
-    if values["preprocess"] is not None and values["preprocess_from"] is not None:
-        errors.append("dataset: set at most one of 'preprocess' and 'preprocess_from'")
-    if values["preprocess_from"] is not None and ":" not in str(values["preprocess_from"]):
-        errors.append("dataset.preprocess_from must be 'path/to/file.py:function'")
-    xy = values["xycoords"]
-    if not (isinstance(xy, list) and len(xy) == 2):
-        errors.append("dataset.xycoords must be a 2-item list [lon_name, lat_name]")
-        xy = ["longitude", "latitude"]
-    values["xycoords"] = (xy[0], xy[1])
-    values["secondary"] = _secondary(values["secondary"], errors)
-
-    variables = values["variables"]
-    if not isinstance(variables, dict) or not variables:
-        errors.append("aggregate.variables must be a non-empty mapping of name -> steps")
-        values["variables"] = {}
-    else:
-        for name, steps in variables.items():
-            _check_steps(name, steps, errors)
-
-    values["years"] = _parse_years(raw.get("years"), errors)
-    out_path, fmt = values["output_path"], values["output_format"]
-    if fmt is None and out_path:
-        ext = os.path.splitext(str(out_path))[1].lstrip(".").lower()
-        fmt = {"pq": "parquet"}.get(ext, ext)
-    if fmt not in ALLOWED_FORMAT:
-        errors.append(f"output.format {fmt!r} not in {sorted(ALLOWED_FORMAT)} "
-                      "(set output.format or use a .parquet/.feather/.csv extension)")
-    values["output_format"] = fmt
-    if values["dataset_path"] and "{year}" in str(values["dataset_path"]) and not values["years"]:
-        errors.append("dataset.path contains '{year}' but no 'years' were given (add years: 'start:end')")
+            hook = AFTER.get((section, key))
+            if hook is not None:
+                hook(values, raw, errors)
     if errors:
         raise ConfigError(errors)
     known = {f.name for f in fields(RunConfig)}

@@ -35,17 +35,17 @@ def _check(node):
         return _check(node.right)
     if isinstance(node, ast.UnaryOp):
         if type(node.op) not in _UN:
-            raise PreprocessError(f"operator {type(node.op).__name__} is not allowed")
+            raise PreprocessError(f"unary {type(node.op).__name__} is not allowed")
         return _check(node.operand)
     if isinstance(node, ast.Constant):
         if isinstance(node.value, bool) or not isinstance(node.value, (int, float)):
-            raise PreprocessError(f"constant {node.value!r} is not allowed (numbers only)")
+            raise PreprocessError(f"only numeric constants are allowed, got {node.value!r}")
         return None
     if isinstance(node, ast.Name):
         if node.id != "x":
-            raise PreprocessError(f"name {node.id!r} is not allowed (the only variable is 'x')")
+            raise PreprocessError(f"only the variable 'x' is allowed, got {node.id!r}")
         return None
-    raise PreprocessError(f"{type(node).__name__} is not allowed in a preprocess expression")
+    raise PreprocessError(f"expression element {type(node).__name__} is not allowed (only arithmetic on 'x' and numbers)")
 
 
 def _eval(node, x):
@@ -67,14 +67,14 @@ def compile_expression(expr: str):
         raise PreprocessError(f"could not parse expression {expr!r}: {e.msg}")
     _check(tree)
     if not any(isinstance(n, ast.Name) and n.id == "x" for n in ast.walk(tree)):
-        raise PreprocessError(f"expression {expr!r} does not reference 'x'")
+        raise PreprocessError(f"expression {expr!r} must use the variable 'x' (e.g. 'x - 273.15')")
     return lambda x: _eval(tree, x)
 
 
 def load_from_file(spec: str):
     path, _, func = spec.rpartition(":")
     if not path or not func:
-        raise PreprocessError("preprocess_from must be 'path/to/file.py:function'")
+        raise PreprocessError(f"preprocess_from must be 'path/to/file.py:function', got {spec!r}")
     if not os.path.exists(path):
         raise PreprocessError(f"preprocess_from file not found: {path}")
     mod_spec = importlib.util.spec_from_file_location("_aggfly_user_preprocess", path)
@@ -92,9 +92,17 @@ def resolve(preprocess=None, preprocess_from=None):
         return load_from_file(preprocess_from)
     if preprocess is None:
         return None
+    if not isinstance(preprocess, str):
+        raise PreprocessError(f"preprocess must be a builtin name or an expression string, got {type(preprocess).__name__}")
     if preprocess in BUILTINS:
         return BUILTINS[preprocess]
-    return compile_expression(str(preprocess))
+    try:
+        return compile_expression(preprocess)
+    except PreprocessError:
+        if preprocess.isidentifier():            # a bare word: the user meant a builtin
+            raise PreprocessError(f"unknown preprocess {preprocess!r}: not a builtin ({', '.join(sorted(BUILTINS))}) "
+                                  "and not a valid expression") from None
+        raise
 
 
 def resolve_from_config(config):

@@ -260,6 +260,11 @@ SHUFFLE_BLOCK = np.dtype([("tmp_off", "<i8"), ("out_off", "<i8"), ("bsize", "<i4
 E_UNSUPPORTED = -2
 
 
+class PlanCapacityError(CodecError):
+    """`blosc_lz4_plan`: the chunks need more stream / block records than the lists passed in hold (their geometry differs
+    from the one the lists were sized for)."""
+
+
 def blosc_lz4_plan(base: np.ndarray, comp_off, comp_size, out_off, out_size, streams: np.ndarray, blocks: np.ndarray):
     """Plan the GPU-side decode of Blosc-1 chunks that sit in ``base`` (uint8; chunk i = ``comp_size[i]`` bytes at
     ``comp_off[i]``): fills ``streams`` (dtype `LZ4_STREAM`) and ``blocks`` (dtype `SHUFFLE_BLOCK`) for
@@ -277,5 +282,8 @@ def blosc_lz4_plan(base: np.ndarray, comp_off, comp_size, out_off, out_size, str
                                     C.byref(tmp), C.byref(maxd), res.ctypes.data)
     bad = [int(i) for i in np.nonzero((res < 0) & (res != E_UNSUPPORTED))[0]]
     if bad or (rc and rc != E_UNSUPPORTED):
-        raise CodecError(f"blosc_lz4_plan: chunks {bad[:8]} are malformed: {lib.afcodec_last_error().decode()}")
+        msg = lib.afcodec_last_error().decode()
+        if not bad and "list too small" in msg:       # more streams / blocks than the caller's record lists hold: not damage
+            raise PlanCapacityError(f"blosc_lz4_plan: {msg}")
+        raise CodecError(f"blosc_lz4_plan: chunks {bad[:8]} are malformed: {msg}")
     return int(ns.value), int(nb.value), int(tmp.value), int(maxd.value), res

@@ -575,6 +575,7 @@ static int lower_columns(afhip_plan* pl) {
                     auto up = [](double t) { float f = (float)t; return (double)f < t ? std::nextafterf(f, INFINITY) : f; };
                     co.s0dn = dn(co.s0); co.s0up = up(co.s0); co.s1dn = dn(co.s1); co.s1up = up(co.s1);
                 }
+                co.swidth = co.s1 - co.s0;
                 pl->has_sine = true;
                 if (c.inner_args[2] != 0.0 && c.inner_args[2] != 1.0)
                     return fail(AFHIP_E_INVALID, "column %d: sine_dd flag must be 0 or 1 (temporal.py:324)", j);
@@ -630,13 +631,18 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
     // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
     pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count(pl->device)) ? 64 : WG;
-    // the LDS-histogram kernel keeps more waves per CU as 4-wave workgroups (configs[3] f32: 3.97 ms with
-    // single-wave workgroups, 3.57 ms with 256 threads; f64 unchanged)
-    if (pl->variant && pl->variant->hb) pl->wg = WG;
+    // the LDS-histogram kernel: single-wave workgroups and MANY time chunks.  It is short of bytes in flight (waves park 65 % of
+    // their cycles on memory at 4.2 waves per SIMD, VALU and LDS far from busy: profiles/r03_c4_bound_pmc.txt), and the more,
+    // smaller workgroups the grid offers the fuller the CUs stay: configs[3] f32 3.15 ms (7 chunks of 256 threads) -> 2.84 ms
+    // (126 chunks of 64), f64 5.86 -> 5.58 (profiles/r03_sweep_chunks_depth.txt).  Round 1 had measured 4-wave workgroups
+    // ahead — at the few chunks of that time.
+    const bool hist = pl->variant && pl->variant->hb;
+    if (hist) pl->wg = 64;
     if (const char* e = getenv("AFHIP_FORCE_WG")) { int w = atoi(e); if (w == 64 || w == 128 || w == 256) pl->wg = w; }   // experiment knob
     pl->tiles = (C + (int64_t)pl->wg * vec - 1) / ((int64_t)pl->wg * vec);
     // aim for ~4 workgroups per CU over the whole grid, never streaming fewer than 64 steps
-    int per_cu = 4;      // measured (profiles/r01_sweep_chunks.txt): the fewer time chunks the better once every CU has ~4 workgroups
+    int per_cu = 4;      // measured (profiles/r01_sweep_chunks.txt, r03_sweep_chunks_depth.txt): the fewer time chunks the better once every CU has ~4 workgroups
+    if (hist) per_cu = 96;   // ... except for the histogram kernel (above)
     if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
     const int64_t want_wgs = (int64_t)cu_count(pl->device) * per_cu * (WG / pl->wg);
     const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
@@ -777,8 +783,27 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // 6.0 TB/s, f32 3.5 vs 4.3; 4-step groups f32 4.4 vs 5.6, f64 equal; 8 steps and longer: equal.
     // every inner group exactly two rows ((tmin, tmax) pairs) and min / max / sine columns: the pair-mode variants of the
     // direct-load path keep DEPTH / 2 whole groups in flight, so they need no ring either
-    bool pairs = desc->G1 > 0 && desc->T == 2 * desc->G1 && pl->nthr == 0 && pl->stat == 2 && !getenv("AFHIP_NO_PAIR_MODE");
+    bool pairs = desc->G1 > 0 && desc->T == 2 * desc->G1 && pl->nthr == 0 && (pl->stat == 1 || pl->stat == 2) && !getenv("AFHIP_NO_PAIR_MODE");
     for (int64_t g = 0; pairs && g < desc->G1; ++g) pairs = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == 2;
+    // pair plans whose columns are all  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  without float32 rounding
+    // take the lean group end (FEAT bit 8); when every column is a plain sine_dd, its tightest form (FEAT bit 9).  A sine_dd
+    // column there needs s0 < s1: its two max() terms are one clamp of width s1 - s0.
+    bool lean = pairs && !getenv("AFHIP_NO_LEAN_PAIRS"), lean_sine = lean && pl->K <= 2;
+    for (const ColOp& c : pl->cols) {
+        const bool sine_ok = c.src == SRC_SINE && c.s0 < c.s1 && std::isfinite(c.swidth);
+        const bool src_ok = c.src == SRC_MEAN || c.src == SRC_SUM || c.src == SRC_MIN || c.src == SRC_MAX || sine_ok;
+        lean = lean && src_ok && (c.tf == TF_NONE || c.tf == TF_POWI) && c.rounding == 0 && (c.outer == OUT_SUM || c.outer == OUT_MEAN);
+        lean_sine = lean_sine && sine_ok && c.tf == TF_NONE;
+    }
+    lean_sine = lean_sine && lean;
+    // mean / sum columns alone (no min, max or sine): the pair path exists in the lean form only, and a light plan (one or two
+    // columns) streams faster through the LDS-DMA ring, whose prefetch runs across the two-row groups (5.99 vs 5.44 TB/s on
+    // 1801 x 3600 f32); with more columns the lean group end wins (profiles/r03_pairs_mean_poly.txt)
+    if (pairs && pl->stat == 1) {
+        int min_k = 3;
+        if (const char* e = getenv("AFHIP_LEAN_STAT1_MIN_K")) min_k = atoi(e);      // experiment knob
+        if (!lean || pl->K < min_k) pairs = lean = lean_sine = false;
+    }
     if (!pairs) {
         const double avg_group = desc->G1 > 0 ? (double)desc->T / (double)desc->G1 : 0.0;
         const int vec16 = desc->dtype == AFHIP_F64 ? 2 : 4;
@@ -854,14 +879,18 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     const bool partition = pl->hb_n > 0 && want_pipe == 0;
     const bool arith = partition && pl->hb_arith;
     pairs = pairs && want_pipe == 0;
-    // pair plans whose columns are all  sine_dd -> sum | mean  (no transform, no float32 rounding): the lean group end
-    bool sine_sum = pairs && pl->K <= 2 && !getenv("AFHIP_NO_SINE_SUM");
-    for (const ColOp& c : pl->cols)
-        sine_sum = sine_sum && c.src == SRC_SINE && c.tf == TF_NONE && c.rounding == 0 && (c.outer == OUT_SUM || c.outer == OUT_MEAN);
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs, sine_sum);
+    lean = lean && pairs; lean_sine = lean_sine && pairs;
+    // rows in flight per lane on the direct-load path: f64 four, f32 eight — but four for f32 plans with two cells per lane on
+    // grids large enough for 256-thread workgroups (the multi-column plans; see gen_variants.py)
+    int depth_hint = desc->dtype == AFHIP_F64 ? 4 : 8;
+    if (desc->dtype == AFHIP_F32 && want_pipe == 0 && want_vec == 2 && !pairs && pl->hb_n == 0 &&
+        (C_ + (int64_t)WG * 2 - 1) / ((int64_t)WG * 2) >= (int64_t)cu_count(pl->device))
+        depth_hint = 4;
+    if (const char* e = getenv("AFHIP_DEPTH_HINT")) depth_hint = atoi(e);      // experiment knob
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
-        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs, sine_sum);
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs, sine_sum);
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);

@@ -66,6 +66,7 @@ struct ColOp {
     double s0, s1;             // sine_dd thresholds
     double s0x2, s1x2;         // 2 * s0, 2 * s1 (exact): the cooling form's 2 thr - tmax - tmin starts from them
     float s0dn, s0up, s1dn, s1up;  // s0 / s1 rounded down / up to float: for float tmin, tmax   tmin < s <=> tmin < up,  s < tmax <=> tmax > dn
+    double swidth;                 // s1 - s0
     double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
     double o0, o1, obase;      // outer dd/bins thresholds
 };
@@ -223,6 +224,16 @@ __device__ __forceinline__ double max0(double x) {
     return d;
 #else
     return x > 0.0 ? x : 0.0;
+#endif
+}
+// min(x, c) with the wave-uniform c in a scalar register pair, one instruction (no canonicalising v_max in front)
+__device__ __forceinline__ double min_vs(double x, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(c));
+    return d;
+#else
+    return x < c ? x : c;
 #endif
 }
 __device__ __forceinline__ double max0_neg(double x) {
@@ -454,18 +465,20 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //             DEPTH / 2 whole groups — all of them in flight at once instead of one group's two rows — and a group's
     //             statistics are min / max / sum of the pair, taken in the input precision, without the per-row accumulators.
     constexpr bool PAIR = (FEAT & 128) != 0;
-    static_assert(!PAIR || (PIPE == 0 && STAT == 2 && NTHR == 0 && DEPTH % 2 == 0), "pair mode: direct loads, sum + min + max, no threshold slots");
-    // FEAT bit 8: pair mode in which EVERY column is  sine_dd -> (no transform, no float32 rounding) -> sum | mean  (configs[4]):
-    //             the group end is the sine closed forms and one add per column — no per-group walk through the column
-    //             records' source / transform / reducer switches (that walk is ~90 scalar instructions per wave and group,
-    //             as many as the vector ones that do the arithmetic: profiles/r03_pmc_c5.txt); the records are loop-invariant
-    //             kernel arguments and stay in scalar registers; a NaN pair is remembered in a lane mask (scalar OR) and
-    //             applied when the period's sum leaves the kernel, since NaN is sticky under + anyway.
-    constexpr bool SINESUM = (FEAT & 256) != 0;
-    static_assert(!SINESUM || (PAIR && (FEAT & 1) && KMAX <= 2), "the sine -> sum fast path is a pair-mode form with at most two columns");
-    static_assert(!HA || HB, "arithmetic edges are a mode of the LDS histogram");
-    static_assert(!HB || (TKI && PIPE == 0), "the LDS histogram replaces the integer bin counters of the direct-load path");
-    static_assert(PIPE == 0 || VEC * sizeof(TIn) == 16, "LDS-DMA path moves 16 B per lane");
+    // FEAT bit 8: pair mode with the LEAN group end: every column is   mean | sum | min | max | sine_dd  ->  (nothing | integer
+    //             power)  ->  sum | mean,   without float32 rounding (configs[4]'s sine_dd -> sum; the daily mean of (tmin, tmax)
+    //             and its polynomial).  The group end is then the column's value, its power chain and one add — no per-group walk
+    //             through the column records' source / transform / reducer switches (that walk is ~90 scalar instructions per wave
+    //             and group, as many as the vector ones that do the arithmetic: profiles/r03_kbench_c5_table_arc.txt); the records
+    //             are loop-invariant kernel arguments and stay in scalar registers; a NaN pair is remembered in a lane mask (scalar
+    //             OR) and applied when the period's sum leaves the kernel, since NaN is sticky under + anyway.
+    constexpr bool LEAN = (FEAT & 256) != 0;
+    // FEAT bit 9: ... and every column is a plain sine_dd (no power): nothing but the closed forms in the group end
+    constexpr bool LEAN_SINE = (FEAT & 512) != 0;
+    static_assert(!LEAN_SINE || (LEAN && (FEAT & 1) && KMAX <= 2), "the sine-only lean form: at most two columns");
+    static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % 2 == 0),
+                  "pair mode: direct loads, sum (+ min + max), no threshold slots");
+    static_assert(!LEAN || PAIR, "the lean group end is a pair-mode form");
     const int64_t C = a.C;
     const int K = a.K;
     const int lane = threadIdx.x & 63;
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     unsigned long long nanmask[VEC];                // lane masks in SGPR pairs: OR-ed on the scalar ALU
     bool pnan[VEC];                                 // pair mode: this lane's pair holds a NaN
     TIn plo[VEC], phi[VEC];                         // pair mode: the pair's min / max in the input precision
-    unsigned long long nanacc[VEC];                 // SINESUM: lanes that met a NaN pair since the last emitted slot
+    unsigned long long nanacc[VEC];                 // lean group end: lanes that met a NaN pair since the last emitted slot
     double acc[(NTHR > 0 && !TKI) ? NTHR : 1][VEC];
     int cthr[(NTHR > 0 && TKI && !HB) ? NTHR : 1][VEC];
     double os[SL ? 1 : KMAX][VEC];
@@ -709,8 +722,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_f)
                     // thr - tavg = thr - s / 2 (s / 2 is exact: one rounding either way)
                     const double d0 = __fma_rn(s[i], -0.5, co.s0), d1 = __fma_rn(s[i], -0.5, co.s1);
-                    if (co.skind == 0) { KEEP_BRANCH(); xv = max0_neg(d0) - max0_neg(d1); }
-                    else xv = max0(d1) - max0(d0);
+                    if constexpr (LEAN) {
+                        // the two max() terms of a column, s0 < s1 (host-checked for this variant): max(t - s0, 0) - max(t - s1, 0)
+                        // = clamp(t - s0, 0, s1 - s0) — the reference's (t - s0) - (t - s1) for t >= s1 is s1 - s0 up to its
+                        // own two roundings (1e-16 relative; sine_dd's contract is 1e-10)
+                        if (co.skind == 0) { KEEP_BRANCH(); xv = min_vs(max0_neg(d0), co.swidth); }
+                        else xv = min_vs(max0(d1), co.swidth);
+                    } else {
+                        if (co.skind == 0) { KEEP_BRANCH(); xv = max0_neg(d0) - max0_neg(d1); }
+                        else xv = max0(d1) - max0(d0);
+                    }
                     if (in0 || in1) {
                         const double alpha = (mx[i] - mn[i]) * 0.5;
                         const double y = rcp_newton1(alpha);
@@ -731,7 +752,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                            + sine_heat(co.s1, in1, mn[i], mx[i], tavg, alpha, 2.0 * inv_rng, sine_tab);
                     }
                 }
-                if constexpr (SINESUM) {
+                if constexpr (LEAN) {
                     x[i] = xv;                                  // the NaN pairs are kept in nanacc (below)
                 } else {
                     // a NaN window: any NaN will do — only the high word is replaced (one v_cndmask instead of two)
@@ -740,14 +761,37 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 }
             }
         };
-        if constexpr (SINESUM) {
+        if constexpr (LEAN) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) nanacc[i] |= __builtin_amdgcn_ballot_w64(pnan[i]);
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
                 if (j < K) {
                     double x[VEC];
-                    sine_column(a.cols[j], x);                  // a.cols[j]: loop-invariant kernel argument, scalar registers
+                    if constexpr (LEAN_SINE) {
+                        sine_column(a.cols[j], x);              // a.cols[j]: loop-invariant kernel argument, scalar registers
+                    } else {
+                        // (zoff is 0 at run time: with up to six columns the records are read where they are used — hoisted out of
+                        // the time loop they overflow the scalar register file, as in the generic group end below)
+                        const int jz = KMAX > 2 ? j + zoff : j;
+                        const int src = a.cols[jz].src;
+                        if ((FEAT & 1) && src == SRC_SINE) {
+                            KEEP_BRANCH();
+                            if constexpr ((FEAT & 1) != 0) { const ColOp co = a.cols[jz]; sine_column(co, x); }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                x[i] = mean[i];                                        // SRC_MEAN: (u + v) / 2, the reference's s / n
+                                if (src == SRC_SUM) x[i] = s[i];
+                                if (STAT >= 2 && src == SRC_MIN) x[i] = mn[i];
+                                if (STAT >= 2 && src == SRC_MAX) x[i] = mx[i];
+                            }
+                        }
+                        // (continuing ONE double-double chain through consecutive exponents of a polynomial — 3 steps instead of 6 for
+                        // power[1..4] — was built and measured: the chain state's registers cost more than the steps save, 5.8 -> 6.5 ms
+                        // on 1801 x 3600 f32; profiles/r03_pairs_mean_poly.txt)
+                        if (a.cols[jz].tf == TF_POWI) powi_dd_vec<VEC>(x, a.cols[jz].tf_iarg);
+                    }
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) os[j][i] += x[i];
                 }
@@ -973,6 +1017,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 plo[i] = lo; phi[i] = hi;
                 mn[i] = (double)lo; mx[i] = (double)hi;
                 s[i] = mn[i] + mx[i];
+                if constexpr (STAT == 1) s[i] = (double)u + (double)v;     // (the same two addends; no min / max needed)
             }
         };
         // ONE group-end site (rolled loop over the block's groups, the rows shifted down two per group): the sine closed

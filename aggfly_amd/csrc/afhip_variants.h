@@ -24,7 +24,8 @@ struct Variant {
     int hb;           // 1: LDS-histogram bins (contiguous equal-width partition)
     int ha;           // 1: ... whose edges are exactly representable: computed, not read from the LDS table
     int pair;         // 1: plans whose inner groups all hold exactly two rows ((tmin, tmax) pairs)
-    int ss;           // 1: ... and whose columns are all  sine_dd -> sum | mean  without transform or rounding (lean group end)
+    int ss;           // ... with the lean group end: 1 = columns mean | sum | min | max | sine_dd -> (integer power) -> sum | mean;
+                      //     2 = every column a plain sine_dd -> sum | mean (the tightest form)
     const void* fn;
     const char* name;
 };
@@ -36,7 +37,7 @@ const Variant* variants_table(int* n);   // generated (variants_table.hip)
 //         e.g. 1404 LDS ring, 4 cells per lane, depth 4;  108 direct loads, 1 cell per lane, 8 rows in flight
 inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning, int vec = 0,
                                    bool all_bins = false, bool single_level = false, bool partition = false, bool arith = false,
-                                   bool pairs = false, bool sine_sum = false) {
+                                   bool pairs = false, int lean = 0, int depth_hint = 0) {
     const Variant* best = nullptr;
     long best_cost = 0;
     int n = 0;
@@ -52,13 +53,14 @@ inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int 
         if (v.dtype != dtype || v.stat < stat || v.nthr < nthr || v.kmax < K) continue;
         if ((v.tki && !(all_bins && nthr > 0)) || (v.sl && !single_level) || (v.hb && !partition) || (v.ha && !arith)) continue;
         if (v.pair && !(pairs && nthr == 0)) continue;
-        if (v.ss && !sine_sum) continue;
+        if (v.ss > lean) continue;                      // a lean variant needs a plan that qualifies for its form (2 implies 1)
         if (v.pipe != want_pipe || v.nt != want_nt) continue;
         if (tuning > 0) {
             if (v.vec != want_vec || v.depth != want_depth) continue;
         } else if (!v.production || (vec > 0 && v.vec != vec)) continue;
         // specialised forms (integer bins, single level) are cheaper than the general one
-        const long cost = (long)v.nthr * 1000 + (long)v.kmax * 10 + v.stat - (v.tki ? 400 : 0) - (v.sl ? 5 : 0) - (v.hb ? 300 : 0) - (v.ha ? 50 : 0) - (v.pair ? 5 : 0) - (v.ss ? 3 : 0);
+        const long cost = (long)v.nthr * 1000 + (long)v.kmax * 10 + v.stat - (v.tki ? 400 : 0) - (v.sl ? 5 : 0) - (v.hb ? 300 : 0) - (v.ha ? 50 : 0) - (v.pair ? 5 : 0) - 3 * v.ss
+                          + ((depth_hint > 0 && v.depth != depth_hint) ? 1 : 0);      // among equals, the burst depth that measured best for the shape
         if (!best || cost < best_cost) { best = &v; best_cost = cost; }
     }
     return best;

@@ -22,6 +22,7 @@
  * LZ4_decompress_safe, LZ4_compress_default, ZSTD_decompress, ZSTD_isError), zlib is linked.
  */
 #include <dlfcn.h>
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -581,6 +582,37 @@ static int64_t read_piece(int fd, uint8_t* dst, int64_t len, int64_t off, int nt
     return done;
 }
 
+/* Is a failed open / stat an ABSENT chunk?  Only "no such file" is (a Zarr chunk that was never written reads as the fill
+ * value); EMFILE, EACCES, EIO ... are failures of this process or the medium and must never be mistaken for one: a batch
+ * larger than RLIMIT_NOFILE used to report existing chunks as absent, and the caller silently filled them with NaN. */
+static int errno_means_absent(int e) { return e == ENOENT || e == ENOTDIR; }
+
+/* The byte range of request i: offset and size checked against the file, WITHOUT keeping a descriptor (batches hold thousands
+ * of files; descriptors are opened per 1 MiB piece below, so at most one per thread is open at a time).
+ * -> size >= 0, -100 for an absent file (or an empty path), AFCODEC_E_FORMAT for an unreadable file or a range beyond its end. */
+static int64_t stat_range(const char* path, const int64_t* offsets, const int64_t* lengths, int64_t i, int64_t* off_out) {
+    *off_out = 0;
+    if (!path || !path[0]) return -100;
+    int64_t off = 0, sz = -1;
+    if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
+    struct stat stt;
+    if (stat(path, &stt) != 0) return errno_means_absent(errno) ? -100 : AFCODEC_E_FORMAT;
+    if (off < 0 || off > (int64_t)stt.st_size) return AFCODEC_E_FORMAT;
+    if (sz < 0) sz = (int64_t)stt.st_size - off;
+    if (off + sz > (int64_t)stt.st_size) return AFCODEC_E_FORMAT;
+    *off_out = off;
+    return sz;
+}
+
+/* One piece of a file: open, read, close.  -> bytes read (short = failure). */
+static int64_t read_piece_of(const char* path, uint8_t* dst, int64_t len, int64_t off, int nt_copy) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    const int64_t done = read_piece(fd, dst, len, off, nt_copy);
+    close(fd);
+    return done;
+}
+
 /* Reads and decodes byte ranges of chunk files -> dsts[i] on an OpenMP team (no Python between chunks):
  * [offsets[i], offsets[i] + lengths[i]) of paths[i]; lengths[i] < 0 (or offsets == NULL) = the whole file.
  * Ranges serve the inner chunks of Zarr v3 shards.  A missing file leaves results[i] = -100 (the caller
@@ -595,26 +627,17 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
          * cut into 1 MiB pieces and the PIECES are spread over the team — a batch of 14 files of 12.5 MB read one file
          * per thread moved 22 GB/s out of the page cache, 227 files of 1.6 MB 60 GB/s */
         enum { PIECE = 1 << 20 };
-        int* fds = (int*)malloc((size_t)n * sizeof(int));
         int64_t* first = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));   /* first piece of file i */
         int64_t* offs = (int64_t*)malloc((size_t)n * sizeof(int64_t));
-        if (!fds || !first || !offs) { free(fds); free(first); free(offs); return fail(AFCODEC_E_SIZE, "out of memory"); }
+        if (!first || !offs) { free(first); free(offs); return fail(AFCODEC_E_SIZE, "out of memory"); }
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
         for (int64_t i = 0; i < n; ++i) {
-            fds[i] = open(paths[i], O_RDONLY);
-            int64_t off = 0, sz = -1;
-            if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
-            if (fds[i] < 0) { results[i] = -100; offs[i] = 0; continue; }
-            struct stat stt;
-            if (fstat(fds[i], &stt) != 0) { results[i] = AFCODEC_E_FORMAT; close(fds[i]); fds[i] = -1; continue; }
-            if (sz < 0) sz = (int64_t)stt.st_size - off;
-            if (sz < 0 || off + sz > (int64_t)stt.st_size) { results[i] = AFCODEC_E_FORMAT; close(fds[i]); fds[i] = -1; continue; }
-            if (sz > dstsizes[i]) { results[i] = AFCODEC_E_SIZE; close(fds[i]); fds[i] = -1; continue; }
+            int64_t sz = stat_range(paths[i], offsets, lengths, i, &offs[i]);
+            if (sz >= 0 && sz > dstsizes[i]) sz = AFCODEC_E_SIZE;
             results[i] = sz;
-            offs[i] = off;
         }
         first[0] = 0;
-        for (int64_t i = 0; i < n; ++i) first[i + 1] = first[i] + (fds[i] >= 0 ? (results[i] + PIECE - 1) / PIECE : 0);
+        for (int64_t i = 0; i < n; ++i) first[i + 1] = first[i] + (results[i] > 0 ? (results[i] + PIECE - 1) / PIECE : 0);
         const int64_t npieces = first[n];
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
         for (int64_t q = 0; q < npieces; ++q) {
@@ -622,20 +645,17 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
             while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
             while (first[lo + 1] <= q) ++lo;                      /* (files without pieces share a boundary) */
             const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            const int64_t done = read_piece(fds[lo], (uint8_t*)dsts[lo] + at, len, offs[lo] + at, nt_copy_default());
+            const int64_t done = read_piece_of(paths[lo], (uint8_t*)dsts[lo] + at, len, offs[lo] + at, nt_copy_default());
             if (done != len) {
 #pragma omp atomic write
                 offs[lo] = -1;                                    /* marks the file as failed */
             }
         }
         for (int64_t i = 0; i < n; ++i) {
-            if (fds[i] >= 0) {
-                close(fds[i]);
-                if (offs[i] < 0) results[i] = AFCODEC_E_FORMAT;
-            }
+            if (results[i] >= 0 && offs[i] < 0) results[i] = AFCODEC_E_FORMAT;
             if (results[i] < 0 && results[i] != -100) bad += 1;
         }
-        free(fds); free(first); free(offs);
+        free(first); free(offs);
         if (bad) {
             for (int64_t i = 0; i < n; ++i)
                 if (results[i] == AFCODEC_E_SIZE) return fail(AFCODEC_E_CODEC, "raw chunk larger than its destination (see results[])");
@@ -649,7 +669,10 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
         const long page = sysconf(_SC_PAGESIZE);
         for (int64_t i = 0; i < n; ++i) {
             const int fd = open(paths[i], O_RDONLY);
-            if (fd < 0) { results[i] = -100; continue; }
+            if (fd < 0) {
+                if (errno_means_absent(errno)) { results[i] = -100; continue; }
+                results[i] = fail(AFCODEC_E_FORMAT, "chunk file could not be opened"); bad += 1; continue;
+            }
             int64_t off = 0, sz = -1;
             if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
             struct stat stt;
@@ -680,7 +703,10 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
 #pragma omp for schedule(dynamic, 1)
         for (int64_t i = 0; i < n; ++i) {
             FILE* f = fopen(paths[i], "rb");
-            if (!f) { results[i] = -100; continue; }
+            if (!f) {
+                if (errno_means_absent(errno)) { results[i] = -100; continue; }
+                results[i] = fail(AFCODEC_E_FORMAT, "chunk file could not be opened"); bad += 1; continue;
+            }
             int64_t off = 0, sz = -1;
             if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
             if (sz < 0) {
@@ -717,31 +743,15 @@ int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offs
     if (nthreads < 1) nthreads = 1;
     out_off[0] = 0;
     if (n == 0) return AFCODEC_OK;
-    int* fds = (int*)malloc((size_t)n * sizeof(int));
     int64_t* first = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
     int64_t* foff = (int64_t*)malloc((size_t)n * sizeof(int64_t));
-    if (!fds || !first || !foff) { free(fds); free(first); free(foff); return fail(AFCODEC_E_SIZE, "out of memory"); }
+    if (!first || !foff) { free(first); free(foff); return fail(AFCODEC_E_SIZE, "out of memory"); }
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
-    for (int64_t i = 0; i < n; ++i) {
-        fds[i] = (paths[i] && paths[i][0]) ? open(paths[i], O_RDONLY) : -1;
-        foff[i] = 0;
-        if (fds[i] < 0) { results[i] = -100; continue; }
-        int64_t off = 0, sz = -1;
-        if (offsets && lengths && lengths[i] >= 0) { off = offsets[i]; sz = lengths[i]; }
-        struct stat stt;
-        if (fstat(fds[i], &stt) != 0 || off > (int64_t)stt.st_size || (sz >= 0 && off + sz > (int64_t)stt.st_size)) {
-            results[i] = AFCODEC_E_FORMAT;
-            close(fds[i]);
-            fds[i] = -1;
-            continue;
-        }
-        results[i] = sz < 0 ? (int64_t)stt.st_size - off : sz;
-        foff[i] = off;
-    }
+    for (int64_t i = 0; i < n; ++i) results[i] = stat_range(paths[i], offsets, lengths, i, &foff[i]);
     int bad = 0;
     first[0] = 0;
     for (int64_t i = 0; i < n; ++i) {
-        const int64_t sz = fds[i] >= 0 ? results[i] : 0;
+        const int64_t sz = results[i] > 0 ? results[i] : 0;
         if (results[i] < 0 && results[i] != -100) bad += 1;
         out_off[i + 1] = out_off[i] + (sz + align - 1) / align * align;
         first[i + 1] = first[i] + (sz + PIECE - 1) / PIECE;
@@ -755,20 +765,16 @@ int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offs
             while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
             while (first[lo + 1] <= q) ++lo;
             const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            const int64_t done = read_piece(fds[lo], (uint8_t*)dst + out_off[lo] + at, len, foff[lo] + at, nt_copy);
+            const int64_t done = read_piece_of(paths[lo], (uint8_t*)dst + out_off[lo] + at, len, foff[lo] + at, nt_copy);
             if (done != len) {
 #pragma omp atomic write
                 foff[lo] = -1;                                    /* marks the file as failed */
             }
         }
     }
-    for (int64_t i = 0; i < n; ++i) {
-        if (fds[i] >= 0) {
-            close(fds[i]);
-            if (foff[i] < 0) { results[i] = AFCODEC_E_FORMAT; bad += 1; }
-        }
-    }
-    free(fds); free(first); free(foff);
+    for (int64_t i = 0; i < n; ++i)
+        if (results[i] >= 0 && foff[i] < 0) { results[i] = AFCODEC_E_FORMAT; bad += 1; }
+    free(first); free(foff);
     if (too_big) return fail(AFCODEC_E_SIZE, "read_packed: the files do not fit the buffer");
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files could not be read (see results[])") : AFCODEC_OK;
 }
@@ -786,8 +792,14 @@ int afcodec_blosc_decode_files(int64_t n, const char* const* paths, void* const*
  * LZ4, byte shuffle on request, blocks never split.  Readable by any Blosc-1 decoder. */
 int64_t afcodec_blosc_bound(int64_t nbytes, int64_t blocksize) {
     if (blocksize <= 0) blocksize = 1 << 16;                     /* the smallest automatic block */
-    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    /* the encoder rounds the block size DOWN to whole elements (and clamps it to the buffer): it may need up to twice the
+     * blocks of the nominal size, plus the short last one */
+    const int64_t nblocks = 2 * ((nbytes + blocksize - 1) / blocksize) + 2;
     return 16 + nblocks * (4 + 4 * 16) + nbytes + nbytes / 255 + 64;      /* block table + up to 16 stream headers per block */
+}
+static int64_t blosc_need(int64_t nbytes, int64_t blocksize) {           /* exact need for the block size actually used */
+    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    return 16 + nblocks * (4 + 4 * 16) + nbytes + nbytes / 255 + 64;
 }
 int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize, int shuffle, int64_t blocksize,
                                  void* dstv, int64_t cap) {
@@ -801,7 +813,11 @@ int64_t afcodec_blosc_encode_lz4(const void* srcv, int64_t nbytes, int typesize,
     blocksize -= blocksize % typesize;
     if (blocksize < typesize) blocksize = typesize;
     if (blocksize > nbytes && nbytes > 0) blocksize = nbytes;
-    if (cap < afcodec_blosc_bound(nbytes, blocksize)) return fail(AFCODEC_E_SIZE, "destination smaller than afcodec_blosc_bound()");
+    /* the clamp may have left a block that is not a whole number of elements: round down again (c-blosc's compute_blocksize
+     * does), so that a split block divides evenly into its byte planes and the remainder becomes the short, unsplit last
+     * block — a 1001-byte buffer of 4-byte elements used to lose its last byte */
+    if (blocksize > typesize) blocksize -= blocksize % typesize;
+    if (cap < blosc_need(nbytes, blocksize)) return fail(AFCODEC_E_SIZE, "destination smaller than afcodec_blosc_bound()");
     const int do_shuf = shuffle && typesize > 1;
     dst[0] = 2; dst[1] = 1; dst[3] = (uint8_t)typesize;
     put32(dst + 4, (uint32_t)nbytes);

@@ -22,7 +22,7 @@ def menu(kind):
         # sine degree days ride on the min/max accumulators; generic pow() only in the
         # all-purpose (STAT 3) variants; bit 2 = nt cache policy on the streaming loads;
         # bit 3 = integer bin counters; bit 4 = single-level plan (no outer accumulators)
-        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0)
+        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0) | (512 if ss == 2 else 0)
         key = (dtype, pipe, vec, stat, nthr, kmax, depth, feat)
         for i, v in enumerate(out):
             if v[:8] == key:
@@ -90,16 +90,26 @@ def menu(kind):
     for dtype in (() if kind == "dev" else (0, 1)):
         for (vec, depth) in (((1, 8), (1, 16), (2, 4), (2, 8)) if dtype == 1 else ((1, 12), (1, 16), (1, 24), (2, 8), (2, 16))):
             add(dtype, 0, vec, 0, 16, 16, depth, tki=1, sl=1, hb=1, ha=1, prod=0)
-        # (tmin, tmax) pairs whose columns are all sine_dd -> sum: the lean group end (FEAT bit 8)
+        # f32, two cells per lane, FOUR rows in flight: +2.6 % over eight on multi-column plans on large grids (configs[1] on float32
+        # storage: 6.31 vs 6.15 TB/s, profiles/r03_sweep_chunks_depth.txt); small grids keep eight (5.73 vs 5.41)
+        if dtype == 0:
+            for (stat, nthr, kmax) in [(st, nt_, km) for st in (0, 1, 3) for nt_ in (0, 1) for km in (2, 6) if not (st == 0 and nt_ == 0)] + [(2, 0, 2), (2, 0, 6)]:
+                add(dtype, 0, 2, stat, nthr, kmax, 4)
+        # (tmin, tmax) pairs with the lean group end (FEAT bit 8): sine_dd / min / max sources (stat 2) and mean / sum alone (stat 1)
         for (vec, depth) in (((1, 4), (1, 8)) if dtype == 1 else ((2, 8), (1, 8), (2, 4))):
-            add(dtype, 0, vec, 2, 0, 2, depth, pair=1, ss=1, prod=1 if (vec, depth) in ((1, 4), (2, 8), (1, 8)) and not (dtype == 1 and depth == 8) else 0)
+            prod = 1 if (vec, depth) in ((1, 4), (2, 8), (1, 8)) and not (dtype == 1 and depth == 8) else 0
+            add(dtype, 0, vec, 2, 0, 2, depth, pair=1, ss=2, prod=prod)      # every column a plain sine_dd (configs[4])
+            add(dtype, 0, vec, 2, 0, 2, depth, pair=1, ss=1, prod=prod)
+            add(dtype, 0, vec, 2, 0, 6, depth, pair=1, ss=1, prod=prod)
+            add(dtype, 0, vec, 1, 0, 2, depth, pair=1, ss=1, prod=prod)
+            add(dtype, 0, vec, 1, 0, 6, depth, pair=1, ss=1, prod=prod)
     return out
 
 
 def name_of(v):
     dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
     return (f"{'f32' if dtype == 0 else 'f64'}_p{pipe}_v{vec}_s{stat}_t{nthr}_k{kmax}_d{depth}" + ("_nt" if feat & 4 else "")
-            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 256 else ""))
+            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 512 else ("_lean" if feat & 256 else "")))
 
 
 def inst(v):
@@ -162,7 +172,7 @@ def main():
             f.write(f"int register_variants_{idx:02d}(Variant* out) {{\n    int n = 0;\n")
             for v in group:
                 dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
-                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {1 if feat & 256 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
+                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {2 if feat & 512 else (1 if feat & 256 else 0)}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
             f.write("    return n;\n}\n}\n")
         files.append(fn)
     with _KeepIfSame(os.path.join(outdir, "variants_table.hip")) as f:

@@ -287,8 +287,12 @@ class Dataset:
         import torch
         from . import hip
         x = self._hbm_time_major()
-        # NumPy 2 promotion: float32 ** np.int64 / np.float64 scalar -> float64; a Python scalar keeps float32
-        out_dtype = torch.float64 if (isinstance(exp, np.generic) and exp.dtype.itemsize == 8) else x.dtype
+        # NumPy 2 promotion of np.power(block, exp): a Python scalar is weak (float32 stays float32); a NumPy scalar brings its
+        # dtype (np.int32 / np.int64 / np.float64 promote float32 to float64, np.int16 / np.float32 do not)
+        out_dtype = x.dtype
+        if isinstance(exp, np.generic):
+            promoted = np.result_type(np.float32 if x.dtype == torch.float32 else np.float64, exp.dtype)
+            out_dtype = torch.float64 if promoted == np.float64 else x.dtype
         out = hip.transform(x, "pow", float(exp), out_dtype=out_dtype)
         return self._transformed(out, f"power{exp}", update)
 

@@ -656,8 +656,19 @@ def _stream_chunks_scatter(za: "ZarrArray", device, threads: int, slab_bytes: in
     (`_scatter_gpu_decode`, `_gpu_decodable`)."""
     job = _ScatterJob(za, device, out_dtype, t_range, yx_box)
     if _gpu_decodable(za, len(job.idxs) * job.cb):
-        return _scatter_gpu_decode(job, threads, post)
+        try:
+            return _scatter_gpu_decode(job, threads, post)
+        except _NotForTheGpuRoute:
+            # `_gpu_decodable` judged the store by its first chunk; a later one differs (another codec, bit shuffle, another
+            # block size).  include/aggfly_codec.h's contract for such a chunk is "decode it on the host": the whole
+            # request goes through the host route (the GPU route has drained its streams before raising, so nothing is
+            # still writing the cube), and so do later requests on this array
+            za._gpu_decodable = False
     return _scatter_host_decode(job, threads, slab_bytes, post)
+
+
+class _NotForTheGpuRoute(Exception):
+    """A chunk of the request cannot be decoded in HBM (raised by `_scatter_gpu_decode` after it has drained its streams)."""
 
 
 def _scatter_host_decode(job: _ScatterJob, threads: int, slab_bytes: int, post):
@@ -760,6 +771,44 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     origin = torch.cuda.Event(enable_timing=True)
     if trace.on:
         origin.record(copy_stream)
+
+    def drain():
+        # earlier batches' uploads and kernels may still be in flight on the copy / work streams: nothing of this request
+        # (cube, staging, page-locked slots) may go back to its pool — or to a retry on the host route — before they are done
+        copy_stream.synchronize()
+        for ws in two:
+            ws.synchronize()
+
+    try:
+        _gpu_decode_batches(job, threads, cuts, per, cmax, cap_streams, cap_blocks, nstage, host, comp_dev, tmp_dev, staged, errors,
+                            copy_stream, work_streams, done, uploaded, trace, cube_bytes)
+    except BaseException:
+        drain()
+        raise
+    last = two[0]
+    for ws in two[1:]:
+        last.wait_stream(ws)
+    with torch.cuda.stream(last):
+        if post is not None:
+            post(cube)
+    trace.skip()
+    last.synchronize()
+    copy_stream.synchronize()
+    trace.drained()
+    trace.report(origin, gpu_decode=True, batches=len(cuts) - 1, chunks_per_batch=per)
+    if int(errors.item()):
+        raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
+                               "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")
+    torch.cuda.current_stream(device).wait_stream(last)
+    return cube
+
+
+def _gpu_decode_batches(job, threads, cuts, per, cmax, cap_streams, cap_blocks, nstage, host, comp_dev, tmp_dev, staged, errors,
+                        copy_stream, work_streams, done, uploaded, trace, cube_bytes):
+    """The batch loop of `_scatter_gpu_decode` (which drains the streams if anything here raises)."""
+    import torch
+    from . import codec, hip
+    za, device, cb, idxs = job.za, job.device, job.cb, job.idxs
     for b, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
         batch = idxs[lo:hi]
         k = b % nstage
@@ -780,13 +829,18 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
         direct = job.whole_steps and all(job.inside(it) for it, _, _ in batch)
         out_offs = (np.array([batch[i][0] * job.tc - job.ka for i in present], dtype=np.int64) * job.step_bytes if direct
                     else present.astype(np.int64) * cb)
-        n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[:-1][present], sizes[present], out_offs,
-                                                                    np.full(len(present), cb, dtype=np.int64), streams, blocks)
+        try:
+            n_st, n_bl, tmp_bytes, max_d, pres = codec.blosc_lz4_plan(hall, offs[:-1][present], sizes[present], out_offs,
+                                                                        np.full(len(present), cb, dtype=np.int64), streams, blocks)
+        except codec.PlanCapacityError:
+            raise _NotForTheGpuRoute() from None
+        if (pres == codec.E_UNSUPPORTED).any() or tmp_bytes > tmp_dev[k].numel() or n_st > cap_streams or n_bl > cap_blocks:
+            # a chunk the GPU decoder does not take (aggfly_codec.h: "decode it on the host"), or one whose geometry differs
+            # from the first chunk's, which sized the buffers: the request falls back to the host route
+            raise _NotForTheGpuRoute()
         if (pres != cb).any():
             badc = [za.chunk_locator(batch[int(present[i])])[0] for i in np.nonzero(pres != cb)[0][:4]]
-            raise codec.CodecError(f"chunks {badc} cannot take the GPU decode route or decode to another size than {cb} bytes "
-                                   "(AGGFLY_HIP_GPU_DECODE=0 decodes on the host)")
-        assert tmp_bytes <= tmp_dev[k].numel()
+            raise codec.CodecError(f"chunks {badc} are damaged or decode to another size than {cb} bytes")
         trace.lap("plan")
         # ---- upload (copy stream), then decode + placement (the slot's stream) ----
         with torch.cuda.stream(copy_stream):
@@ -820,22 +874,6 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
             if trace.on:
                 trace.batches[-1]["k1"].record(work_streams[k])
         trace.lap("enqueue")
-    last = two[0]
-    for ws in two[1:]:
-        last.wait_stream(ws)
-    with torch.cuda.stream(last):
-        if post is not None:
-            post(cube)
-    trace.skip()
-    last.synchronize()
-    copy_stream.synchronize()
-    trace.drained()
-    trace.report(origin, gpu_decode=True, batches=len(cuts) - 1, chunks_per_batch=per)
-    if int(errors.item()):
-        raise codec.CodecError(f"{int(errors.item())} LZ4 stream(s) of {za.path} are malformed (GPU decode); "
-                               "AGGFLY_HIP_GPU_DECODE=0 decodes on the host and names the chunk")
-    torch.cuda.current_stream(device).wait_stream(last)
-    return cube
 
 
 def _decode_time(values, attrs):

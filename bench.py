@@ -148,7 +148,10 @@ def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
     cores = min(cores, ny_sample)          # OpenMP runs over grid rows, like numba's prange
     return {"value": T * ny_sample * nx / dt, "unit": "grid-cell-timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{ny_sample}x{nx} latitude band of the workload grid, T={T}, fp64, {reps} passes of {dt:.2f} s "
-                      f"(C/OpenMP port of the reference's numba engine, oracle/c)"}
+                      f"(C/OpenMP port of the reference's numba engine, oracle/c: `omp parallel for` over the band's {ny_sample} grid rows like "
+                      "prange(NY), each cell walking time with the reference's stride of a whole grid row — cache-hostile, and on this band "
+                      "SLOWER than the vectorised numpy restatement of the dask path, whereas the reference's real numba engine is ~12x "
+                      "faster than its dask engine (internal/backend-plan.md:4): not a stand-in for numba's speed, only for its arithmetic)"}
 
 
 def cpu_baseline_dask_path(T, ny_sample, nx, seed, target_s=8.0):
@@ -260,7 +263,7 @@ def run_ingest(torch):
     return out
 
 
-def run_other_configs(torch, steps=5, warmup=2):
+def run_other_configs(torch, steps=10, warmup=10):      # the first ~10 launches after idle run up to 15 % slow (clock ramp: scripts/probe/back_to_back.py)
     from aggfly_amd import hip, synth
     out = []
     valu = _valu_counts()
@@ -282,6 +285,14 @@ def run_other_configs(torch, steps=5, warmup=2):
                                  "sine_dd[10,30]@date->sum@year, f32 storage, K=1",
              T=730, ny=1801, nx=3600, spd=2, periods=1, R=40000, dtype="f32", secondary=False,
              cols=[dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum")]),
+        # the ONE workload the reference published a number for (/root/reference/benchmarks/bench_engine.py:19-23,60-69 ->
+        # internal/backend-plan.md:4-5): temporal stage of mean@date -> power[1..4] -> sum@month on one year of GLOBAL 0.25 deg
+        # hourly float32.  Here the whole path runs (the spatial stage too), on a synthetic field of that shape.
+        dict(name="REF", workload="the reference's own published benchmark shape (benchmarks/bench_engine.py): hourly float32, 1 year, GLOBAL 0.25 deg "
+                                  "721x1440 cells (36.4 GB resident), mean@date->power[1..4]->sum@month, K=4, P=12, + 3100 regions here; published for "
+                                  "the temporal stage alone on a 32-core CPU: 15.2 s (numba engine) / 179 s (dask engine), internal/backend-plan.md:4-5",
+             T=8760, ny=721, nx=1440, spd=24, periods=12, months=True, R=3100, dtype="f32", secondary=False,
+             cols=[dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]),
     ]
     only = os.environ.get("AGGFLY_BENCH_ONLY")          # e.g. "C5": one config (PMC passes over a single kernel)
     for c in cfgs:
@@ -297,6 +308,8 @@ def run_other_configs(torch, steps=5, warmup=2):
             ib = synth.hourly_bounds(T, c["spd"])
             G1 = len(ib) - 1
             ob = np.round(np.linspace(0, G1, c["periods"] + 1)).astype(np.int64)
+            if c.get("months"):                                         # calendar months of a 365-day year
+                ob = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])]).astype(np.int64)
             if c.get("single_level"):
                 ib, ob = ib[ob], np.arange(c["periods"] + 1, dtype=np.int64)
             tab = synth.weights_table(ny, nx, c["R"], seed=7, secondary=c["secondary"])
@@ -552,13 +565,26 @@ def main():
             cands.sort(key=lambda c: -(c["value"] or 0.0))
             line["cpu_baseline"] = cands[0]
             line["cpu_baseline_other_engine"] = cands[1]
+            if cands[0]["value"] and cands[1]["value"]:
+                line["cpu_baseline"]["sample"] += (f" | the faster of two restatements of the reference's CPU engines ({cands[0]['value'] / cands[1]['value']:.1f}x the "
+                                                   "other, see cpu_baseline_other_engine); a stated baseline, not the target")
         if world == 1 and not args.no_other_configs and (T, ny, nx) == (8760, 215, 1440):
             del cube
             torch.cuda.empty_cache()
             line["other_configs"] = run_other_configs(torch)
+            # the same figures where the driver's record keeps them (it stores `roofline` whole): every BASELINE shape's fraction of
+            # its bounding roofline, kernel time and whole-pass time
+            line["roofline"]["other"] = {
+                r["config"]: ({"bound": r["bound"], "frac": r["frac"], "hbm_frac": r.get("hbm_frac", r["frac"]), "kernel_ms_mean": r["kernel_ms_mean"],
+                               "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "kernel": r["kernel"]} if "error" not in r else {"error": r["error"]})
+                for r in line["other_configs"]}
             if not args.no_ingest:
                 try:
                     line["ingest"] = run_ingest(torch)
+                    f0 = next(iter(line["ingest"]["fields"].values()))
+                    line["roofline"]["ingest"] = {"workload": "configs[0] store (RAM) -> HBM, decoded GB/s, noisy bench field",
+                                                  "hbm_decode_GBps": f0["chunks_decoded_in_hbm"]["GBps"],
+                                                  "host_decode_GBps": f0["chunks_decoded_on_host_threads"]["GBps"]}
                 except Exception as e:      # the ingest figure must never take the headline down with it
                     line["ingest"] = {"failed": repr(e)}
         print(json.dumps(line), flush=True)

@@ -32,7 +32,9 @@ def columns(plan):
         return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)], False
     if plan == "mean":      # daily mean of short groups -> annual sum (tmin/tmax pairs, 6-hourly data)
         return [dict(inner="mean", outer="sum")], False
-    raise SystemExit("plan must be c1, c2, c4, c5 or mean")
+    if plan == "meanpoly":  # the polynomial of the daily mean (of tmin / tmax pairs, of 6-hourly steps ...) -> annual sum
+        return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)], False
+    raise SystemExit("plan must be c1, c2, c4, c5, mean or meanpoly")
 
 
 def main():

@@ -385,3 +385,59 @@ def test_read_packed_packs_ranges_of_files_back_to_back(tmp_path):
         codec.read_packed([(paths[0], 0, 2)], dst, 64)
     o, z = codec.read_packed([], dst, 64)
     assert o.tolist() == [0] and len(z) == 0
+
+
+def test_batches_larger_than_the_descriptor_limit_read_every_file(tmp_path):
+    """A batch may hold thousands of chunk files (io.py: up to 4096 per request) while RLIMIT_NOFILE is 1024 on most hosts.
+    The batch readers used to open every file of a batch first; past the limit `open` failed with EMFILE, the file was
+    reported as ABSENT (-100) and the caller filled existing chunks with the fill value — no error, wrong weighted means.
+    Now no descriptor is kept (one per thread and 1 MiB piece), and only "no such file" ever means absent."""
+    import resource
+    n = 400
+    paths = []
+    for i in range(n):
+        p = tmp_path / f"c{i}"
+        p.write_bytes(bytes([i % 251]) * 1024)
+        paths.append(str(p))
+    locs = [(p, 0, -1) for p in paths] + [(str(tmp_path / "never_written"), 0, -1), None]
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    resource.setrlimit(resource.RLIMIT_NOFILE, (64, hard))
+    try:
+        dst = np.zeros((n + 2) * 1024, dtype=np.uint8)
+        off, res = codec.read_packed(locs, dst, align=64, threads=8)
+        outs = [np.zeros(1024, dtype=np.uint8) for _ in locs]
+        got = codec.decode_ranges("raw", locs, outs, threads=8, exact=False)
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+    assert list(res[:n]) == [1024] * n and list(res[n:]) == [-100, -100]
+    assert got[:n] == [1024] * n and got[n:] == [-100, -100]
+    for i in range(n):
+        assert dst[off[i]] == i % 251 and dst[off[i] + 1023] == i % 251 and outs[i][0] == i % 251 and outs[i][-1] == i % 251
+
+
+def test_unreadable_file_is_an_error_not_an_absent_chunk(tmp_path):
+    """EACCES / EISDIR and friends must raise; only ENOENT / ENOTDIR mean "this chunk was never written"."""
+    d = tmp_path / "a_directory"
+    d.mkdir()
+    for fn in (lambda: codec.read_packed([(str(d), 0, -1)], np.zeros(64, dtype=np.uint8)),
+               lambda: codec.decode_ranges("zlib", [(str(d), 0, -1)], [np.zeros(64, dtype=np.uint8)], exact=False)):
+        with pytest.raises(codec.CodecError):
+            fn()
+    # a path THROUGH a regular file (ENOTDIR) is an absent chunk, like a missing file
+    f = tmp_path / "plain"
+    f.write_bytes(b"x" * 10)
+    _, res = codec.read_packed([(str(f / "0.0.0"), 0, -1)], np.zeros(64, dtype=np.uint8))
+    assert list(res) == [-100]
+
+
+@pytest.mark.parametrize("n, typesize", [(1001, 4), (4099, 4), (70001, 8), (131, 8), (65536 * 4 + 3, 4), (1000003, 255)])
+@pytest.mark.parametrize("blocksize", [0, 1001, 4096])
+def test_encoder_keeps_the_bytes_beyond_the_last_whole_element(n, typesize, blocksize):
+    """A buffer that is not a whole number of elements: the clamped block size is rounded down to whole elements again
+    (c-blosc's compute_blocksize), the remainder travels in the short, unsplit last block — a split block used to drop it."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 255, n, dtype=np.uint8)
+    a[: n // 2] = 7
+    enc = codec.blosc_encode(a.tobytes(), typesize=typesize, shuffle=True, blocksize=blocksize)
+    assert len(enc) <= codec.load().afcodec_blosc_bound(n, blocksize)
+    assert bytes(codec.blosc_decode(enc)) == a.tobytes()

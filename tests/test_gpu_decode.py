@@ -215,3 +215,27 @@ def test_format3_stores_and_shards_decode_in_hbm(torch_cuda, tmp_path, monkeypat
     np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)
     win = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03 05:00", "2001-01-09 11:00"))
     np.testing.assert_array_equal(win.cube().cpu().numpy(), cube[53:204])
+
+
+def test_chunk_of_another_geometry_sends_the_request_to_the_host_route(torch_cuda, tmp_path, monkeypatch):
+    """`_gpu_decodable` judges a store by its FIRST chunk and sizes the route's buffers from it.  A later chunk written with
+    another block size (or another inner codec) does not fit them / is not taken by the GPU decoder: the contract of
+    include/aggfly_codec.h for such a chunk is "decode it on the host".  The request must then come out right through the
+    host route — after the batches already in flight on the copy / kernel streams have drained — instead of raising
+    mid-loop (round 2) or, worse, writing past the staging buffers."""
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", "1")
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "1")         # several batches: the odd chunk is met mid-request
+    T, ny, nx = 24 * 30, 40, 64
+    cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=5, scattered_nan=40) + np.float32(273.15)
+    path = _store(tmp_path, "odd.zarr", cube, {"time": 48, "latitude": ny, "longitude": nx})
+    odd = os.path.join(path, "t2m", "9.0.0")
+    assert os.path.exists(odd)
+    with open(odd, "wb") as f:                                        # same data, 4 KiB blocks: 30x the streams the buffers were sized for
+        f.write(codec.blosc_encode(cube[9 * 48:10 * 48].tobytes(), typesize=4, shuffle=True, blocksize=4096))
+    kinds = []
+    real, real_packed = codec.decode_ranges, codec.read_packed
+    monkeypatch.setattr(codec, "decode_ranges", lambda kind, locs, outs, threads=8, exact=True: kinds.append(kind) or real(kind, locs, outs, threads, exact))
+    monkeypatch.setattr(codec, "read_packed", lambda locs, dst, align=64, threads=8: kinds.append("files as they are") or real_packed(locs, dst, align, threads))
+    got = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
+    assert "files as they are" in kinds and "blosc" in kinds, kinds   # started on the GPU route, finished on the host route
+    np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)

@@ -640,3 +640,66 @@ def test_skewed_rows_take_the_wave_and_segment_paths(torch_cuda):
     direct = plan.run(dd, csr)["res"].cpu().numpy()
     via_panel = plan.run(dd, csr, want_cells=True)["res"].cpu().numpy()
     np.testing.assert_allclose(direct, via_panel, rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(2 * 61, 6, 20), (2 * 61, 5, 7)])
+def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
+    """(tmin, tmax) pairs: every inner group is two rows (configs[4]; the reference's daily mean of tmin and tmax,
+    `temporal.py:99-125`).  Plans whose columns are  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  take the
+    lean group end (FEAT bit 8); a column that needs anything else (hinge, an outer min, float32 rounding) sends the plan to the
+    generic pair form or, for sum-only plans, off the pair path.  All of them against the oracle: statistics bit-exact (same
+    operation order: s = u + v, mean = s / 2), integer powers within 4e-16 (np.power's libm vs the double-double chain), sine 1e-10;
+    NaN pairs give NaN periods; several outer periods in one chunk and periods split over chunks."""
+    from aggfly_amd import hip
+    T, ny, nx = shape
+    rng = np.random.default_rng(17)
+    day = 15 + 10 * np.sin(2 * np.pi * np.arange(T // 2) / 365.0)
+    cube = np.empty((T, ny, nx))
+    cube[0::2] = day[:, None, None] - 5 + rng.normal(0, 3, (T // 2, ny, nx))
+    cube[1::2] = day[:, None, None] + 6 + rng.normal(0, 3, (T // 2, ny, nx))
+    cube[rng.integers(0, T, 9), rng.integers(0, ny, 9), rng.integers(0, nx, 9)] = np.nan
+    cube[:, 1, 2] = np.nan
+    cube = cube.astype(dtype)
+    ib = np.arange(0, T + 1, 2, dtype=np.int64)
+    ob = np.array([0, 20, 21, 61], dtype=np.int64)             # three periods: 20 days, one day, 40 days
+    d = torch_cuda.from_numpy(cube).cuda()
+    f64 = cube.astype(np.float64)
+
+    def want(col):
+        x = cport.resample(f64, ib, col["inner"], col.get("inner_args"))
+        if col.get("transform") == "pow":
+            x = cport.power(x, col["transform_arg"])
+        elif col.get("transform") == "hinge":
+            x = (x > col["transform_arg"]) * (x - col["transform_arg"])
+        return cport.resample(x, ob, col["outer"])
+
+    lean = [dict(inner="mean", outer="sum"), dict(inner="mean", transform="pow", transform_arg=2, outer="sum"),
+            dict(inner="mean", transform="pow", transform_arg=3, outer="mean"), dict(inner="sum", outer="sum")]
+    lean2 = [dict(inner="min", outer="sum"), dict(inner="max", transform="pow", transform_arg=2, outer="mean"),
+             dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="mean", outer="mean")]
+    generic = [dict(inner="mean", transform="hinge", transform_arg=20.0, outer="sum"), dict(inner="max", outer="max"),
+               dict(inner="sine_dd", inner_args=(0, 18, 1), outer="sum")]
+    sum_only_generic = [dict(inner="mean", outer="max"), dict(inner="sum", transform="hinge", transform_arg=20.0, outer="sum")]
+    sine_only = [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="sine_dd", inner_args=(0, 18, 1), outer="mean")]
+    light = [dict(inner="mean", outer="sum")]                  # one or two mean / sum columns stream through the LDS-DMA ring instead
+    for cols, expect in ((lean, "_pair_lean"), (lean2, "_pair_lean"), (sine_only, "_pair_ss"), (generic, "_pair"), (sum_only_generic, None), (light, None)):
+        plan = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols, exact_order=True)
+        name = plan.describe().split()[0]
+        if expect is None:
+            assert "_pair" not in name, name
+        else:
+            assert name.endswith(expect), name
+        got = plan.run_temporal(d).cpu().numpy()                 # [K, P, cells]
+        for k, col in enumerate(cols):
+            w = want(col).reshape(len(ob) - 1, -1)
+            assert np.array_equal(np.isnan(got[k]), np.isnan(w)), (name, col)
+            if col["inner"] == "sine_dd":
+                np.testing.assert_allclose(got[k], w, rtol=1e-10, atol=1e-10, equal_nan=True)
+            elif col.get("transform") == "pow":
+                np.testing.assert_allclose(got[k], w, rtol=4e-15, equal_nan=True)
+            else:
+                np.testing.assert_array_equal(got[k], w)
+        # the same plan with periods free to split over chunks: only the association of the outer sum changes
+        free = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols).run_temporal(d).cpu().numpy()
+        np.testing.assert_allclose(free, got, rtol=1e-12, atol=1e-12, equal_nan=True)
