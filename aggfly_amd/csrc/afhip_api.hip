@@ -109,18 +109,18 @@ int pointer_device(const void* p) {
     return at.device;
 }
 
-// The acos table of sine_theta (afhip_kernels.h), in the layout the kernel copies into LDS: 2 halves x SINE_ROWS rows of
-// (C, S, TH, 0).  Row k of either half belongs to phi_k = asin(k / 256):
-//   half 0 (a <= g: theta = pi/2 - asin(u)):  (-cos phi_k, +sin phi_k, pi/2 - phi_k)
-//   half 1 (a >  g: theta = asin(u)):         (+cos phi_k, -sin phi_k, phi_k)
+// The acos table of sine_theta (afhip_kernels.h), in the layout the kernel copies into LDS: SINE_ROWS pairs of rows
+// (C, S, TH, 0); pair k belongs to phi_k = asin(k / 256):
+//   row 2k     (a <= g: theta = pi/2 - asin(u)):  (-cos phi_k, +sin phi_k, pi/2 - phi_k)
+//   row 2k + 1 (a >  g: theta = asin(u)):         (+cos phi_k, -sin phi_k, phi_k)
 std::vector<double> sine_table_host() {
     std::vector<double> t((size_t)2 * SINE_ROWS * 4, 0.0);
     for (int k = 0; k < SINE_ROWS; ++k) {
         const double sn = std::min(1.0, (double)k / (double)SINE_SCALE);
         const double cs = std::sqrt((1.0 - sn) * (1.0 + sn));
         const double phi = std::asin(sn);
-        double* lo = &t[(size_t)k * 4];
-        double* hi = &t[((size_t)SINE_ROWS + k) * 4];
+        double* lo = &t[(size_t)(2 * k) * 4];               // the two cases of a k sit next to each other (sine_theta's row address)
+        double* hi = &t[(size_t)(2 * k + 1) * 4];
         lo[0] = -cs; lo[1] = sn; lo[2] = 1.57079632679489661923 - phi;
         hi[0] = cs; hi[1] = -sn; hi[2] = phi;
     }
@@ -625,6 +625,23 @@ static int lower_columns(afhip_plan* pl) {
 // Chunking.  target_len = time steps a workgroup should stream; a long period is cut on
 // inner-group boundaries into pieces (each emits a partial), short consecutive periods are
 // packed into one chunk (each emits its own final value).
+static int lay_chunks(afhip_plan* pl, int64_t want_chunks);
+
+// dynamic LDS of a launch of the plan's variant with pl->wg threads per workgroup
+static size_t plan_lds_bytes(const afhip_plan* pl) {
+    size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
+    if (pl->has_sine) lds += SINE_TAB_BYTES;            // the acos table, behind the ring (variants with stat >= 2 carry the code)
+    if (pl->variant->hb) lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
+    return lds;
+}
+
+// workgroups of the plan's variant one CU holds at once (registers, LDS, wave slots)
+static int resident_wgs_per_cu(const afhip_plan* pl) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pl->variant->fn, pl->wg, plan_lds_bytes(pl)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 static int build_chunks(afhip_plan* pl, int vec) {
     const auto& ib = pl->ib;
     const auto& ob = pl->ob;
@@ -646,7 +663,40 @@ static int build_chunks(afhip_plan* pl, int vec) {
     if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
     const int64_t want_wgs = (int64_t)cu_count(pl->device) * per_cu * (WG / pl->wg);
     const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
-    const int64_t target_len = std::max<int64_t>(64, T / want_chunks);
+    int rc = lay_chunks(pl, want_chunks);
+    if (rc) return rc;
+    // Rounds.  A CU holds `resident` workgroups of this variant at once; a grid of more workgroups than the chip holds runs in
+    // "rounds", and a last round that is mostly empty is paid in full: the reference's own benchmark shape (global 0.25 deg,
+    // 2,028 tiles as ONE chunk against 1,536 resident workgroups = 1.32 rounds) ran at 0.65 of the HBM peak, as three chunks
+    // (3.96 rounds) at 0.79 (profiles/r03_ref_shape_arms.txt).  When the grid does not fit the chip at once, take the chunk
+    // count (of the next few) whose last round is fullest; a grid that fits keeps the fewest chunks, which measured best.
+    if (!getenv("AFHIP_NO_ROUND_FILL") && !getenv("AFHIP_WGS_PER_CU")) {
+        const int64_t capacity = (int64_t)resident_wgs_per_cu(pl) * cu_count(pl->device);
+        auto fill = [&](int64_t total) { const int64_t rounds = (total + capacity - 1) / capacity; return (double)total / (double)(rounds * capacity); };
+        int64_t total = pl->tiles * (int64_t)pl->chunks.size();
+        if (capacity > 0 && total > capacity && fill(total) < 0.92) {
+            int64_t best_c = want_chunks;
+            double best = fill(total);
+            size_t last_n = pl->chunks.size();
+            for (int64_t c = want_chunks + 1; c <= want_chunks + 12 && best < 0.92; ++c) {
+                if ((rc = lay_chunks(pl, c))) return rc;
+                if (pl->chunks.size() == last_n) continue;         // (period boundaries: not every count exists)
+                last_n = pl->chunks.size();
+                const double f = fill(pl->tiles * (int64_t)pl->chunks.size());
+                if (f > best + 1e-9) { best = f; best_c = c; }
+            }
+            if ((rc = lay_chunks(pl, best_c))) return rc;
+        }
+    }
+    return AFHIP_OK;
+}
+
+// Chunk table for ~want_chunks time chunks (see build_chunks).
+static int lay_chunks(afhip_plan* pl, int64_t want_chunks) {
+    const auto& ib = pl->ib;
+    const auto& ob = pl->ob;
+    const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T;
+    const int64_t target_len = std::max<int64_t>(64, T / std::max<int64_t>(want_chunks, 1));
     // splitting a period adds partial traffic (16 B per extra slot, column and cell, write +
     // read); keep it under ~5 % of the cube: extra_slots*K*16 <= 0.05*T*elem.  (2 % starved the
     // CONUS-window f32 plan of workgroups: 9 chunks 0.229 ms, 22 chunks 0.151 ms.)
@@ -1021,8 +1071,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     for (int j = 0; j < MAX_COLS; ++j) { fa.pk_word[j] = pl->pk.word[j]; fa.pk_shift[j] = pl->pk.shift[j]; }
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
-    size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
-    if (pl->has_sine) lds += SINE_TAB_BYTES;            // the acos table, behind the ring (variants with stat >= 2 carry the code)
+    const size_t lds = plan_lds_bytes(pl);
     if (pl->variant->hb) {
         fa.hb_n = pl->hb_n; fa.hb_c1 = pl->hb_c1; fa.hb_c0 = pl->hb_c0;
         fa.hb_c1f = (float)pl->hb_c1; fa.hb_c0f = (float)pl->hb_c0;
@@ -1037,7 +1086,6 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         }
         fa.hb_w = pl->hb_w; fa.hb_lo0 = pl->hb_lo0; fa.hb_gl = pl->hb_gl; fa.hb_gh = pl->hb_gh;
         fa.hb_wf = (float)pl->hb_w; fa.hb_lo0f = (float)pl->hb_lo0; fa.hb_glf = (float)pl->hb_gl; fa.hb_ghf = (float)pl->hb_gh;
-        lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
     }
     HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;

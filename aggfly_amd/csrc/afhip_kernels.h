@@ -263,7 +263,8 @@ __device__ __forceinline__ double max0_neg(double x) {
 // and theta = acos(a) is asin(u) when g is the smaller one, pi/2 - asin(u) otherwise.  Both cases are one table row
 // (C, S, TH) per (half, k):  theta = TH + asin(u C + w S)   with
 //   a <= g:  C = -cos(phi_k), S = +sin(phi_k), TH = pi/2 - phi_k          a > g:  C = +cos(phi_k), S = -sin(phi_k), TH = phi_k
-// (host: afhip_api.hip:sine_table_host; 2 x 184 rows of 32 bytes, copied into LDS by every workgroup of a sine_dd plan).
+// (host: afhip_api.hip:sine_table_host; 184 x 2 rows of 32 bytes, the two cases of a k next to each other, copied into LDS by
+// every workgroup of a sine_dd plan).
 // 11 fp64 + 3 integer instructions and two LDS reads.  Checked on the host against the reference's libm form by
 // scripts/fit/arc_table_emulation.py (1.9e-13 absolute on values of order 1-30) and on the device by scripts/sine_accuracy.py.
 constexpr int SINE_SCALE = 256;
@@ -281,21 +282,25 @@ __device__ __forceinline__ double sqrt_unit(double q) {
     const double r = __fma_rn(-h, g, 0.5);
     return __fma_rn(g, r, g);
 }
-// acos(a) for 0 <= a <= 1 given g = sqrt(1 - a^2)
+// acos(a) for 0 <= a <= 1 given g = sqrt(1 - a^2).  CLAMP = false: the caller guarantees a <= 1 or NaN (pair mode: the arc is
+// only evaluated where the threshold lies strictly inside the window, so |thr - tavg| < alpha; a NaN a gives k = 0), and the row
+// index needs no bound; the generic form may be handed |r| up to 2 (the reference's heating form, NaN there) and keeps it.
+template <bool CLAMP = true>
 __device__ __forceinline__ double sine_theta(double a, double g, sine_tab_t tab) {
     static_assert(SINE_SCALE == 256, "the index trick below adds 2^44 = 2^52 / 256");
     const double u = __builtin_fmin(a, g), w = __builtin_fmax(a, g);
     const double t = u + 17592186044416.0;                                      // + 2^44 (ulp 2^-8): the sum's low word is round(256 u)
     uint32_t k = (uint32_t)__double2loint(t);
-    k = k < (uint32_t)(SINE_ROWS - 1) ? k : (uint32_t)(SINE_ROWS - 1);          // NaN / out-of-range operands stay inside the table
-    // row address = base of the half + 32 k: one v_cndmask between the two bases (loop-invariant) and one v_lshl_add_u32
-    const uint32_t lo_base = (uint32_t)(uintptr_t)tab, hi_base = lo_base + (uint32_t)(SINE_ROWS * sizeof(SineRow));
-    sine_tab_t row = (sine_tab_t)(uintptr_t)lshl_add((a <= g) ? lo_base : hi_base, k, 5);
+    if (CLAMP) k = k < (uint32_t)(SINE_ROWS - 1) ? k : (uint32_t)(SINE_ROWS - 1);   // NaN / out-of-range operands stay inside the table
+    // the two cases of a k are neighbouring rows (row 2k: a <= g, row 2k + 1: a > g): row address = 64 k + base + (0 | 32)
+    const uint32_t base = (uint32_t)(uintptr_t)tab;
+    const uint32_t half = (a <= g) ? base : base + (uint32_t)sizeof(SineRow);       // (v_mov of the second base + v_cndmask)
+    sine_tab_t row = (sine_tab_t)(uintptr_t)lshl_add(half, k, 6);
     const double C = row->C, S = row->S, TH = row->TH;
     const double delta = __fma_rn(u, C, w * S);
     const double t2 = delta * delta;
     const double p = fma_vsv(t2, 0.075, 0.16666666666666666);
-    return TH + __fma_rn(delta * t2, p, delta);
+    return __fma_rn(delta, __fma_rn(t2, p, 1.0), TH);            // TH + delta (1 + t2 p): four instructions from delta
 }
 __device__ __forceinline__ double sine_arc(double d, double x, double alpha, sine_tab_t tab) {
     const double HALF_PI = 1.57079632679489661923;
@@ -311,7 +316,7 @@ __device__ __forceinline__ double sine_arc(double d, double x, double alpha, sin
 // the max() term alone is the reference's value on either side of the window).  -> pi F(a)
 __device__ __forceinline__ double sine_pair_f(double a, sine_tab_t tab) {
     const double g = sqrt_unit(__fma_rn(-a, a, 1.0));
-    return __fma_rn(-a, sine_theta(a, g, tab), g);
+    return __fma_rn(-a, sine_theta<false>(a, g, tab), g);
 }
 // cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
 __device__ __forceinline__ double sine_cool(double thr, double thr2, bool inside, double tmin, double tmax, double tavg, double alpha,

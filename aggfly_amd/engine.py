@@ -263,7 +263,8 @@ def get_csr(weights, dataset: Dataset, device=None):
     cell_key = ck[1:] if ck is not None and ck[0] == id(weights.grid.cell_id) else _hash(np.asarray(weights.grid.cell_id))
     dev = hip._device_index(device)
     ckey = (dev, id(wdf), len(wdf), ny, nx, _hash(order), cell_key)
-    hit = _CSR_CACHE.get(ckey)
+    with _CACHE_LOCK:
+        hit = _CSR_CACHE.get(ckey)
     if hit is not None:
         return hit
     try:
@@ -279,9 +280,12 @@ def get_csr(weights, dataset: Dataset, device=None):
     cols_mem = iy * nx + order[ixs]            # sorted-grid position -> position in the stored cube
     csr = hip.CSR(rows, cols_mem, w, len(region_ids), ny * nx, device=dev)
     if ckey is not None:
-        if len(_CSR_CACHE) >= 8:
-            _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
-        _CSR_CACHE[ckey] = (csr, region_ids)
+        with _CACHE_LOCK:
+            if ckey in _CSR_CACHE:                      # another thread built the same table meanwhile: keep one
+                return _CSR_CACHE[ckey]
+            if len(_CSR_CACHE) >= 8:
+                _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
+            _CSR_CACHE[ckey] = (csr, region_ids)
     return csr, region_ids
 
 
@@ -392,18 +396,20 @@ def plan_groups(time_index, cols):
     return out
 
 
-# Plans (and their scratch in HBM) are cached per process and a handle must not be used by two calls at once
-# (include/aggfly_hip.h): calls from several host threads — the reference runs its kernels from a dask thread pool,
-# `nb_kernels.py:271-305` — enqueue their kernel sequences one after the other.  The sequences stay in order on the
-# stream they share, so no device synchronisation is needed; threads that use DIFFERENT streams must not share a
-# process-wide cache entry (give them `exact_order` / `tuning` variants or separate processes).
-_RUN_LOCK = threading.RLock()
+# Re-entrancy (the reference's kernels are called concurrently from dask's thread pool, `nb_kernels.py:271-305`).
+# Two locks, neither global over the runs:
+#   * ``_CACHE_LOCK`` guards the two caches (lookup / insert / evict) — held for microseconds;
+#   * every cached plan has its own lock (``hip.FusedPlan.lock``), held while ONE call binds its second cubes and enqueues its
+#     kernel sequence: a plan handle owns scratch in HBM and must not be entered twice at once (include/aggfly_hip.h).
+# Calls on DIFFERENT plans (other shapes, other specs, other devices) enqueue concurrently; calls on the same plan enqueue one
+# after the other and stay in order on the stream they share, so no device synchronisation is needed.  Threads that put the
+# SAME plan on different streams would race on its scratch: give them `exact_order` / `tuning` variants or separate processes.
+_CACHE_LOCK = threading.RLock()
 
 
 def run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=None):
     """Run one fused pass; splits it if the library says the pass is too wide."""
-    with _RUN_LOCK:
-        return _run_fused_pass(cube, cols, ib, ob, csr, want_cells, exact_order)
+    return _run_fused_pass(cube, cols, ib, ob, csr, want_cells, exact_order)
 
 
 def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=None):
@@ -413,17 +419,20 @@ def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=N
     f32_rules = config.match_reference_f32 and code == hip.F32
     cdicts = [_column_dict(c, f32_rules) for c in cols]
     try:
-        plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order, device=cube.device)
+        with _CACHE_LOCK:
+            plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order, device=cube.device)
     except hip.HipUnsupported:
         if len(cols) == 1:
             raise
         h = len(cols) // 2
         return _run_fused_pass(cube, cols[:h], ib, ob, None, True, exact_order) + \
             _run_fused_pass(cube, cols[h:], ib, ob, None, True, exact_order)
-    for j, cd in enumerate(cdicts):
-        if cd.get("transform") == "inter":
-            plan.bind_inter(j, inter_time_major(cd["inter"], len(ib) - 1, int(cube.shape[1]), int(cube.shape[2]), cube.device))
-    if csr is not None:
-        out = plan.run(cube, csr, want_cells=want_cells)
-        return [PassResult([c.key for c in cols], None, plan, out.get("cells"), out)]
-    return [PassResult([c.key for c in cols], None, plan, plan.run_temporal(cube), None)]
+    inters = {j: inter_time_major(cd["inter"], len(ib) - 1, int(cube.shape[1]), int(cube.shape[2]), cube.device)
+              for j, cd in enumerate(cdicts) if cd.get("transform") == "inter"}
+    with plan.lock:                     # bind + enqueue as one step: another thread's call on this plan binds its own second cubes
+        for j, other in inters.items():
+            plan.bind_inter(j, other)
+        if csr is not None:
+            out = plan.run(cube, csr, want_cells=want_cells)
+            return [PassResult([c.key for c in cols], None, plan, out.get("cells"), out)]
+        return [PassResult([c.key for c in cols], None, plan, plan.run_temporal(cube), None)]

@@ -445,6 +445,10 @@ class FusedPlan:
         self._h = h
         self.G1 = len(self.ib) - 1
         self._inter = {}               # column -> the bound second cube (kept alive while bound)
+        import threading
+        #: held by a caller while it binds second cubes and enqueues a run: the handle owns scratch in HBM and must not be
+        #: entered by two calls at once (include/aggfly_hip.h); `engine._run_fused_pass` takes it around bind + run
+        self.lock = threading.RLock()
 
     def bind_inter(self, column: int, other):
         """Bind an 'inter' column's second cube: an HBM tensor [G1, n_cells...] (float32 / float64, time-major)."""

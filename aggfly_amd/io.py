@@ -353,6 +353,26 @@ def _torch_dtype(np_dtype):
 _PINNED_STAGE = {}      # (nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
 
 
+def _release_staging_at_exit():
+    """Interpreter teardown: wait for every stream of every device this process touched, then give the page-locked staging
+    buffers back while the HIP runtime is still alive.  The ingest routes drain their own copy / work streams before they
+    return, but the cached buffers outlived the runtime's teardown order: under `rocprofv3 --memory-copy-trace` the process
+    ended with "completion callbacks were not delivered" for the last asynchronous uploads (round 2's timeline run)."""
+    try:
+        import torch
+        if _PINNED_STAGE and torch.cuda.is_available() and torch.cuda.is_initialized():
+            for d in range(torch.cuda.device_count()):
+                torch.cuda.synchronize(d)
+    except Exception:      # teardown must never raise
+        pass
+    _PINNED_STAGE.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_release_staging_at_exit)
+
+
 def _pinned_stage(nbytes: int, count: int):
     """``count`` page-locked host buffers of >= nbytes, cached for the life of the process (the CLI's
     year loop and every later dataset reuse them).  Pinning costs ~0.1 s per GB, which is why a

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 passes of scripts/r02_bench_profiles.sh into the files bench.py reads:
-gpurun_out/r02/traffic_<tag>.json (entry for profiles/traffic.json: HBM bytes per launch of the headline kernel, gfx950
+"""Turns the rocprofv3 passes of scripts/r03_bench_profiles.sh (round 2: r02_bench_profiles.sh; ROUND=r02) into the files bench.py reads:
+gpurun_out/<round>/traffic_<tag>.json (entry for profiles/traffic.json: HBM bytes per launch of the headline kernel, gfx950
 FETCH_SIZE correction applied, with the library build it was measured on), gpurun_out/r02/valu_counts_<tag>.json
 (VALU instructions per grid-cell-timestep of the C5 sine_dd kernel + its issue utilisation) and the kernel stats CSV."""
 import glob
@@ -12,7 +12,8 @@ import sys
 import pandas as pd
 
 tag = sys.argv[1]
-o = "gpurun_out/r02"
+rnd = os.environ.get("ROUND", "r03")
+o = f"gpurun_out/{rnd}"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -56,7 +57,7 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
            "algorithmic_bytes_per_launch": T * C * 8, "build": build_id(),
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py itself "
                      "(--steps 5 --no-cpu-baseline --no-other-configs); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the "
-                     "bytes of a coalesced streaming read)", "source": f"profiles/r02_pmc_traffic_bench_{tag}.json (scripts/r02_bench_profiles.sh)"}
+                     "bytes of a coalesced streaming read)", "source": f"profiles/{rnd}_pmc_traffic_bench_{tag}.json (scripts/{rnd}_bench_profiles.sh)"}
     json.dump({f"c2_f64_T{T}_C{C}": ent}, open(f"{o}/traffic_{tag}.json", "w"), indent=1)
     print("traffic:", json.dumps(ent, indent=1))
 
@@ -64,13 +65,13 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
 v = {}
 for f in glob.glob(f"{o}/pmc_bench_{tag}_c5_*"):
     if os.path.isdir(f):
-        v.update(counters(f"{f}/**/*counter_collection.csv", "133>"))       # the pair-mode sine_dd variant (FEAT 133)
+        v.update(counters(f"{f}/**/*counter_collection.csv", "2, 0, 2, 8, "))       # the pair-mode sine_dd variant (float, 0, 2, 2, 0, 2, 8, FEAT)
 if "SQ_INSTS_VALU" in v:
     T5, C5 = 730, 1801 * 3600
     per = v["SQ_INSTS_VALU"][0] * 64 / (T5 * C5)
     ent = {"valu_inst_per_cell_step": per, "kernel": v["SQ_INSTS_VALU"][2].replace("void afhip::", ""), "build": build_id(),
            "counters_per_launch": {k: x[0] for k, x in v.items()},
-           "source": f"profiles/r02_pmc_valu_bench_{tag}.json: SQ_INSTS_VALU x 64 lanes / (T x cells), rocprofv3 --pmc over bench.py's own C5 run "
+           "source": f"profiles/{rnd}_pmc_valu_bench_{tag}.json: SQ_INSTS_VALU x 64 lanes / (T x cells), rocprofv3 --pmc over bench.py's own C5 run "
                      "(AGGFLY_BENCH_ONLY=C5, ERA5-like (tmin, tmax) field)"}
     if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs

@@ -32,6 +32,8 @@ def columns(plan):
         return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)], False
     if plan == "mean":      # daily mean of short groups -> annual sum (tmin/tmax pairs, 6-hourly data)
         return [dict(inner="mean", outer="sum")], False
+    if plan == "ref":       # the reference's published benchmark shape: mean@date -> power[1..4] -> sum@month (use --periods 12)
+        return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)], False
     if plan == "meanpoly":  # the polynomial of the daily mean (of tmin / tmax pairs, of 6-hourly steps ...) -> annual sum
         return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)], False
     raise SystemExit("plan must be c1, c2, c4, c5, mean or meanpoly")
