@@ -24,6 +24,7 @@
 #include "afhip_panel_kernels.h"
 #include "afhip_lz4_kernels.h"
 #include "afhip_variants.h"
+#include "afhip_sine_p2_table.h"
 
 using namespace afhip;
 
@@ -58,6 +59,7 @@ constexpr int MAX_DEVICES = 64;
 struct DevState {
     int cus = -1;                  // compute units (hipDeviceProp_t::multiProcessorCount)
     double* sine_tab = nullptr;    // acos table of the sine_dd closed forms (afhip_kernels.h: sine_theta), uploaded on first use
+    double* sine_p2 = nullptr;     // P2 table of the pair-mode arc (afhip_kernels.h: sine_pair_f; afhip_sine_p2_table.h), uploaded on first use
 };
 DevState g_dev[MAX_DEVICES];
 std::mutex g_dev_mu;
@@ -127,21 +129,30 @@ std::vector<double> sine_table_host() {
     return t;
 }
 
-int sine_table_dev(int dev, const double** out) {
+// pair = true: the P2 table of the pair-mode arc; false: the acos table.  Each lives as long as the process (8 / 11.5 KB per device).
+int sine_table_dev(int dev, bool pair, const double** out) {
     *out = nullptr;
     if (dev < 0 || dev >= MAX_DEVICES) return fail(AFHIP_E_INVALID, "device %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_dev_mu);
     DevState& d = g_dev[dev];
-    if (!d.sine_tab) {
-        const std::vector<double> h = sine_table_host();
-        static_assert(SINE_TAB_BYTES == 2 * SINE_ROWS * 4 * sizeof(double), "table layout");
+    double*& slot = pair ? d.sine_p2 : d.sine_tab;
+    if (!slot) {
+        std::vector<double> h;
+        if (pair) {
+            static_assert(AFHIP_SINE_P2_N == SINE_P2_N && SINE_P2_BYTES >= (SINE_P2_N + 1) * 4 * (int)sizeof(double), "table layout");
+            h.assign(SINE_P2_BYTES / sizeof(double), 0.0);
+            std::copy(afhip_sine_p2_table, afhip_sine_p2_table + (SINE_P2_N + 1) * 4, h.begin());
+        } else {
+            static_assert(SINE_TAB_BYTES == 2 * SINE_ROWS * 4 * sizeof(double), "table layout");
+            h = sine_table_host();
+        }
         double* p = nullptr;
         HIP_TRY(hipMalloc((void**)&p, h.size() * sizeof(double)));
         hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(p); return fail(AFHIP_E_HIP, "sine table upload failed: %s", hipGetErrorString(e)); }
-        d.sine_tab = p;            // lives as long as the process (one 11.5 KB table per device)
+        slot = p;
     }
-    *out = d.sine_tab;
+    *out = slot;
     return AFHIP_OK;
 }
 
@@ -630,7 +641,7 @@ static int lay_chunks(afhip_plan* pl, int64_t want_chunks);
 // dynamic LDS of a launch of the plan's variant with pl->wg threads per workgroup
 static size_t plan_lds_bytes(const afhip_plan* pl) {
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
-    if (pl->has_sine) lds += SINE_TAB_BYTES;            // the acos table, behind the ring (variants with stat >= 2 carry the code)
+    if (pl->has_sine) lds += pl->variant->pair ? SINE_P2_BYTES : SINE_TAB_BYTES;      // the variant's sine table, behind the ring
     if (pl->variant->hb) lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
     return lds;
 }
@@ -1056,7 +1067,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     fa.xcd_remap = pl->xcd_remap;
     fa.sine_tab = nullptr;
     if (pl->has_sine) {
-        int rc = sine_table_dev(pl->device, &fa.sine_tab);
+        int rc = sine_table_dev(pl->device, pl->variant->pair != 0, &fa.sine_tab);
         if (rc) return rc;
     }
     for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];

@@ -313,10 +313,42 @@ __device__ __forceinline__ double sine_arc(double d, double x, double alpha, sin
 // (tmin, tmax) pairs: tavg is the mid-range, so z = r = (thr - tavg) / alpha =: d / alpha in both forms and, with a = |d| / alpha,
 //   cooling part = max(tavg - thr, 0) + [tmin < thr < tmax] alpha F(a),     heating part = max(thr - tavg, 0) + [..] alpha F(a),
 //   F(a) = (sqrt(1 - a^2) - a acos(a)) / pi        (F(-a) = F(a) + a folds the sign of z into the max() term;
-// the max() term alone is the reference's value on either side of the window).  -> pi F(a)
-__device__ __forceinline__ double sine_pair_f(double a, sine_tab_t tab) {
-    const double g = sqrt_unit(__fma_rn(-a, a, 1.0));
-    return __fma_rn(-a, sine_theta<false>(a, g, tab), g);
+// the max() term alone is the reference's value on either side of the window).
+// F has ONE singularity on [0, 1], the (1 - a)^(3/2) branch point at a = 1:  F(a) = (1 - a)^(3/2) P2(a)  with P2 analytic for
+// |1 - a| < 2 — and nearly constant on [0, 1] (0.300 .. 0.318).  P2 is a table of cubics: row k = round(256 a) holds the cubic in
+// da = a - k / 256 (scripts/fit/sine_p2_fit.py: mpmath, Chebyshev nodes, 2.3e-15 from P2), so the arc is ONE square root
+// (t = sqrt(1 - a), t^3 = t (1 - a)), four instructions for (k, da, row address), three FMAs and one 32-byte LDS row: 17 fp64 /
+// integer instructions + v_rsq_f64, where acos from sine_theta and g - a theta took 23 (and the degree-14 asin of round 2, 44).
+// It is better conditioned, too: no cancellation g - a theta next to a = 1.
+constexpr int SINE_P2_N = 256;                                   // = AFHIP_SINE_P2_N of the generated table
+constexpr int SINE_P2_BYTES = (SINE_P2_N + 1) * 32 + 32;         // (+ a pad row: multiple of 64 bytes)
+struct alignas(32) SineP2Row { double c0, c1, c2, c3; };
+typedef const __attribute__((address_space(3))) SineP2Row* sine_p2_t;
+// max(x, DBL_MIN): 1 - a may come out 0 or a rounding error below it (a = |d| / alpha next to 1): t = sqrt(.) is then ~1e-154,
+// F = 0 — the limit — without a NaN from rsq; one v_max_f64 (a NaN operand would give DBL_MIN too: the cubic still carries it)
+__device__ __forceinline__ double max_tiny(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(2.2250738585072014e-308));
+    return d;
+#else
+    return x > 2.2250738585072014e-308 ? x : 2.2250738585072014e-308;
+#endif
+}
+__device__ __forceinline__ double sine_pair_f(double a, sine_p2_t tab) {
+    static_assert(SINE_P2_N == 256, "the index trick adds 2^44 = 2^52 / 256");
+    const double om = 1.0 - a;                                   // exact for a >= 1/2
+    const double q = max_tiny(om);
+    const double y = __builtin_amdgcn_rsq(q);                    // sqrt(q): rsq seed + one coupled Goldschmidt step (sqrt_unit)
+    const double t0 = q * y, h = 0.5 * y;
+    const double t = __fma_rn(t0, __fma_rn(-h, t0, 0.5), t0);
+    const double ti = a + 17592186044416.0;                      // + 2^44 (ulp 2^-8): the sum's low word is k = round(256 a)
+    const uint32_t k = (uint32_t)__double2loint(ti);
+    const double da = a - (ti - 17592186044416.0);               // a - k / 256, exact
+    sine_p2_t row = (sine_p2_t)(uintptr_t)lshl_add((uint32_t)(uintptr_t)tab, k, 5);
+    const double c0 = row->c0, c1 = row->c1, c2 = row->c2, c3 = row->c3;
+    const double p = __fma_rn(__fma_rn(__fma_rn(c3, da, c2), da, c1), da, c0);
+    return (t * om) * p;
 }
 // cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
 __device__ __forceinline__ double sine_cool(double thr, double thr2, bool inside, double tmin, double tmax, double tavg, double alpha,
@@ -542,15 +574,20 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     const int bd = blockDim.x, tid = threadIdx.x;
     // sine_dd plans: every workgroup copies the acos table (sine_theta) into LDS, behind the LDS-DMA ring if there is one
     static_assert(!(HB && (FEAT & 1)), "histogram variants carry no sine_dd code");
+    // (pair-mode variants: the P2 table of sine_pair_f; the others: the acos table of sine_theta — the host hands over the one
+    // the variant reads)
     sine_tab_t sine_tab = nullptr;
+    sine_p2_t sine_p2 = nullptr;
     if constexpr ((FEAT & 1) != 0) {
         unsigned char* base = dynlds + (PIPE == 1 ? (size_t)(bd >> 6) * DEPTH * 1024 : (size_t)0);
         if (a.sine_tab != nullptr) {            // uniform: the host sets it iff a column is sine_dd (and then sizes the LDS for it)
             typedef double d2 __attribute__((ext_vector_type(2)));
-            for (int e = tid; e < SINE_TAB_BYTES / 16; e += bd) ((d2*)base)[e] = ((const d2*)a.sine_tab)[e];
+            constexpr int bytes = ((FEAT & 128) != 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
+            for (int e = tid; e < bytes / 16; e += bd) ((d2*)base)[e] = ((const d2*)a.sine_tab)[e];
             __syncthreads();
         }
         sine_tab = (sine_tab_t)(lds_ptr_t)base;
+        sine_p2 = (sine_p2_t)(lds_ptr_t)base;
     }
     const int hb_bins = a.hb_n + 2;
     TIn hb_c1 = 0, hb_c0 = 0, hb_top = 0;
@@ -740,9 +777,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if (in0 || in1) {
                         const double alpha = (mx[i] - mn[i]) * 0.5;
                         const double y = rcp_newton1(alpha);
-                        const double api = alpha * (co.skind == 0 ? INV_PI : -INV_PI);       // cooling: + part(s0) - part(s1); heating: the reverse
-                        if (in0) xv = __fma_rn(api, sine_pair_f(fabs(d0) * y, sine_tab), xv);
-                        if (in1) xv = __fma_rn(-api, sine_pair_f(fabs(d1) * y, sine_tab), xv);
+                        // cooling: + part(s0) - part(s1); heating: the reverse
+                        const double sa = alpha * (co.skind == 0 ? 1.0 : -1.0);
+                        if (in0) xv = __fma_rn(sa, sine_pair_f(fabs(d0) * y, sine_p2), xv);
+                        if (in1) xv = __fma_rn(-sa, sine_pair_f(fabs(d1) * y, sine_p2), xv);
                     }
                 } else {
                     const double rng = mx[i] - mn[i], alpha = rng * 0.5;

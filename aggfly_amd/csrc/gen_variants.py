@@ -103,6 +103,7 @@ def menu(kind):
             add(dtype, 0, vec, 2, 0, 6, depth, pair=1, ss=1, prod=prod)
             add(dtype, 0, vec, 1, 0, 2, depth, pair=1, ss=1, prod=prod)
             add(dtype, 0, vec, 1, 0, 6, depth, pair=1, ss=1, prod=prod)
+        # (four cells per lane — half the per-wave scalar work per cell — measured level with two: 4.28 vs 4.25 ms on C5; not kept)
     return out
 
 
