@@ -643,7 +643,7 @@ def test_skewed_rows_take_the_wave_and_segment_paths(torch_cuda):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(2 * 61, 6, 20), (2 * 61, 5, 7)])
+@pytest.mark.parametrize("shape", [(2 * 150, 6, 20), (2 * 150, 5, 7)])
 def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
     """(tmin, tmax) pairs: every inner group is two rows (configs[4]; the reference's daily mean of tmin and tmax,
     `temporal.py:99-125`).  Plans whose columns are  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  take the
@@ -662,7 +662,7 @@ def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
     cube[:, 1, 2] = np.nan
     cube = cube.astype(dtype)
     ib = np.arange(0, T + 1, 2, dtype=np.int64)
-    ob = np.array([0, 20, 21, 61], dtype=np.int64)             # three periods: 20 days, one day, 40 days
+    ob = np.array([0, 20, 21, 150], dtype=np.int64)            # three periods: 20 days, one day, 129 days (long enough to be cut in two)
     d = torch_cuda.from_numpy(cube).cuda()
     f64 = cube.astype(np.float64)
 
@@ -701,5 +701,8 @@ def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
             else:
                 np.testing.assert_array_equal(got[k], w)
         # the same plan with periods free to split over chunks: only the association of the outer sum changes
-        free = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols).run_temporal(d).cpu().numpy()
+        fplan = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols)
+        if not any(c["outer"] in ("max", "min") or c.get("transform") == "hinge" for c in cols):
+            assert int(fplan.describe().split("out_slots=")[1].split()[0]) > 3, fplan.describe()      # the long period was cut
+        free = fplan.run_temporal(d).cpu().numpy()
         np.testing.assert_allclose(free, got, rtol=1e-12, atol=1e-12, equal_nan=True)
