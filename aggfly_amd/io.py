@@ -370,7 +370,8 @@ def _release_staging_at_exit():
 
 import atexit  # noqa: E402
 
-atexit.register(_release_staging_at_exit)
+if os.environ.get("AGGFLY_HIP_NO_EXIT_HOOK") != "1":
+    atexit.register(_release_staging_at_exit)
 
 
 def _pinned_stage(nbytes: int, count: int):

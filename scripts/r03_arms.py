@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--data", default="era5", choices=["iid", "era5"])
     ap.add_argument("--arms", nargs="+", default=["base"])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--sustained", type=int, default=0, help="also time N launches of every arm back to back WITHOUT a sync between them "
+                                                             "(HIP-event pairs around the temporal kernel, as bench.py does)")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     C = a.ny * a.nx
@@ -117,12 +119,27 @@ def main():
                 continue
             res[t].append(out["kernel_ms"][0])
             tot[t].append(out["kernel_ms"][1])
+    sustained = {}
+    if a.sustained:
+        for t, p in plans.items():
+            outb = p.run(cube, csr)
+            for _ in range(10):
+                p.run(cube, csr, out=outb)
+            torch.cuda.synchronize()
+            p.profile_begin(a.sustained)
+            for _ in range(a.sustained):
+                p.run(cube, csr, out=outb)
+            torch.cuda.synchronize()
+            sustained[t] = float(np.mean(p.profile_end()))
     rows = []
     for t in plans:
         med, mn = float(np.median(res[t])), float(np.min(res[t]))
         rows.append({"arm": t, "variant": plans[t].describe().split()[0], "temporal_ms_med": round(med, 4), "temporal_ms_min": round(mn, 4),
                      "GBps_med": round(bytes_alg / med / 1e6, 1), "frac_of_8TBps": round(bytes_alg / med / 1e6 / 8000, 3),
                      "sequence_ms_med": round(float(np.median(tot[t])), 4), "describe": plans[t].describe()})
+        if a.sustained:
+            rows[-1]["sustained_ms_mean"] = round(sustained[t], 4)
+            rows[-1]["sustained_frac_of_8TBps"] = round(bytes_alg / sustained[t] / 1e6 / 8000, 3)
         print(json.dumps({k: v for k, v in rows[-1].items() if k != "describe"}), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
