@@ -309,6 +309,23 @@ def test_c5_sine_dd_tenth_degree_global(torch_cuda):
     for k, dd in enumerate(([10, 30, 0], [0, 18, 1])):
         want = cport.resample(cport.resample(host, ib, "sine_dd", dd), ob, "sum").reshape(-1)
         np.testing.assert_allclose(got[k], want, rtol=1e-10, atol=1e-9, equal_nan=True)
+    # the same cube through the LEAN pair form of other columns (the daily mean of tmin / tmax and its polynomial, min, max):
+    # sampled cells against the oracle — statistics bit-exact, powers within libm's last bit — and default chunking (the one period
+    # cut over chunks) against the unsplit order
+    lean_cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)] + \
+                [dict(inner="min", outer="sum"), dict(inner="max", outer="mean")]
+    lplan = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, lean_cols, exact_order=True)
+    assert lplan.describe().split()[0].endswith("_pair_lean"), lplan.describe()
+    lcells = lplan.run_temporal(cube)
+    lgot = lcells[:, 0, torch.from_numpy(pick).cuda()].cpu().numpy()
+    m = cport.resample(host, ib, "mean")
+    for k, e in enumerate((1, 2, 3, 4)):
+        np.testing.assert_allclose(lgot[k], cport.resample(np.power(m, e), ob, "sum").reshape(-1), rtol=4e-16 if e > 1 else 0, atol=0, equal_nan=True)
+    np.testing.assert_array_equal(lgot[4], cport.resample(cport.resample(host, ib, "min"), ob, "sum").reshape(-1))
+    np.testing.assert_array_equal(lgot[5], cport.resample(cport.resample(host, ib, "max"), ob, "mean").reshape(-1))
+    lfree = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, lean_cols).run_temporal(cube)
+    np.testing.assert_allclose(lfree.cpu().numpy(), lcells.cpu().numpy(), rtol=1e-12, equal_nan=True)
+    del lcells, lfree, lplan
     # the whole path: 40,000 admin-2-like regions (7 M table entries), then the same on a log-normal table whose
     # largest region holds > 10^5 cells
     for kw, seed in ((dict(), 33), (dict(skew="lognormal"), 35)):
