@@ -641,7 +641,7 @@ static int lay_chunks(afhip_plan* pl, int64_t want_chunks);
 // dynamic LDS of a launch of the plan's variant with pl->wg threads per workgroup
 static size_t plan_lds_bytes(const afhip_plan* pl) {
     size_t lds = pl->variant->pipe == 1 ? (size_t)(pl->wg / 64) * pl->variant->depth * 1024 : 0;
-    if (pl->has_sine) lds += pl->variant->pair ? SINE_P2_BYTES : SINE_TAB_BYTES;      // the variant's sine table, behind the ring
+    if (pl->has_sine) lds += (pl->variant->pair && !pl->variant->quad) ? SINE_P2_BYTES : SINE_TAB_BYTES;      // the variant's sine table, behind the ring
     if (pl->variant->hb) lds = (size_t)HB_TABLE_BYTES + (size_t)(pl->hb_n + 2) * pl->variant->vec * pl->wg * 4;
     return lds;
 }
@@ -844,12 +844,22 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // 6.0 TB/s, f32 3.5 vs 4.3; 4-step groups f32 4.4 vs 5.6, f64 equal; 8 steps and longer: equal.
     // every inner group exactly two rows ((tmin, tmax) pairs) and min / max / sine columns: the pair-mode variants of the
     // direct-load path keep DEPTH / 2 whole groups in flight, so they need no ring either
-    bool pairs = desc->G1 > 0 && desc->T == 2 * desc->G1 && pl->nthr == 0 && (pl->stat == 1 || pl->stat == 2) && !getenv("AFHIP_NO_PAIR_MODE");
-    for (int64_t g = 0; pairs && g < desc->G1; ++g) pairs = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == 2;
+    // ... and the same for groups of exactly four rows (6-hourly data), in the lean form only (FEAT bit 10)
+    int glen = 0;
+    if (desc->G1 > 0 && pl->nthr == 0 && (pl->stat == 1 || pl->stat == 2) && !getenv("AFHIP_NO_PAIR_MODE")) {
+        for (int L : {2, 4}) {
+            bool all = desc->T == (int64_t)L * desc->G1;
+            for (int64_t g = 0; all && g < desc->G1; ++g) all = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == L;
+            if (all) glen = L;
+        }
+    }
+    if (glen == 4 && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
+    bool pairs = glen == 2 || glen == 4;                 // short-group mode (two- or four-row groups)
+    const bool quad_len = glen == 4;
     // pair plans whose columns are all  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  without float32 rounding
     // take the lean group end (FEAT bit 8); when every column is a plain sine_dd, its tightest form (FEAT bit 9).  A sine_dd
     // column there needs s0 < s1: its two max() terms are one clamp of width s1 - s0.
-    bool lean = pairs && !getenv("AFHIP_NO_LEAN_PAIRS"), lean_sine = lean && pl->K <= 2;
+    bool lean = pairs && !getenv("AFHIP_NO_LEAN_PAIRS"), lean_sine = lean && pl->K <= 2 && !quad_len;
     for (const ColOp& c : pl->cols) {
         const bool sine_ok = c.src == SRC_SINE && c.s0 < c.s1 && std::isfinite(c.swidth);
         const bool src_ok = c.src == SRC_MEAN || c.src == SRC_SUM || c.src == SRC_MIN || c.src == SRC_MAX || sine_ok;
@@ -857,11 +867,15 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         lean_sine = lean_sine && sine_ok && c.tf == TF_NONE;
     }
     lean_sine = lean_sine && lean;
+    // four-row groups exist in the lean form only, for as many columns as its variants hold
+    if (quad_len && !(lean && find_variant(desc->dtype, 0, pl->stat, 0, pl->K, 0, 0, false, false, false, false, false, 1, 0, true)))
+        pairs = lean = false;
     // mean / sum columns alone (no min, max or sine): the pair path exists in the lean form only, and a light plan (one or two
     // columns) streams faster through the LDS-DMA ring, whose prefetch runs across the two-row groups (5.99 vs 5.44 TB/s on
     // 1801 x 3600 f32); with more columns the lean group end wins (profiles/r03_pairs_mean_poly.txt)
+    // (four-row groups: the lean form measured ahead of the ring at every column count, profiles/r03_quad_groups.txt)
     if (pairs && pl->stat == 1) {
-        int min_k = 3;
+        int min_k = quad_len ? 1 : 3;
         if (const char* e = getenv("AFHIP_LEAN_STAT1_MIN_K")) min_k = atoi(e);      // experiment knob
         if (!lean || pl->K < min_k) pairs = lean = lean_sine = false;
     }
@@ -948,10 +962,13 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         (C_ + (int64_t)WG * 2 - 1) / ((int64_t)WG * 2) >= (int64_t)cu_count(pl->device))
         depth_hint = 4;
     if (const char* e = getenv("AFHIP_DEPTH_HINT")) depth_hint = atoi(e);      // experiment knob
-    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
+    const bool quads = pairs && quad_len, twos = pairs && !quad_len;
+    if (quads) depth_hint = 8;                           // two groups per block
+    const int lean_code = lean ? (lean_sine ? 2 : 1) : 0;
+    const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, twos, lean_code, depth_hint, quads);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
-        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
-    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, pairs, lean ? (lean_sine ? 2 : 1) : 0, depth_hint);
+        v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, all_bins, single_level, partition, arith, twos, lean_code, depth_hint, quads);
+    if (!v) v = find_variant(desc->dtype, 0, pl->stat, pl->nthr, pl->K, 0, 1, all_bins, single_level, pl->hb_n > 0, pl->hb_n > 0 && pl->hb_arith, twos, lean_code, depth_hint, quads);
     if (!v) {
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
@@ -1067,7 +1084,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     fa.xcd_remap = pl->xcd_remap;
     fa.sine_tab = nullptr;
     if (pl->has_sine) {
-        int rc = sine_table_dev(pl->device, pl->variant->pair != 0, &fa.sine_tab);
+        int rc = sine_table_dev(pl->device, pl->variant->pair != 0 && pl->variant->quad == 0, &fa.sine_tab);
         if (rc) return rc;
     }
     for (int i = 0; i < pl->nthr; ++i) fa.thr[i] = pl->thr[(size_t)i];

@@ -513,9 +513,15 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     // FEAT bit 9: ... and every column is a plain sine_dd (no power): nothing but the closed forms in the group end
     constexpr bool LEAN_SINE = (FEAT & 512) != 0;
     static_assert(!LEAN_SINE || (LEAN && (FEAT & 1) && KMAX <= 2), "the sine-only lean form: at most two columns");
-    static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % 2 == 0),
-                  "pair mode: direct loads, sum (+ min + max), no threshold slots");
-    static_assert(!LEAN || PAIR, "the lean group end is a pair-mode form");
+    // FEAT bit 10: the same mode for inner groups of exactly FOUR rows (6-hourly data): GL rows per group, DEPTH / GL groups per block;
+    //              lean form only.  The sum runs in time order ((u0 + u1) + u2) + u3, the mean is s / 4 = s * 0.25 exactly, min / max
+    //              are taken in the input precision; sine_dd columns use the general closed forms (tavg is not the mid-range of four
+    //              steps), so these variants read the acos table.
+    constexpr int GL = (FEAT & 1024) ? 4 : 2;
+    static_assert(!(FEAT & 1024) || (PAIR && LEAN && !LEAN_SINE), "four-row groups: a lean short-group form");
+    static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % GL == 0),
+                  "short-group mode: direct loads, sum (+ min + max), no threshold slots");
+    static_assert(!LEAN || PAIR, "the lean group end is a short-group form");
     const int64_t C = a.C;
     const int K = a.K;
     const int lane = threadIdx.x & 63;
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         unsigned char* base = dynlds + (PIPE == 1 ? (size_t)(bd >> 6) * DEPTH * 1024 : (size_t)0);
         if (a.sine_tab != nullptr) {            // uniform: the host sets it iff a column is sine_dd (and then sizes the LDS for it)
             typedef double d2 __attribute__((ext_vector_type(2)));
-            constexpr int bytes = ((FEAT & 128) != 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
+            constexpr int bytes = ((FEAT & 128) != 0 && (FEAT & 1024) == 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
             for (int e = tid; e < bytes / 16; e += bd) ((d2*)base)[e] = ((const d2*)a.sine_tab)[e];
             __syncthreads();
         }
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         for (int i = 0; i < VEC; ++i) {
             if constexpr (PAIR) hasnan[i] = pnan[i];
             else hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
-            if constexpr (PAIR) mean[i] = s[i] * 0.5;                  // == s / 2 bit for bit
+            if constexpr (PAIR) mean[i] = s[i] * (1.0 / GL);           // == s / 2 (s / 4) bit for bit
             else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
         }
         // single-sine degree days of one column (nb_kernels.py:218-251).  The reciprocal of the window's range and the arcs are
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             for (int i = 0; i < VEC; ++i) {
                 const double tavg = mean[i];
                 bool in0, in1;
-                if constexpr (PAIR && sizeof(TIn) == 4) {       // float data: exact float compares against the rounded thresholds
+                if constexpr (PAIR && GL == 2 && sizeof(TIn) == 4) {       // float data: exact float compares against the rounded thresholds
                     in0 = (plo[i] < co.s0up) && (phi[i] > co.s0dn);
                     in1 = (plo[i] < co.s1up) && (phi[i] > co.s1dn);
                 } else {
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     in1 = (mn[i] < co.s1) && (co.s1 < mx[i]);
                 }
                 double xv;
-                if constexpr (PAIR) {
+                if constexpr (PAIR && GL == 2) {
                     // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_f)
                     // thr - tavg = thr - s / 2 (s / 2 is exact: one rounding either way)
                     const double d0 = __fma_rn(s[i], -0.5, co.s0), d1 = __fma_rn(s[i], -0.5, co.s1);
@@ -1042,16 +1048,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 
     if constexpr (PAIR) {
         const TIn* p = cube;
-        constexpr int GB = DEPTH / 2;                 // groups per block of rows
-        // the pair's statistics: min / max in the input precision (exact), the sum as min + max — the same two addends
-        // the reference adds in time order; a NaN in either row marks the lane (the group is NaN, nb_kernels.py:145-147)
-        auto pair_stats = [&](const RawVec<TIn, VEC>& r0, const RawVec<TIn, VEC>& r1) {
+        constexpr int GB = DEPTH / GL;                // groups per block of rows
+        // the group's statistics: min / max in the input precision (exact), the sum in time order — for a pair min + max, the same
+        // two addends the reference adds; a NaN in any row marks the lane (the group is NaN, nb_kernels.py:145-147)
+        auto short_stats = [&](const RawVec<TIn, VEC>* r) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const TIn u = r0.v[i], v = r1.v[i];
+                const TIn u = r[0].v[i], v = r[1].v[i];
                 pnan[i] = u != u || v != v;
                 // v_min / v_max straight on the loaded values: the builtins first canonicalise both operands (v_max x, x)
-                // against signalling NaNs; a pair with any NaN is a NaN group anyway
+                // against signalling NaNs; a group with any NaN is a NaN group anyway
                 TIn lo, hi;
                 if constexpr (sizeof(TIn) == 4) {
                     asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(u), "v"(v));
@@ -1060,14 +1066,34 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(u), "v"(v));
                     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(u), "v"(v));
                 }
-                plo[i] = lo; phi[i] = hi;
-                mn[i] = (double)lo; mx[i] = (double)hi;
-                s[i] = mn[i] + mx[i];
-                if constexpr (STAT == 1) s[i] = (double)u + (double)v;     // (the same two addends; no min / max needed)
+                if constexpr (GL == 2) {
+                    plo[i] = lo; phi[i] = hi;
+                    mn[i] = (double)lo; mx[i] = (double)hi;
+                    s[i] = mn[i] + mx[i];
+                    if constexpr (STAT == 1) s[i] = (double)u + (double)v;     // (the same two addends; no min / max needed)
+                } else {
+                    const TIn u2 = r[2].v[i], u3 = r[3].v[i];
+                    pnan[i] = pnan[i] || u2 != u2 || u3 != u3;
+                    s[i] = (((double)u + (double)v) + (double)u2) + (double)u3;             // nb_kernels.py:130-137: k ascending
+                    if constexpr (STAT >= 2) {
+                        TIn lo2, hi2;
+                        if constexpr (sizeof(TIn) == 4) {
+                            asm("v_min_f32 %0, %1, %2" : "=v"(lo2) : "v"(u2), "v"(u3));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(hi2) : "v"(u2), "v"(u3));
+                            asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(lo2));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(hi2));
+                        } else {
+                            asm("v_min_f64 %0, %1, %2" : "=v"(lo2) : "v"(u2), "v"(u3));
+                            asm("v_max_f64 %0, %1, %2" : "=v"(hi2) : "v"(u2), "v"(u3));
+                            asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(lo2));
+                            asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(hi2));
+                        }
+                        plo[i] = lo; phi[i] = hi;
+                        mn[i] = (double)lo; mx[i] = (double)hi;
+                    }
+                }
             }
         };
-        // ONE group-end site (rolled loop over the block's groups, the rows shifted down two per group): the sine closed
-        // forms are long, and DEPTH / 2 inlined copies of them (66 KB of code) would not fit the instruction cache.
         // Rows beyond the chunk's end (last, partial block) re-read its last row; their groups are not evaluated.
         const int last = rows - 1;
         while (g < g_hi) {
@@ -1078,29 +1104,18 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 const int row = (kk + d) < last ? (kk + d) : last;
                 r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)row * C);
             }
-#ifdef AFHIP_PAIR_ROLLED
-#pragma unroll 1
-            for (int q = 0; q < ng; ++q) {
-                const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
-                pair_stats(r[0], r[1]);
-                group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63), g + q);
-#pragma unroll
-                for (int d = 0; d + 2 < DEPTH; ++d) r[d] = r[d + 2];
-            }
-#else
-            // one copy of the group end per group of the block: since the arcs come from a table (sine_theta) the copies fit
-            // the instruction cache, and the rows need not be shifted down two registers per group (4 VALU per cell-day)
+            // one copy of the group end per group of the block: since the arcs come from a table the copies fit the instruction
+            // cache, and the rows need not be shifted down GL registers per group (round 2's rolled loop: 4 VALU per cell-day)
 #pragma unroll
             for (int q = 0; q < GB; ++q) {
                 if (q < ng) {
                     const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
-                    pair_stats(r[2 * q], r[2 * q + 1]);
-                    group_end((w & 1) != 0, 2, 0.5, (int)((uint64_t)w >> 63), g + q);
+                    short_stats(&r[GL * q]);
+                    group_end((w & 1) != 0, GL, 1.0 / GL, (int)((uint64_t)w >> 63), g + q);
                 }
             }
-#endif
             g += ng;
-            kk += 2 * ng;
+            kk += GL * ng;
         }
     } else if constexpr (PIPE == 0) {
         const TIn* p = cube;

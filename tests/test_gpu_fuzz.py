@@ -86,21 +86,24 @@ def _time_axes(rng, T, spd, seed):
     return prod[keep], orc[keep], keep
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(44))
 def test_random_specs_match_oracle(torch_cuda, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = np.float64 if seed % 2 == 0 else np.float32
     spd = 24 if seed < 16 else int(rng.choice([1, 2, 24]))            # hourly; later seeds also daily / 12-hourly
-    pair_seed = 28 <= seed < 36 or (seed >= 36 and seed % 3 == 0)      # (seeds beyond the parametrised ones: scripts/fuzz_more.py)
+    pair_seed = 28 <= seed < 36 or (seed >= 44 and seed % 3 == 0)      # (seeds beyond the parametrised ones: scripts/fuzz_more.py)
+    quad_seed = 36 <= seed < 44 or (seed >= 44 and seed % 3 == 1)
     if pair_seed:
         spd = 2             # unbroken (tmin, tmax)-like pairs: the date groups are all two rows -> pair mode and its lean group ends
+    if quad_seed:
+        spd = 4             # unbroken 6-hourly steps: the date groups are all four rows -> the four-row form of the lean group end
     ndays = int(rng.integers(70, 130)) if spd == 24 else int(rng.integers(400, 800))
     T, ny, nx = spd * ndays + (int(rng.integers(0, 24)) if spd == 24 else 0), int(rng.integers(3, 9)), int(rng.integers(3, 12))
     cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=seed, steps_per_day=spd, ocean_frac=0.1, scattered_nan=15)
     if seed < 16:
         time = otime = pd.date_range("2001-11-17 05:00", periods=T, freq="h")
-    elif pair_seed:
-        time = otime = pd.date_range("2001-11-17 00:00", periods=T, freq="12h")
+    elif pair_seed or quad_seed:
+        time = otime = pd.date_range("2001-11-17 00:00", periods=T, freq="12h" if pair_seed else "6h")
     else:
         time, otime, keep = _time_axes(rng, T, spd, seed)
         cube = np.ascontiguousarray(cube[keep])

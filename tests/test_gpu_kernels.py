@@ -706,3 +706,72 @@ def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
             assert int(fplan.describe().split("out_slots=")[1].split()[0]) > 3, fplan.describe()      # the long period was cut
         free = fplan.run_temporal(d).cpu().numpy()
         np.testing.assert_allclose(free, got, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(4 * 150, 6, 20), (4 * 150, 5, 7), (4 * 151, 3, 130)])
+def test_four_row_groups_take_the_lean_group_end(torch_cuda, dtype, shape):
+    """6-hourly data: every inner group holds exactly four rows (`temporal.py:99-125` resampling 00/06/12/18 UTC to the day).
+    Plans that qualify for the lean group end keep whole groups in registers (FEAT bit 10) instead of walking the generic
+    row loop; the group sum adds the four rows in time order, as the oracle does, so mean / sum / min / max are bit-exact.
+    Plans that do not qualify (hinge, outer max, more columns than the variants hold) must leave the four-row path; unlike
+    two-row groups, even one mean column takes it (it measured ahead of the ring, profiles/r03_quad_groups.txt)."""
+    from aggfly_amd import hip
+    T, ny, nx = shape
+    rng = np.random.default_rng(23)
+    k = np.arange(T)
+    base = 15 + 10 * np.sin(2 * np.pi * (k // 4) / 365.0) + 6 * np.sin(2 * np.pi * (k % 4) / 4 - np.pi / 2)
+    cube = base[:, None, None] + rng.normal(0, 3, (T, ny, nx))
+    cube[rng.integers(0, T, 9), rng.integers(0, ny, 9), rng.integers(0, nx, 9)] = np.nan
+    cube[:, 1, 2] = np.nan
+    cube = cube.astype(dtype)
+    ib = np.arange(0, T + 1, 4, dtype=np.int64)
+    G1 = T // 4
+    ob = np.array([0, 20, 21, G1], dtype=np.int64)
+    d = torch_cuda.from_numpy(cube).cuda()
+    f64 = cube.astype(np.float64)
+    code = hip.F64 if dtype == np.float64 else hip.F32
+
+    def want(col):
+        x = cport.resample(f64, ib, col["inner"], col.get("inner_args"))
+        if col.get("transform") == "pow":
+            x = cport.power(x, col["transform_arg"])
+        elif col.get("transform") == "hinge":
+            x = (x > col["transform_arg"]) * (x - col["transform_arg"])
+        return cport.resample(x, ob, col["outer"])
+
+    poly = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
+    mixed = [dict(inner="min", outer="sum"), dict(inner="max", transform="pow", transform_arg=2, outer="mean"),
+             dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="mean", outer="mean"), dict(inner="sum", outer="sum"),
+             dict(inner="sine_dd", inner_args=(0, 18, 1), outer="mean")]
+    two = [dict(inner="max", outer="sum"), dict(inner="min", outer="mean")]
+    generic = [dict(inner="mean", transform="hinge", transform_arg=20.0, outer="sum"), dict(inner="max", outer="max")]
+    many = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4, 5, 6, 7)]
+    light = [dict(inner="mean", outer="sum")]
+    for cols, quad in ((poly, True), (mixed, True), (two, True), (generic, False), (many, False), (light, True)):
+        plan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True)
+        name = plan.describe().split()[0]
+        assert name.endswith("_quad") == quad, name
+        got = plan.run_temporal(d).cpu().numpy()
+        for kk, col in enumerate(cols):
+            w = want(col).reshape(len(ob) - 1, -1)
+            assert np.array_equal(np.isnan(got[kk]), np.isnan(w)), (name, col)
+            if col["inner"] == "sine_dd":
+                np.testing.assert_allclose(got[kk], w, rtol=1e-10, atol=1e-10, equal_nan=True)
+            elif col.get("transform") == "pow":
+                np.testing.assert_allclose(got[kk], w, rtol=4e-15, equal_nan=True)
+            else:
+                np.testing.assert_array_equal(got[kk], w)
+        fplan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols)
+        free = fplan.run_temporal(d).cpu().numpy()
+        np.testing.assert_allclose(free, got, rtol=1e-12, atol=1e-12, equal_nan=True)
+    # the knob that switches the form off gives the same numbers through the general path
+    import os
+    os.environ["AFHIP_NO_QUAD_MODE"] = "1"
+    try:
+        ring = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
+    finally:
+        del os.environ["AFHIP_NO_QUAD_MODE"]
+    assert "_quad" not in ring.describe().split()[0]
+    quadp = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
+    np.testing.assert_allclose(quadp.run_temporal(d).cpu().numpy(), ring.run_temporal(d).cpu().numpy(), rtol=4e-15, equal_nan=True)
