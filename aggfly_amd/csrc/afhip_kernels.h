@@ -205,6 +205,16 @@ __device__ __forceinline__ double fma_vsv(double a, double b, double c) {
     return __builtin_fma(a, b, c);
 #endif
 }
+// a * b + c with the addend in scalar registers (three-address form: the compiler's v_fmac needs a v_mov of the constant first)
+__device__ __forceinline__ double fma_vvs(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
 // (k << n) + base in one instruction
 __device__ __forceinline__ uint32_t lshl_add(uint32_t base, uint32_t k, int n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -335,20 +345,31 @@ __device__ __forceinline__ double max_tiny(double x) {
     return x > 2.2250738585072014e-308 ? x : 2.2250738585072014e-308;
 #endif
 }
-__device__ __forceinline__ double sine_pair_f(double a, sine_p2_t tab) {
-    static_assert(SINE_P2_N == 256, "the index trick adds 2^44 = 2^52 / 256");
-    const double om = 1.0 - a;                                   // exact for a >= 1/2
-    const double q = max_tiny(om);
-    const double y = __builtin_amdgcn_rsq(q);                    // sqrt(q): rsq seed + one coupled Goldschmidt step (sqrt_unit)
-    const double t0 = q * y, h = 0.5 * y;
-    const double t = __fma_rn(t0, __fma_rn(-h, t0, 0.5), t0);
-    const double ti = a + 17592186044416.0;                      // + 2^44 (ulp 2^-8): the sum's low word is k = round(256 a)
+// one threshold strictly inside a (tmin, tmax) pair: alpha F(a) = u sqrt(om) P2(1 - om), u = alpha - |thr - tavg| in (0, alpha],
+// om = u / alpha = 1 - a — without the reciprocal of alpha: with rng = 2 alpha, u2 = 2 u and the seed z ~ rsq(u2 rng),
+//   th = u2 z (3 - (u2 rng) z^2) = 2 sqrt(om)   (one Newton step on the seed, in product form),   x = th^2 = 4 om,
+//   alpha F = (u2 th) G(x),   G(x) = P2(1 - x / 4) / 4: cubic rows in x itself (scripts/fit/sine_p2_fit.py),
+// returned as the two factors w = su2 th and p = G(x).  12 VALU + rsq; `su2` is u2 carrying the sign the caller wants on the
+// product (only |su2| enters v and th).
+__device__ __forceinline__ void sine_pair_g(double su2, double rng, sine_p2_t tab, double& w, double& p) {
+    static_assert(SINE_P2_N == 256, "the index trick adds 2^46 = 2^52 / 64");
+    double v;                                                    // |su2| rng + tiny: u may round to 0 (thr one ulp inside the window); rsq(0) = inf
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_f64 %0, |%1|, %2, %3" : "=v"(v) : "v"(su2), "v"(rng), "s"(1e-300));
+#else
+    v = __builtin_fma(__builtin_fabs(su2), rng, 1e-300);
+#endif
+    const double z = __builtin_amdgcn_rsq(v);
+    const double a = v * z;
+    const double e = __fma_rn(-a, z, 3.0);
+    const double th = (__builtin_fabs(su2) * z) * e;
+    const double x = th * th;
+    const double ti = x + 70368744177664.0;                      // + 2^46 (ulp 2^-6): the sum's low word is k = round(64 x)
     const uint32_t k = (uint32_t)__double2loint(ti);
-    const double da = a - (ti - 17592186044416.0);               // a - k / 256, exact
     sine_p2_t row = (sine_p2_t)(uintptr_t)lshl_add((uint32_t)(uintptr_t)tab, k, 5);
     const double c0 = row->c0, c1 = row->c1, c2 = row->c2, c3 = row->c3;
-    const double p = __fma_rn(__fma_rn(__fma_rn(c3, da, c2), da, c1), da, c0);
-    return (t * om) * p;
+    p = __fma_rn(__fma_rn(__fma_rn(c3, x, c2), x, c1), x, c0);
+    w = su2 * th;
 }
 // cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
 __device__ __forceinline__ double sine_cool(double thr, double thr2, bool inside, double tmin, double tmax, double tavg, double alpha,
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     const int bd = blockDim.x, tid = threadIdx.x;
     // sine_dd plans: every workgroup copies the acos table (sine_theta) into LDS, behind the LDS-DMA ring if there is one
     static_assert(!(HB && (FEAT & 1)), "histogram variants carry no sine_dd code");
-    // (pair-mode variants: the P2 table of sine_pair_f; the others: the acos table of sine_theta — the host hands over the one
+    // (pair-mode variants: the G table of sine_pair_g; the others: the acos table of sine_theta — the host hands over the one
     // the variant reads)
     sine_tab_t sine_tab = nullptr;
     sine_p2_t sine_p2 = nullptr;
@@ -767,7 +788,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 }
                 double xv;
                 if constexpr (PAIR && GL == 2) {
-                    // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_f)
+                    // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_g)
                     // thr - tavg = thr - s / 2 (s / 2 is exact: one rounding either way)
                     const double d0 = __fma_rn(s[i], -0.5, co.s0), d1 = __fma_rn(s[i], -0.5, co.s1);
                     if constexpr (LEAN) {
@@ -781,15 +802,23 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         else xv = max0(d1) - max0(d0);
                     }
                     if (in0 || in1) {
-                        const double alpha = (mx[i] - mn[i]) * 0.5;
-                        const double y = rcp_newton1(alpha);
+                        const double rng = mx[i] - mn[i];               // = 2 alpha, exact
                         // cooling: + part(s0) - part(s1); heating: the reverse.  (ONE arc site for both thresholds — a lane's window
                         // rarely holds both, but some lanes of a wave hold s0 while others hold s1 on spring / autumn days — was built
                         // and measured: only 7 % fewer arcs on the ERA5-like field, and the operand selects cost more: 23.1 -> 24.9
                         // VALU per cell-step, same time; profiles/r03_kbench_c5_table_arc.txt)
-                        const double sa = alpha * (co.skind == 0 ? 1.0 : -1.0);
-                        if (in0) xv = __fma_rn(sa, sine_pair_f(fabs(d0) * y, sine_p2), xv);
-                        if (in1) xv = __fma_rn(-sa, sine_pair_f(fabs(d1) * y, sine_p2), xv);
+                        // (the sign rides on u2 = rng - 2 |d|: a scalar branch around one instruction instead of a multiplication)
+                        double w, p, su;
+                        if (in0) {
+                            if (co.skind == 0) { KEEP_BRANCH(); su = __fma_rn(fabs(d0), -2.0, rng); } else su = __fma_rn(fabs(d0), 2.0, -rng);
+                            sine_pair_g(su, rng, sine_p2, w, p);
+                            xv = __fma_rn(w, p, xv);
+                        }
+                        if (in1) {
+                            if (co.skind == 0) { KEEP_BRANCH(); su = __fma_rn(fabs(d1), -2.0, rng); } else su = __fma_rn(fabs(d1), 2.0, -rng);
+                            sine_pair_g(su, rng, sine_p2, w, p);
+                            xv = __fma_rn(-w, p, xv);
+                        }
                     }
                 } else {
                     const double rng = mx[i] - mn[i], alpha = rng * 0.5;
