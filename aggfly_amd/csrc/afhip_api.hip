@@ -854,6 +854,8 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         }
     }
     if (glen == 4 && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
+    // (its loads address a row by a 32-bit byte offset per lane: rows of 4 GiB and more take the general path)
+    if ((uint64_t)desc->n_cells * (desc->dtype == AFHIP_F64 ? 8u : 4u) >= (1ull << 32)) glen = 0;
     bool pairs = glen == 2 || glen == 4;                 // short-group mode (two- or four-row groups)
     const bool quad_len = glen == 4;
     // pair plans whose columns are all  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  without float32 rounding

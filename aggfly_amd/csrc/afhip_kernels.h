@@ -470,6 +470,32 @@ __device__ __forceinline__ RawVec<TIn, VEC> ld_stream(const TIn* p) {
     return r;
 }
 
+// The same through a buffer descriptor on a UNIFORM row pointer + the lane's 32-bit byte offset: the address needs no vector
+// arithmetic at all (a global_load wants a 64-bit vector address: one v_lshl_add_u64 per load).
+template <typename TIn, int VEC, int AUX>
+__device__ __forceinline__ RawVec<TIn, VEC> ld_stream_row(const void* row, uint32_t voff) {
+    RawVec<TIn, VEC> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(row), 0, -1, 0x00020000);
+    constexpr int aux = AUX != 0 ? 2 : 0;          // nt
+    constexpr int bytes = (int)sizeof(TIn) * VEC;
+    static_assert(bytes == 4 || bytes == 8 || bytes == 16, "one dword, two or four per lane");
+    if constexpr (bytes == 4) {
+        const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, aux);
+        __builtin_memcpy(&r, &t, 4);
+    } else if constexpr (bytes == 8) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, aux);
+        __builtin_memcpy(&r, &t, 8);
+    } else {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, aux);
+        __builtin_memcpy(&r, &t, 16);
+    }
+#endif
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------
 // k_fused_temporal
 //
@@ -883,8 +909,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if (j < K) {
                         double* dst = a.partial + ((int64_t)slot * K + j) * C + c0;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            if (active) dst[i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                        for (int i = 0; i < VEC; ++i) {
+                            const double val = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                            if (active) dst[i] = val;
+                        }
                     }
                 }
 #pragma unroll
@@ -1123,16 +1151,28 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 }
             }
         };
-        // Rows beyond the chunk's end (last, partial block) re-read its last row; their groups are not evaluated.
-        const int last = rows - 1;
+        // Loads run one block ahead, group by group: as soon as a group's rows have been reduced to its statistics the same
+        // group's rows of the NEXT block are requested, so the memory pipe works while the arcs run (a block that loads, then
+        // waits, then computes left it idle: VALU busy 0.81 of the kernel; with this 0.90).  The requests sit under the branch
+        // "the next block has this group", which makes the compiler land them in fresh registers and move them into place at the
+        // loop's back edge behind one s_waitcnt vmcnt(0).  The textbook form — unconditional loads straight into the ring's
+        // registers, counted waits vmcnt(DEPTH - GL) per group, no moves — was built too and measured BEHIND this one on every
+        // short-group shape (C5 3.59 vs 3.53 ms, mean -> power[1..4] -> sum f32 5.66 vs 5.53, f64 3.74 vs 3.61; the old
+        // load-wait-compute block on the latter two: 5.76 / 3.90; profiles/r03_short_group_loads.txt); depths 4, 6, 8 measure alike.
+        // Addresses: ONE scalar row pointer that advances by a row per load, in a buffer descriptor, + the lane's 32-bit byte
+        // offset — no vector address arithmetic (a global_load needs a v_lshl_add_u64 per row) and two scalar adds per row; the host
+        // keeps plans whose rows reach 4 GiB off this path.
+        const char* nx = (const char*)a.cube + (size_t)(k_lo * C) * sizeof(TIn);       // the next row to load (uniform)
+        const uint32_t voff = (uint32_t)((uint64_t)c_ld * sizeof(TIn));
+        const size_t rowb = (size_t)C * sizeof(TIn);
+        RawVec<TIn, VEC> r[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (d < rows) { r[d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+            else r[d] = r[0];                      // (a chunk shorter than a block: these rows' groups are not evaluated)
+        }
         while (g < g_hi) {
             const int ng = (g_hi - g) < GB ? (g_hi - g) : GB;
-            RawVec<TIn, VEC> r[DEPTH];
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int row = (kk + d) < last ? (kk + d) : last;
-                r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)row * C);
-            }
             // one copy of the group end per group of the block: since the arcs come from a table the copies fit the instruction
             // cache, and the rows need not be shifted down GL registers per group (round 2's rolled loop: 4 VALU per cell-day)
 #pragma unroll
@@ -1140,6 +1180,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 if (q < ng) {
                     const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
                     short_stats(&r[GL * q]);
+                    if (kk + DEPTH + GL * (q + 1) <= rows) {       // (groups are whole: all of the next block's group q, or none)
+#pragma unroll
+                        for (int d = 0; d < GL; ++d) { r[GL * q + d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+                    }
                     group_end((w & 1) != 0, GL, 1.0 / GL, (int)((uint64_t)w >> 63), g + q);
                 }
             }
