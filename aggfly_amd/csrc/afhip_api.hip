@@ -865,7 +865,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     for (const ColOp& c : pl->cols) {
         const bool sine_ok = c.src == SRC_SINE && c.s0 < c.s1 && std::isfinite(c.swidth);
         const bool src_ok = c.src == SRC_MEAN || c.src == SRC_SUM || c.src == SRC_MIN || c.src == SRC_MAX || sine_ok;
-        lean = lean && src_ok && (c.tf == TF_NONE || c.tf == TF_POWI) && c.rounding == 0 && (c.outer == OUT_SUM || c.outer == OUT_MEAN);
+        lean = lean && src_ok && (c.tf == TF_NONE || (c.tf == TF_POWI && c.tf_iarg >= 1)) && c.rounding == 0 && (c.outer == OUT_SUM || c.outer == OUT_MEAN);
         lean_sine = lean_sine && sine_ok && c.tf == TF_NONE;
     }
     lean_sine = lean_sine && lean;
@@ -1095,7 +1095,11 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         fa.thr[i].t0 = INFINITY; fa.thr[i].t1 = -INFINITY;
         fa.thr[i].t0f = INFINITY; fa.thr[i].t1f = -INFINITY;
     }
-    for (int j = 0; j < pl->K; ++j) fa.cols[j] = pl->cols[(size_t)j];
+    for (int j = 0; j < pl->K; ++j) {
+        const ColOp& c = pl->cols[(size_t)j];
+        fa.cols[j] = c;
+        fa.ccode[j] = (uint32_t)c.src | ((uint32_t)c.tf << 4) | ((uint32_t)(uint8_t)(int8_t)c.tf_iarg << 8);
+    }
     fa.packed = pl->packed ? 1 : 0;
     fa.pk_nw = pl->pk.nw; fa.pk_mask = pl->pk.mask;
     for (int j = 0; j < MAX_COLS; ++j) { fa.pk_word[j] = pl->pk.word[j]; fa.pk_shift[j] = pl->pk.shift[j]; }

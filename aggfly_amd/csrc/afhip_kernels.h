@@ -114,6 +114,10 @@ struct FusedArgs {
     float hb_wf, hb_lo0f, hb_glf, hb_ghf;
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
+    // the lean group end's view of a column in ONE word (src | tf << 4 | (tf_iarg & 0xff) << 8): six of them stay in scalar
+    // registers through the time loop; the full records do not (they were re-read, three scalar loads and their waits, per column
+    // and group: 13 s_load per two-row group on a four-column polynomial)
+    uint32_t ccode[MAX_COLS];
 };
 
 // ---------------------------------------------------------------------------------------
@@ -126,11 +130,16 @@ __device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff000
 #define KEEP_BRANCH() asm volatile("")
 
 // x**e for a small integer e, evaluated as a double-double product chain so that the
-// result is the correctly rounded power in all but ~1e-16 of cases — what libm's pow()
+// result is the correctly rounded power in all but ~1e-14 of cases — what libm's pow()
 // behind np.power (dataset.py:543) returns.  Plain repeated multiplication differs from
 // np.power in the last bit for 26-35 % of inputs at e = 3, 4.
 // The exponent is wave-uniform: one scalar loop drives the N independent chains of a lane.
-template <int N>
+//
+// The pair (hi, lo) is NOT renormalised between steps: (hi + lo) x = p + (err + lo x) with p = RN(hi x), err = hi x - p exactly
+// (one fma) and the small term rounded once (a second fma) — |lo| stays within a few ulps of hi for every exponent lowered to this
+// form (|e| <= 64), so its rounding errors are of order 2^-106 and only the final hi + lo rounds at 2^-53.  Three instructions per
+// step, two for the first (lo = 0), instead of the six of a renormalising step: x^3 6 instructions, x^4 9 (were 13 and 19).
+template <int N, bool NEG = true>
 __device__ __forceinline__ void powi_dd_vec(double (&x)[N], int e) {
     if (e == 0) {
 #pragma unroll
@@ -138,32 +147,38 @@ __device__ __forceinline__ void powi_dd_vec(double (&x)[N], int e) {
         return;
     }
     const int n = e < 0 ? -e : e;
-    double hi[N], lo[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { hi[i] = x[i]; lo[i] = 0.0; }
     if (n == 2) {                       // the chain's first step is RN(x * x) exactly: one multiply
         KEEP_BRANCH();
 #pragma unroll
-        for (int i = 0; i < N; ++i) hi[i] = x[i] * x[i];
-    } else
-    for (int it = 1; it < n; ++it) {
+        for (int i = 0; i < N; ++i) x[i] = x[i] * x[i];
+    } else if (n > 2) {
+        double hi[N], lo[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            // (hi + lo) * x  ->  (p + q)
-            const double p = hi[i] * x[i];
-            const double err = __fma_rn(hi[i], x[i], -p);
-            const double q = __fma_rn(lo[i], x[i], err);
-            const double sm = p + q;
-            lo[i] = q - (sm - p);
-            hi[i] = sm;
+        for (int i = 0; i < N; ++i) { hi[i] = x[i] * x[i]; lo[i] = __fma_rn(x[i], x[i], -hi[i]); }
+        auto step = [&]() {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double p = hi[i] * x[i];
+                const double err = __fma_rn(hi[i], x[i], -p);
+                lo[i] = __fma_rn(lo[i], x[i], err);
+                hi[i] = p;
+            }
+        };
+        step();                         // n >= 3; the cube and the fourth power (polynomials) are straight-line code: a loop
+        if (n > 3) {                    // carries (hi, lo) through register copies
+            KEEP_BRANCH();
+            step();
+            for (int it = 4; it < n; ++it) step();
         }
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = hi[i] + lo[i];
     }
+    if constexpr (NEG) {                // (the lean short-group forms take non-negative exponents only: no division code in them)
+        if (e < 0) {
+            KEEP_BRANCH();
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = hi[i] + lo[i];
-    if (e < 0) {
-        KEEP_BRANCH();
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = 1.0 / x[i];
+            for (int i = 0; i < N; ++i) x[i] = 1.0 / x[i];
+        }
     }
 }
 __device__ __forceinline__ double powi_dd(double x, int e) {
@@ -677,6 +692,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     }
     auto reset_outer = [&]() {
         if (SL) return;
+        if constexpr ((FEAT & 256) != 0) {          // lean forms: every outer reducer is sum | mean — no per-column identity, no j < K masks
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) os[j][i] = 0.0;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             if (j < K) {
@@ -878,13 +900,23 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     if constexpr (LEAN_SINE) {
                         sine_column(a.cols[j], x);              // a.cols[j]: loop-invariant kernel argument, scalar registers
                     } else {
-                        // (zoff is 0 at run time: with up to six columns the records are read where they are used — hoisted out of
-                        // the time loop they overflow the scalar register file, as in the generic group end below)
-                        const int jz = KMAX > 2 ? j + zoff : j;
-                        const int src = a.cols[jz].src;
+                        // (the empty asm makes the word opaque at this point: the six words stay in scalar registers through the time
+                        // loop while their decoded fields — a multiplier, masks and a trip count per column — are NOT hoisted out of
+                        // it, where they overflowed the scalar register file and came back through v_readlane)
+                        uint32_t cc = a.ccode[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" : "+s"(cc));
+#endif
+                        const int src = (int)(cc & 15u);
                         if ((FEAT & 1) && src == SRC_SINE) {
                             KEEP_BRANCH();
-                            if constexpr ((FEAT & 1) != 0) { const ColOp co = a.cols[jz]; sine_column(co, x); }
+                            // (the full record of a sine_dd column is read where it is used: zoff is 0, but only known at run time)
+                            if constexpr ((FEAT & 1) != 0) { const ColOp co = a.cols[KMAX > 2 ? j + zoff : j]; sine_column(co, x); }
+                        } else if constexpr (STAT == 1) {
+                            // mean | sum: s / n with n = 2 or 4 is s * (1 / n) exactly; one multiply by a scalar either way
+                            const double sc = src == SRC_SUM ? 1.0 : 1.0 / GL;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) x[i] = s[i] * sc;
                         } else {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) {
@@ -897,7 +929,47 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         // (continuing ONE double-double chain through consecutive exponents of a polynomial — 3 steps instead of 6 for
                         // power[1..4] — was built and measured: the chain state's registers cost more than the steps save, 5.8 -> 6.5 ms
                         // on 1801 x 3600 f32; profiles/r03_pairs_mean_poly.txt)
-                        if (a.cols[jz].tf == TF_POWI) powi_dd_vec<VEC>(x, a.cols[jz].tf_iarg);
+                        // powi_dd_vec's chain for exponents >= 2 (the host keeps e < 1 off the lean forms and lowers e = 1 to "none"),
+                        // written out: nested scalar branches with straight-line code for the squares, cubes and fourth powers of a
+                        // polynomial, and the column's add at every leaf (one merged add would cost a register copy per path)
+                        const int n = ((cc >> 4) & 15u) == (uint32_t)TF_POWI ? (int)(cc >> 8) : 1;
+                        if (n >= 2) {
+                            KEEP_BRANCH();
+                            double hi[VEC], lo[VEC];
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) hi[i] = x[i] * x[i];
+                            if (n >= 3) {
+                                KEEP_BRANCH();
+                                auto step = [&]() {
+#pragma unroll
+                                    for (int i = 0; i < VEC; ++i) {
+                                        const double p = hi[i] * x[i];
+                                        const double err = __fma_rn(hi[i], x[i], -p);
+                                        lo[i] = __fma_rn(lo[i], x[i], err);
+                                        hi[i] = p;
+                                    }
+                                };
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) lo[i] = __fma_rn(x[i], x[i], -hi[i]);
+                                step();
+                                if (n >= 4) {
+                                    KEEP_BRANCH();
+                                    step();
+                                    if (n > 4) {
+                                        KEEP_BRANCH();
+                                        for (int it = 4; it < n; ++it) step();
+                                    }
+                                }
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) os[j][i] += hi[i] + lo[i];
+                                asm volatile("; leaf: x^n, n >= 3");          // (distinct tails: the leaves are not merged back)
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) os[j][i] += hi[i];
+                                asm volatile("; leaf: x^2");
+                            }
+                            continue;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) os[j][i] += x[i];
