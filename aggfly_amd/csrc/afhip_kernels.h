@@ -929,7 +929,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         // (continuing ONE double-double chain through consecutive exponents of a polynomial — 3 steps instead of 6 for
                         // power[1..4] — was built and measured: the chain state's registers cost more than the steps save, 5.8 -> 6.5 ms
                         // on 1801 x 3600 f32; profiles/r03_pairs_mean_poly.txt)
-                        // powi_dd_vec's chain for exponents >= 2 (the host keeps e < 1 off the lean forms and lowers e = 1 to "none"),
+                        // powi_dd_vec's chain for exponents >= 2 (the host keeps e < 1 off the lean forms; e = 1 adds x itself),
                         // written out: nested scalar branches with straight-line code for the squares, cubes and fourth powers of a
                         // polynomial, and the column's add at every leaf (one merged add would cost a register copy per path)
                         const int n = ((cc >> 4) & 15u) == (uint32_t)TF_POWI ? (int)(cc >> 8) : 1;

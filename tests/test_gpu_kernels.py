@@ -683,7 +683,12 @@ def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
     sum_only_generic = [dict(inner="mean", outer="max"), dict(inner="sum", transform="hinge", transform_arg=20.0, outer="sum")]
     sine_only = [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="sine_dd", inner_args=(0, 18, 1), outer="mean")]
     light = [dict(inner="mean", outer="sum")]                  # one or two mean / sum columns stream through the LDS-DMA ring instead
-    for cols, expect in ((lean, "_pair_lean"), (lean2, "_pair_lean"), (sine_only, "_pair_ss"), (generic, "_pair"), (sum_only_generic, None), (light, None)):
+    # exponents below 1 are kept off the lean form (its written-out power chain starts at the square; no division code in it)
+    odd_powers = [dict(inner="max", transform="pow", transform_arg=-1, outer="sum"), dict(inner="min", transform="pow", transform_arg=0, outer="sum"),
+                  dict(inner="mean", transform="pow", transform_arg=5, outer="sum"), dict(inner="mean", transform="pow", transform_arg=1, outer="sum")]
+    high_powers = [dict(inner="mean", transform="pow", transform_arg=e, outer="mean") for e in (5, 7, 8)] + [dict(inner="max", outer="sum")]
+    for cols, expect in ((lean, "_pair_lean"), (lean2, "_pair_lean"), (sine_only, "_pair_ss"), (generic, "_pair"), (sum_only_generic, None), (light, None),
+                         (odd_powers, "_pair"), (high_powers, "_pair_lean")):
         plan = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, ib, ob, cols, exact_order=True)
         name = plan.describe().split()[0]
         if expect is None:
