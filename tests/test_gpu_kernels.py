@@ -780,3 +780,32 @@ def test_four_row_groups_take_the_lean_group_end(torch_cuda, dtype, shape):
     assert "_quad" not in ring.describe().split()[0]
     quadp = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
     np.testing.assert_allclose(quadp.run_temporal(d).cpu().numpy(), ring.run_temporal(d).cpu().numpy(), rtol=4e-15, equal_nan=True)
+
+
+@pytest.mark.parametrize("glen", [2, 4])
+@pytest.mark.parametrize("ngroups", [1, 2, 3, 5, 9])
+def test_short_group_plans_shorter_than_a_block_of_rows(torch_cuda, glen, ngroups):
+    """Chunks that hold fewer rows than the short-group forms keep in flight (8): the prologue loads only the rows that exist,
+    the group loop stops at the chunk's last group, and no request for "the next block" is issued past the end."""
+    from aggfly_amd import hip
+    T, ny, nx = glen * ngroups, 3, 70
+    rng = np.random.default_rng(5 + ngroups)
+    cube = (15 + rng.normal(0, 8, (T, ny, nx))).astype(np.float32)
+    cube[0, 0, 0] = np.nan
+    ib = np.arange(0, T + 1, glen, dtype=np.int64)
+    ob = np.array([0, ngroups], dtype=np.int64) if ngroups < 3 else np.array([0, 1, ngroups], dtype=np.int64)
+    cols = [dict(inner="max", outer="sum"), dict(inner="mean", transform="pow", transform_arg=3, outer="sum"),
+            dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum")]
+    d = torch_cuda.from_numpy(cube).cuda()
+    f64 = cube.astype(np.float64)
+    for dtype, code, dev in ((np.float32, hip.F32, d), (np.float64, hip.F64, d.double())):
+        plan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True)
+        assert "_pair" in plan.describe().split()[0], plan.describe()
+        got = plan.run_temporal(dev).cpu().numpy()
+        for k, col in enumerate(cols):
+            x = cport.resample(f64, ib, col["inner"], col.get("inner_args"))
+            if col.get("transform") == "pow":
+                x = cport.power(x, col["transform_arg"])
+            w = cport.resample(x, ob, col["outer"]).reshape(len(ob) - 1, -1)
+            assert np.array_equal(np.isnan(got[k]), np.isnan(w))
+            np.testing.assert_allclose(got[k], w, rtol=1e-10 if col["inner"] == "sine_dd" else 4e-15, atol=1e-10 if col["inner"] == "sine_dd" else 0, equal_nan=True)
