@@ -1148,6 +1148,52 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
     return AFHIP_OK;
 }
 
+// AFHIP_NO_SLOT_SPMM=1 (experiment / test knob, read per run): keep k_combine_slots + k_csr_spmm on every route.
+static bool slot_spmm_off() { return env_flag("AFHIP_NO_SLOT_SPMM"); }
+
+// sums[row][p][K + 1] straight from partial (k_csr_spmm_slots): slot merge, shared validity and the weighted sums of every
+// (segment, period) in one pass; then the pieces of cut rows.  The lanes per (segment, period) follow the table's mean
+// segment length — 64 for county-sized rows on a fine grid (and then bit-identical to combine + k_csr_spmm_wave), 8 for
+// tables whose regions hold a handful of cells.
+static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double* partial, hipStream_t st) {
+    const int64_t P = pl->desc.P, K = pl->K, Q = (K + 1) * P;
+    if (csr->nseg * P == 0) return AFHIP_OK;
+    SlotSpmmArgs sa{};
+    sa.seg_ptr = csr->seg_ptr.p; sa.dst = csr->seg_dst.p; sa.cols = csr->cols.p; sa.w = csr->w.p;
+    sa.partial = partial; sa.slot_ptr = pl->d_slot_ptr.p; sa.outer_bounds = pl->d_ob.p; sa.out = pl->sums;
+    sa.nseg = csr->nseg; sa.P = P; sa.C = pl->desc.n_cells; sa.K = (int32_t)K;
+    for (int j = 0; j < pl->K; ++j) {
+        sa.outer[j] = pl->cols[(size_t)j].outer;
+        sa.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
+    }
+    const int64_t mean_len = csr->nnz / std::max<int64_t>(csr->nseg, 1);
+    int sub = mean_len > 32 ? 64 : (mean_len > 16 ? 32 : (mean_len > 8 ? 16 : 8));
+    if (const char* e = getenv("AFHIP_SLOT_SPMM_SUB")) { const int s = atoi(e); if (s == 8 || s == 16 || s == 32 || s == 64) sub = s; }
+    const int64_t pairs = csr->nseg * P;
+    const int64_t blocks = (pairs * sub + WG - 1) / WG;
+    if (blocks > INT32_MAX) return fail(AFHIP_E_UNSUPPORTED, "plan_run: %lld (segment, period) pairs in one call", (long long)pairs);
+#define AFHIP_SLOTS_SUB(KB)                                                                                                   \
+    switch (sub) {                                                                                                            \
+        case 8: hipLaunchKernelGGL((k_csr_spmm_slots<KB, 8>), dim3((unsigned)blocks), dim3(WG), 0, st, sa); break;            \
+        case 16: hipLaunchKernelGGL((k_csr_spmm_slots<KB, 16>), dim3((unsigned)blocks), dim3(WG), 0, st, sa); break;          \
+        case 32: hipLaunchKernelGGL((k_csr_spmm_slots<KB, 32>), dim3((unsigned)blocks), dim3(WG), 0, st, sa); break;          \
+        default: hipLaunchKernelGGL((k_csr_spmm_slots<KB, 64>), dim3((unsigned)blocks), dim3(WG), 0, st, sa); break;          \
+    }
+    if (K <= 2) { AFHIP_SLOTS_SUB(2) }
+    else if (K <= 4) { AFHIP_SLOTS_SUB(4) }
+    else if (K <= 8) { AFHIP_SLOTS_SUB(8) }
+    else { AFHIP_SLOTS_SUB(16) }
+#undef AFHIP_SLOTS_SUB
+    HIP_TRY(hipGetLastError());
+    if (csr->n_split) {
+        const int64_t n = csr->n_split * Q;
+        hipLaunchKernelGGL(k_csr_combine_segments, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, pl->sums, csr->split_row.p,
+                           csr->split_ptr.p, csr->R, Q, csr->n_split);
+        HIP_TRY(hipGetLastError());
+    }
+    return AFHIP_OK;
+}
+
 static int ensure_ws(afhip_plan* pl, int64_t bytes, void* user_ws, char** base) {
     if (user_ws) { *base = (char*)user_ws; return AFHIP_OK; }
     if (pl->own_ws_bytes < bytes) {
@@ -1226,6 +1272,9 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
                 HIP_TRY(hipGetLastError());
             }
         }
+    } else if (!exact && !cells_dev && !plan->packed && K > 0 && !slot_spmm_off()) {
+        // no per-cell output wanted, no table-order promise: the weighted sums gather the slots directly (no panel)
+        if ((rc = launch_spmm_slots(plan, csr, partial, st))) return rc;
     } else {
         if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
         if ((rc = launch_spmm(csr, panel, plan->sums, Q, st, exact))) return rc;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
             acc[MAX_COLS] = __dadd_rn(acc[MAX_COLS], __dmul_rn(wj, valid ? 1.0 : 0.0));
         };
         int64_t j = j0;
-        for (; j + 4 <= j1; j += 4) {
+        for (; j + 4 <= j1; j += 4) {          // (eight in flight measured no better: 0.30 vs 0.27 ms on configs[3])
             uint64_t q[4][4];
             double wj[4];
 #pragma unroll
@@ -341,6 +341,130 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_wave(const int64_t* __restrict_
 #pragma unroll
         for (int q = 0; q < QB; ++q)
             if (q < Q) o[q] = acc[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_csr_spmm_slots: k_combine_slots + k_csr_spmm_wave in ONE pass, straight from partial[slot][K][C] — the cell-major panel
+// (K + 1 doubles per cell and period, written once and read back once: 0.5 GB on the reference's own benchmark shape, 12
+// monthly periods x 4 columns x 1.04 M cells, where the two kernels took 0.48 ms beside a 5.8 ms streaming pass) is never
+// built.  A group of SUB lanes owns one (row segment v, period p): the lanes stride over the segment's table entries (cols /
+// w read as contiguous runs; for regions that are runs of neighbouring cells, so are the K plane reads), every lane merges
+// the period's slots of its cell exactly like k_combine_slots (slot order; OUT_MEAN / ng; the reference's float32 rounding),
+// applies the shared validity rule (spatial.py:114-123: x = where(valid, x, 0), valid = no NaN among the K columns) and keeps
+// K + 1 partial sums; a fixed xor butterfly adds the SUB partials.  SUB = 64 reproduces k_csr_spmm_wave's sums bit for bit
+// (same per-lane order, same butterfly); smaller groups serve tables whose rows hold a handful of cells (several (v, p) pairs
+// per wave instead of 56 idle lanes).  SUB depends on the table only, never on the data: deterministic.  Not the table order
+// of np.add.at — exact_order plans keep k_combine_slots + k_csr_spmm.
+// ---------------------------------------------------------------------------------------
+struct SlotSpmmArgs {
+    const int64_t* seg_ptr;          // device [nseg + 1]
+    const int32_t* dst;              // device [nseg]: row of `out` a segment's sums go to
+    const int32_t* cols;
+    const double* w;
+    const double* partial;           // device [n_slots][K][C]
+    const int32_t* slot_ptr;         // device [P + 1]
+    const int64_t* outer_bounds;     // device [P + 1]
+    double* out;                     // device [rows][P][K + 1]
+    int64_t nseg, P, C;
+    int32_t K, pad;
+    int32_t outer[MAX_COLS];
+    int32_t round_final[MAX_COLS];
+};
+
+template <int KB, int SUB>
+__global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
+    static_assert(SUB == 8 || SUB == 16 || SUB == 32 || SUB == 64, "a power-of-two share of a wave");
+    const int64_t n = a.nseg * a.P;
+    const int64_t first = ((int64_t)blockIdx.x * WG + (threadIdx.x & ~63)) / SUB;     // the wave's first (v, p) pair
+    if (first >= n) return;                                        // whole waves leave together
+    const int64_t gid = ((int64_t)blockIdx.x * WG + threadIdx.x) / SUB;
+    const bool live = gid < n;                                     // (a last wave's spare groups redo the last pair, unstored)
+    const int64_t g = live ? gid : n - 1;
+    const int64_t v = g / a.P, p = g - v * a.P;
+    const int sl = threadIdx.x & (SUB - 1);
+    const int K = a.K;
+    const int64_t C = a.C;
+    const int s0 = a.slot_ptr[p], s1 = a.slot_ptr[p + 1];
+    const double ng = (double)(a.outer_bounds[p + 1] - a.outer_bounds[p]);
+    double acc[KB + 1];
+#pragma unroll
+    for (int k = 0; k <= KB; ++k) acc[k] = 0.0;
+    constexpr int UNR = KB <= 4 ? 4 : (KB <= 8 ? 2 : 1);           // entries in flight per lane
+    auto finish = [&](double (&x)[KB], double wj) {                // mean / rounding / validity / the K + 1 products
+        bool valid = true;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (k < K) {
+                if (a.outer[k] == OUT_MEAN) x[k] = x[k] / ng;
+                if (a.round_final[k]) x[k] = (double)(float)x[k];
+                valid = valid && (x[k] == x[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < K) acc[k] = __dadd_rn(acc[k], __dmul_rn(wj, valid ? x[k] : 0.0));
+        acc[KB] = __dadd_rn(acc[KB], __dmul_rn(wj, valid ? 1.0 : 0.0));
+    };
+    auto merged = [&](int k, int64_t c) -> double {                // a period cut into several slots: k_combine_slots' merge
+        double val = a.partial[((int64_t)s0 * K + k) * C + c];
+        const int o = a.outer[k];
+        for (int s = s0 + 1; s < s1; ++s) {
+            const double x = a.partial[((int64_t)s * K + k) * C + c];
+            if (o == OUT_MIN) { double t = (x < val) ? x : val; val = (x != x || val != val) ? nan64() : t; }
+            else if (o == OUT_MAX) { double t = (x > val) ? x : val; val = (x != x || val != val) ? nan64() : t; }
+            else if (o == OUT_FIRST) { /* a period is never split for OUT_FIRST */ }
+            else val += x;
+        }
+        return val;
+    };
+    if (s1 != s0) {                                                // else: empty resample bin — every cell invalid, all sums 0
+        const int64_t j0 = a.seg_ptr[v], j1 = a.seg_ptr[v + 1];
+        int64_t j = j0 + sl;
+        if (s1 == s0 + 1) {
+            const double* base = a.partial + (int64_t)s0 * K * C;
+            for (; j + (UNR - 1) * SUB < j1; j += UNR * SUB) {
+                double x[UNR][KB], wj[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t c = a.cols[j + u * SUB];
+                    wj[u] = a.w[j + u * SUB];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) x[u][k] = (k < K) ? base[(int64_t)k * C + c] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) finish(x[u], wj[u]);
+            }
+            for (; j < j1; j += SUB) {
+                double x[KB];
+                const int64_t c = a.cols[j];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) x[k] = (k < K) ? base[(int64_t)k * C + c] : 0.0;
+                finish(x, a.w[j]);
+            }
+        } else {
+            for (; j < j1; j += SUB) {
+                double x[KB];
+                const int64_t c = a.cols[j];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) x[k] = (k < K) ? merged(k, c) : 0.0;
+                finish(x, a.w[j]);
+            }
+        }
+    }
+    // xor butterfly inside the group: every lane of it ends with the same sums
+#pragma unroll
+    for (int m = SUB / 2; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int k = 0; k <= KB; ++k)
+            if (k < K || k == KB) acc[k] = __dadd_rn(acc[k], __shfl_xor(acc[k], m, 64));
+    }
+    if (sl == 0 && live) {
+        double* o = a.out + ((int64_t)a.dst[v] * a.P + p) * (K + 1);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < K) o[k] = acc[k];
+        o[K] = acc[KB];
     }
 }
 

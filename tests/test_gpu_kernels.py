@@ -223,8 +223,11 @@ def test_single_level_plan_panel_matches_the_definition(torch_cuda, dtype):
     assert "_sl" in plan.describe(), plan.describe()
     direct = plan.run(d, csr)
     twopass = plan.run(d, csr, want_cells=True)
+    # (without the per-cell output the weighted sums gather the slots directly, lanes striding over a row's entries + a fixed
+    # butterfly — k_csr_spmm_slots; with it they run in table order over the panel: the same numbers to rounding)
     for k in ("num", "den", "res"):
-        np.testing.assert_array_equal(direct[k].cpu().numpy(), twopass[k].cpu().numpy(), err_msg=k)
+        np.testing.assert_allclose(direct[k].cpu().numpy(), twopass[k].cpu().numpy(), rtol=1e-13, atol=1e-12 if k == "num" else 0,
+                                   equal_nan=True, err_msg=k)
     # and against the definition: shared validity, weighted sums in table order
     cells = twopass["cells"].cpu().numpy()                        # [K, P, C]
     valid = ~np.isnan(cells).any(axis=0)                          # [P, C]
@@ -498,7 +501,9 @@ def test_many_periods_and_grid_limits(torch_cuda):
     cells = plan.run_temporal(d).cpu().numpy()
     np.testing.assert_array_equal(cells[0].reshape(T, ny, nx), want.astype(np.float64))
     csr = hip.CSR([0, 0, 1, 1, 1], [0, 1, 2, 5, 7], [0.5, 0.5, 0.2, 0.3, 0.5], 2, ny * nx)
-    out = plan.run(d, csr)
+    out = plan.run(d, csr)                       # default: 140,000 (row, period) pairs of 8 lanes gather the slots directly
+    exact = hip.FusedPlan(T, ny * nx, hip.F32, ib, ib, [dict(inner="max"), dict(inner="dd", inner_args=(5, 15, 0))],
+                          exact_order=True).run(d, csr)              # table order: combine + one thread per (row, column)
     flat = want.astype(np.float64).reshape(T, -1)
     dd = cport.block_dd(cube, ib, [5, 15, 0])[..., 0].astype(np.float64).reshape(T, -1)
     valid = ~(np.isnan(flat) | np.isnan(dd))
@@ -509,7 +514,8 @@ def test_many_periods_and_grid_limits(torch_cuda):
             num = num + w * np.where(valid[:, c], flat[:, c], 0.0)
         with np.errstate(invalid="ignore", divide="ignore"):
             want_r = np.where(den != 0, num / den, np.nan)
-        np.testing.assert_array_equal(out["res"][0, r].cpu().numpy(), want_r)
+        np.testing.assert_array_equal(exact["res"][0, r].cpu().numpy(), want_r)
+        np.testing.assert_allclose(out["res"][0, r].cpu().numpy(), want_r, rtol=1e-14, equal_nan=True)
 
 
 def test_caller_workspace_and_side_stream(torch_cuda):
@@ -640,6 +646,86 @@ def test_skewed_rows_take_the_wave_and_segment_paths(torch_cuda):
     direct = plan.run(dd, csr)["res"].cpu().numpy()
     via_panel = plan.run(dd, csr, want_cells=True)["res"].cpu().numpy()
     np.testing.assert_allclose(direct, via_panel, rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("table", ["county", "tiny", "skewed"])
+def test_slot_gather_spatial_stage_against_the_panel_route_and_the_oracle(torch_cuda, monkeypatch, table):
+    """The default spatial stage of a plan run without per-cell output gathers the period slots directly (k_csr_spmm_slots:
+    slot merge + shared validity + weighted sums in one pass, no cell-major panel).  Checked against (a) the route it replaced
+    (k_combine_slots + k_csr_spmm*, AFHIP_NO_SLOT_SPMM=1): bit for bit where a whole wave serves a (segment, period) and the old
+    route was the wave kernel, 1e-12 otherwise; (b) exact_order plans (table order, spatial.py:181-186) at 1e-12; (c) the
+    oracle's spatial restatement on the plan's own per-cell values.  Tables: county-sized rows, rows of a handful of cells
+    (8 lanes per pair), log-normal rows with cut segments.  Plans: several periods incl. an empty one, periods cut into
+    several slots, outer mean / min / max, float32 rounding of the final value, NaN cells (shared validity), K = 1 .. 13."""
+    from aggfly_amd import hip
+    if table == "county":
+        ny, nx, R = 96, 160, 60
+        tab = synth.weights_table(ny, nx, R, seed=21, zero_frac=0.05)
+    elif table == "tiny":
+        ny, nx, R = 40, 64, 600
+        tab = synth.weights_table(ny, nx, R, seed=22, secondary=True)
+    else:
+        ny, nx, R = 200, 300, 300
+        tab = synth.weights_table(ny, nx, R, seed=23, skew="lognormal")
+    C = ny * nx
+    ridx, cidx, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+    nR = int(ridx.max()) + 1
+    csr = hip.CSR(ridx, cidx, w, nR, C)
+    mean_len = len(w) / nR
+    assert {"county": mean_len > 64, "tiny": mean_len <= 8, "skewed": True}[table]
+    T = 24 * 60
+    cube = _cube(T, ny, nx, np.float64, seed=24)
+    d = torch_cuda.from_numpy(cube).cuda()
+    ib = synth.hourly_bounds(T)
+    poly = [dict(inner="mean", transform="pow", transform_arg=float(e), outer="sum") for e in (1, 2, 3, 4)]
+    dd = dict(inner="dd", inner_args=(10, 30, 0), outer="sum")
+    plans = [
+        # (outer bounds over the 60 daily groups, columns)
+        (np.array([0, 60]), [dict(inner="mean", outer="sum")]),                                   # P = 1: the headline's shape
+        (np.array([0, 60]), [dd] + poly),
+        (np.array([0, 10, 10, 31, 60]), poly),                                                     # an empty period
+        (np.array([0, 7, 20, 33, 47, 60]), [dict(inner="mean", outer="mean"), dict(inner="max", outer="max"),
+                                            dict(inner="min", outer="min"), dd,
+                                            dict(inner="mean", outer="mean", rounding=hip.ROUND_FINAL)]),
+        (np.arange(0, 61, 5), [dict(inner="dd", inner_args=(float(t), float(t) + 7, 0), outer="sum") for t in range(-10, 29, 3)]),   # K = 13
+    ]
+    saw_split = False
+    for ob, cols in plans:
+        ob = ob.astype(np.int64)
+        K, P = len(cols), len(ob) - 1
+        plan = hip.FusedPlan(T, C, hip.F64, ib, ob, cols)
+        slots = int(plan.describe().split("out_slots=")[1].split()[0])
+        saw_split = saw_split or slots > P
+        fused = plan.run(d, csr)
+        monkeypatch.setenv("AFHIP_NO_SLOT_SPMM", "1")
+        panel = plan.run(d, csr)
+        monkeypatch.delenv("AFHIP_NO_SLOT_SPMM")
+        whole_wave = mean_len > 32 and (K + 1) * P <= 16            # 64 lanes per pair, and the old route was k_csr_spmm_wave
+        for key in ("num", "den", "res"):
+            a, b = fused[key].cpu().numpy(), panel[key].cpu().numpy()
+            if whole_wave:
+                np.testing.assert_array_equal(a, b)
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-9 if key == "num" else 0, equal_nan=True)
+        ex = hip.FusedPlan(T, C, hip.F64, ib, ob, cols, exact_order=True).run(d, csr, want_cells=True)
+        np.testing.assert_allclose(fused["res"].cpu().numpy(), ex["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(fused["den"].cpu().numpy(), ex["den"].cpu().numpy(), rtol=1e-12)
+        # the oracle's spatial stage on the default plan's own per-cell values (these may differ from the exact_order
+        # plan's in the last bits where a period is cut into chunks)
+        cells = plan.run(d, csr, want_cells=True)["cells"].cpu().numpy()                        # [K, P, C]
+        nums, den, _ = spatial_num_den({f"k{k:02d}": cells[k].T for k in range(K)}, tab, np.arange(C))
+        np.testing.assert_allclose(fused["den"].cpu().numpy(), den, rtol=1e-12)
+        for k in range(K):
+            np.testing.assert_allclose(fused["num"][k].cpu().numpy(), nums[f"k{k:02d}"], rtol=1e-12, atol=1e-9)
+    assert saw_split, "no plan of this test cut a period into several slots: the merge path went untested"
+    # every group width gives the same sums to rounding
+    ob = np.array([0, 20, 41, 60], dtype=np.int64)
+    plan = hip.FusedPlan(T, C, hip.F64, ib, ob, [dd] + poly)
+    want = plan.run(d, csr)["num"].cpu().numpy()
+    for sub in (8, 16, 32, 64):
+        monkeypatch.setenv("AFHIP_SLOT_SPMM_SUB", str(sub))
+        np.testing.assert_allclose(plan.run(d, csr)["num"].cpu().numpy(), want, rtol=1e-12, atol=1e-9)
+    monkeypatch.delenv("AFHIP_SLOT_SPMM_SUB")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
