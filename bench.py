@@ -550,6 +550,10 @@ def main():
                          "traffic_source": traffic_source, "traffic_build": traffic_build, "build": build,
                          "traffic_measured_on_this_build": bool(traffic_build) and traffic_build == build,
                          "kernel": "k_fused_temporal", "kernel_ms_mean": k_ms, "launches": len(kms),
+                         # the spread of the per-launch HIP-event times: a run that slows down as it goes (power / thermal) shows in
+                         # first10 vs last10, a process that sits in a slow mode from its first launch does not
+                         "kernel_ms": ({"min": float(np.min(kms)), "median": float(np.median(kms)), "max": float(np.max(kms)),
+                                        "first10_mean": float(np.mean(kms[:10])), "last10_mean": float(np.mean(kms[-10:]))} if kms else None),
                          "algorithmic_bytes_per_launch": T * my_C * elem},
         }
         if world > 1 and len({i[:2] for i in idents}) < world:
