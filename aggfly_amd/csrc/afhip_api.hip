@@ -216,7 +216,7 @@ struct afhip_plan {
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
-    bool hb_arith = false; double hb_w = 0, hb_lo0 = 0, hb_gl = 0, hb_gh = 0;   // ... with exactly representable edges
+    bool hb_arith = false; double hb_w = 0, hb_lo0 = 0, hb_gl = 0, hb_gh = 0, hb_c0b = 0;   // ... with exactly representable edges (+ the biased guess constant)
     int xcd_remap = 1;        // measured +0.2..1 % on configs[1] (profiles/r01_xcd_remap.txt): harmless, kept on
     bool counts_spmm = true;  // packed-count plans: gather the records directly when no per-cell output is asked for
     bool packed = false;      // single-level, all columns plain bin counts: partial holds packed records (FusedArgs::packed)
@@ -948,8 +948,38 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
                 }
                 ex = ex && gl > lo0 && gl < e0 && gh > pl->hb_edge[n] && gh < pl->hb_edge[n] + w;
             }
+            // the one-sided guess (ha_update): the guess constant biased down by the smallest delta of a ladder for which, with the
+            // kernel's own fma in the input precision, every edge E[k] of the guarded partition guesses bin k - 1 and the clamp
+            // points guess their guard bins.  fma and floor are monotone in v, so every value of [E[t], E[t+1]) then guesses t - 1
+            // or t.  No delta fits (bins of a few ulps): the table form.
+            double c0b = 0.0;
+            if (ex) {
+                const double c1 = pl->hb_c1, c0 = pl->hb_c0;
+                bool found = false;
+                for (int k = (desc->dtype == AFHIP_F32 ? 22 : 50); !found && k >= 8; --k) {
+                    const double delta = std::ldexp(1.0, -k);
+                    bool okd = true;
+                    if (desc->dtype == AFHIP_F32) {
+                        const float c1f = (float)c1, cbf = (float)(c0 - delta);
+                        auto guess = [&](double v) { return (double)floorf(fmaf((float)v, c1f, cbf)); };
+                        for (int g = 1; okd && g <= n + 1; ++g) okd = guess(pl->hb_edge[g - 1]) == (double)(g - 1);
+                        okd = okd && guess(gl) == 0.0 && guess(gh) == (double)(n + 1);
+                        if (okd) c0b = (double)cbf;
+                    } else {
+                        const double cb = c0 - delta;
+                        auto guess = [&](double v) { return floor(fma(v, c1, cb)); };
+                        for (int g = 1; okd && g <= n + 1; ++g) okd = guess(pl->hb_edge[g - 1]) == (double)(g - 1);
+                        okd = okd && guess(gl) == 0.0 && guess(gh) == (double)(n + 1);
+                        if (okd) c0b = cb;
+                    }
+                    found = okd;
+                }
+                ex = found;
+            }
+            // (these variants address a row by a 32-bit byte offset per lane)
+            if ((uint64_t)desc->n_cells * (desc->dtype == AFHIP_F64 ? 8u : 4u) >= (1ull << 32)) ex = false;
             if (getenv("AFHIP_NO_ARITH_EDGES")) ex = false;       // experiment knob: force the table form
-            pl->hb_arith = ex; pl->hb_w = w; pl->hb_lo0 = lo0; pl->hb_gl = gl; pl->hb_gh = gh;
+            pl->hb_arith = ex; pl->hb_w = w; pl->hb_lo0 = lo0; pl->hb_gl = gl; pl->hb_gh = gh; pl->hb_c0b = c0b;
         }
     }
     if (pl->hb_n > 0 && tuning == 0) { want_pipe = 0; want_vec = 1; }   // the LDS histogram lives on the direct-load path
@@ -1120,6 +1150,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         }
         fa.hb_w = pl->hb_w; fa.hb_lo0 = pl->hb_lo0; fa.hb_gl = pl->hb_gl; fa.hb_gh = pl->hb_gh;
         fa.hb_wf = (float)pl->hb_w; fa.hb_lo0f = (float)pl->hb_lo0; fa.hb_glf = (float)pl->hb_gl; fa.hb_ghf = (float)pl->hb_gh;
+        fa.hb_c0b = pl->hb_c0b; fa.hb_c0bf = (float)pl->hb_c0b;
     }
     HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;

@@ -112,6 +112,13 @@ struct FusedArgs {
     uint8_t pk_word[MAX_COLS], pk_shift[MAX_COLS];
     double hb_w, hb_lo0, hb_gl, hb_gh;
     float hb_wf, hb_lo0f, hb_glf, hb_ghf;
+    // ... and the guess constant biased DOWN (hb_c0 - delta, host-chosen): floor(v * hb_c1 + hb_c0b) is then never above the
+    // value's bin and at most one below it, and an edge value E[k] always guesses k - 1 — checked by the host on every edge
+    // with the kernel's own fma in the input precision; the fma and the floor are monotone in v, so the edges decide it for
+    // every value between them (ha_update)
+    double hb_c0b;
+    float hb_c0bf;
+    int32_t hb_pad;
     ThrSlot thr[MAX_THR];
     ColOp cols[MAX_COLS];
     // the lean group end's view of a column in ONE word (src | tf << 4 | (tf_iarg & 0xff) << 8): six of them stay in scalar
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     }
     const int hb_bins = a.hb_n + 2;
     TIn hb_c1 = 0, hb_c0 = 0, hb_top = 0;
-    TIn ha_w = 0, ha_lo0 = 0, ha_e0 = 0, ha_gl = 0, ha_gh = 0;
+    TIn ha_w = 0, ha_c0b = 0, ha_e0 = 0, ha_gl = 0, ha_gh = 0;
     int hb_sh = 0, hb_lane[VEC] = {0};
     if constexpr (HB) {
         if (tid < hb_bins) {
@@ -679,11 +686,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         else { hb_c1 = a.hb_c1; hb_c0 = a.hb_c0; }
         hb_top = (TIn)(a.hb_n + 1);
         if constexpr (HA) {
-            if constexpr (sizeof(TIn) == 4) { ha_w = a.hb_wf; ha_lo0 = a.hb_lo0f; ha_gl = a.hb_glf; ha_gh = a.hb_ghf; }
-            else { ha_w = a.hb_w; ha_lo0 = a.hb_lo0; ha_gl = a.hb_gl; ha_gh = a.hb_gh; }
-            ha_e0 = ha_lo0 + ha_w;                                  // exact (host-checked)
+            if constexpr (sizeof(TIn) == 4) { ha_w = a.hb_wf; ha_e0 = a.hb_lo0f + a.hb_wf; ha_gl = a.hb_glf; ha_gh = a.hb_ghf; ha_c0b = a.hb_c0bf; }
+            else { ha_w = a.hb_w; ha_e0 = a.hb_lo0 + a.hb_w; ha_gl = a.hb_gl; ha_gh = a.hb_gh; ha_c0b = a.hb_c0b; }   // (lo0 + w: exact, host-checked)
             // VOP3 takes one scalar operand: keep the second operand of the clamp and the fma addends in VGPRs
-            asm volatile("" : "+v"(ha_gh), "+v"(ha_lo0), "+v"(ha_e0));
+            asm volatile("" : "+v"(ha_gh), "+v"(ha_c0b), "+v"(ha_e0));
         }
         asm volatile("" : "+v"(hb_c0));      // keep the addend in a VGPR: v_fma takes one scalar operand only
         hb_sh = a.hb_shift + 2 + (VEC == 4 ? 2 : (VEC == 2 ? 1 : 0));     // byte stride between bins = VEC * blockDim * 4
@@ -736,27 +742,29 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         if (count)
             __hip_atomic_fetch_add((int*)((char*)hcnt + (b << hb_sh) + hb_lane[i]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
-    // arithmetic-edge form of hb_guess + hb_count: no table read
+    // arithmetic-edge form of hb_guess + hb_count: no table read, and (round 3) a ONE-SIDED guess.  With the guess constant biased
+    // down by a host-chosen delta, tf = floor(vc * c1 + c0b) is the value's bin or the one below it, and exactly the one below for a
+    // value ON an edge (FusedArgs::hb_c0b: the host checks every edge with this very fma; fma and floor are monotone, so what holds
+    // at E[k] and E[k + 1] holds between them).  Only the UPPER edge of the guessed bin is then needed, hi = E[tf + 1] (one exact
+    // fma):  vc > hi -> bin tf + 1;  vc == hi -> on an edge, in no bin (strict inequalities, nb_kernels.py:190-196);  else bin tf.
+    // 9 VALU per element where the two-sided form (both edges, two repairs, two equality tests) took 14: the kernel had become
+    // issue-bound beside its stream (16 VALU per 4-byte element with the address arithmetic: the vector ALUs ~70 % busy,
+    // profiles/r03_c4_bound_pmc.txt).
     auto ha_update = [&](TIn vr, int i) {
         TIn vc;                                                     // clamped into the guarded range; NaN -> lower guard bin
         if constexpr (sizeof(TIn) == 4) vc = __builtin_amdgcn_fmed3f(vr, ha_gl, ha_gh);
         else vc = fmin(fmax(vr, ha_gl), ha_gh);
-        TIn tf, lo, hi;
+        TIn tf, hi;
         if constexpr (sizeof(TIn) == 4) {
-            tf = __builtin_floorf(__fmaf_rn(vc, hb_c1, hb_c0));
-            lo = __fmaf_rn(tf, ha_w, ha_lo0);                       // E[b] and E[b + 1], exactly
-            hi = __fmaf_rn(tf, ha_w, ha_e0);
+            tf = __builtin_floorf(__fmaf_rn(vc, hb_c1, ha_c0b));
+            hi = __fmaf_rn(tf, ha_w, ha_e0);                        // E[tf + 1], exactly
         } else {
-            tf = __builtin_floor(__fma_rn(vc, hb_c1, hb_c0));
-            lo = __fma_rn(tf, ha_w, ha_lo0);
+            tf = __builtin_floor(__fma_rn(vc, hb_c1, ha_c0b));
             hi = __fma_rn(tf, ha_w, ha_e0);
         }
-        // branch-free repair of a guess that is off by one (carry-in adds), and a value ON an edge is in no bin
         int b = (int)tf;
-        b += (vc >= hi) ? 1 : 0;
-        b -= (vc <= lo) ? 1 : 0;
-        const bool on_edge = (vc == hi) | (vc == lo);
-        if (!on_edge) {
+        b += (vc > hi) ? 1 : 0;                                     // (a carry-in add)
+        if (vc != hi) {
             int* p = (int*)((char*)hcnt + (b << hb_sh) + hb_lane[i]);
 #ifdef HA_PLAIN_RMW
             *p = *p + 1;                                              // the counter is private to this lane
@@ -1264,6 +1272,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     } else if constexpr (PIPE == 0) {
         const TIn* p = cube;
+        // histogram variants with arithmetic edges are issue-bound beside their stream: their rows are addressed like the short-group
+        // forms' — ONE scalar row pointer in a buffer descriptor + the lane's 32-bit byte offset, no vector address arithmetic (a
+        // global_load wants a 64-bit vector address: one v_lshl_add_u64 per row and lane, a fifteenth of the element's instructions);
+        // the host keeps plans whose rows reach 4 GiB off these variants
+        const char* nx = (const char*)a.cube + (size_t)(k_lo * C) * sizeof(TIn);
+        const uint32_t voff = (uint32_t)((uint64_t)c_ld * sizeof(TIn));
+        const size_t rowb = (size_t)C * sizeof(TIn);
         // group table word for g is fetched one group ahead: its scalar-load latency hides behind
         // the previous group's work (matters for 1-2 step groups: daily data, tmin/tmax pairs)
         int64_t w_next = ld_uniform(&a.gtab[2 * g]), iv_next = ld_uniform(&a.gtab[2 * g + 1]);
@@ -1279,6 +1294,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             // ring that re-arms each row's load right after the row is consumed, across group ends, was
             // measured too: f64 6.88 -> 6.48 TB/s, f32 unchanged.  Bursts of DEPTH rows per wave win.)
             auto load_block = [&](RawVec<TIn, VEC> (&r)[DEPTH]) {
+                if constexpr (HA) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) { r[d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+                    return;
+                }
 #pragma unroll
                 for (int d = 0; d < DEPTH; ++d) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
                 p += (int64_t)DEPTH * C;
@@ -1315,10 +1335,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             if (kk < gend) {
                 const int rem = gend - kk;
                 RawVec<TIn, VEC> r[DEPTH];
+                if constexpr (HA) {
 #pragma unroll
-                for (int d = 0; d < DEPTH - 1; ++d)
-                    if (d < rem) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
-                p += (int64_t)rem * C;
+                    for (int d = 0; d < DEPTH - 1; ++d)
+                        if (d < rem) { r[d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < DEPTH - 1; ++d)
+                        if (d < rem) r[d] = ld_stream<TIn, VEC, AUX>(p + (int64_t)d * C);
+                    p += (int64_t)rem * C;
+                }
 #pragma unroll
                 for (int d = 0; d < DEPTH - 1; ++d)
                     if (d < rem) consume(r[d]);

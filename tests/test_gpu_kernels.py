@@ -424,6 +424,48 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("part", [(-20.0, 5.0, 13), (0.0, 1.0, 16), (-7.5, 2.5, 12), (250.0, 10.0, 8), (-1.0, 0.25, 9), (-64.0, 8.0, 16),
+                                  (1024.0, 0.5, 6), (-3.0, 0.125, 11)])
+def test_arithmetic_edge_histogram_one_sided_guess_on_every_edge(torch_cuda, dtype, part):
+    """The arithmetic-edge histogram guesses a value's bin with a constant biased DOWN (chosen by the host per partition, checked
+    on every edge with the kernel's own fma) and repairs upward only (`ha_update`): a value ON an edge must guess the bin below
+    and land in no bin, values 1 .. 3 ulps to either side in the neighbouring bins — for every edge of several exactly
+    representable partitions (first edge, width, bins), with out-of-range values of every size, signed zeros, NaN and
+    infinities in the guard bins.  Bit-exact against the oracle's compare chain (nb_kernels.py:182-199)."""
+    from aggfly_amd import hip
+    e0, w, n = part
+    edges = (e0 + w * np.arange(n + 1)).astype(np.float64)
+    assert np.all(edges.astype(dtype).astype(np.float64) == edges)          # exactly representable: the arithmetic form's premise
+    T, ny, nx = 400, 4, 16
+    rng = np.random.default_rng(int(abs(e0) * 8 + n))
+    cube = rng.uniform(edges[0] - 2 * w, edges[-1] + 2 * w, (T, ny, nx)).astype(dtype)
+    flat = cube.reshape(-1)
+    plant = []
+    for e in edges.astype(dtype):
+        up = dn = e
+        plant.append(e)
+        for _ in range(3):
+            up = np.nextafter(up, dtype(np.inf)); dn = np.nextafter(dn, dtype(-np.inf))
+            plant += [up, dn]
+    plant += [dtype(v) for v in (0.0, -0.0, 1e-30, -1e-30, 1e30, -1e30, np.inf, -np.inf, np.nan,
+                                 np.finfo(dtype).max, -np.finfo(dtype).max, np.finfo(dtype).tiny, edges[0] - 0.5 * w, edges[-1] + 0.5 * w)]
+    plant = np.array(plant * 6, dtype=dtype)
+    flat[rng.choice(flat.size, plant.size, replace=False)] = plant
+    bounds = np.array([0, 150, 400], dtype=np.int64)
+    dda = [[edges[i], edges[i + 1], 0] for i in range(n)]
+    want = cport.block_bins(cube, bounds, dda)                               # [G, ny, nx, D]
+    d = torch_cuda.from_numpy(cube).cuda()
+    plan = hip.FusedPlan(T, ny * nx, hip.F64 if dtype == np.float64 else hip.F32, bounds, np.arange(3),
+                         [dict(inner="bins", inner_args=r) for r in dda], exact_order=True)
+    assert "_hist_arith" in plan.describe(), plan.describe()
+    got = plan.run_temporal(d).cpu().numpy()                                 # [D, G, cells]
+    np.testing.assert_array_equal(np.transpose(got, (1, 2, 0)), want.reshape(2, -1, n))
+    # every planted edge value really sits in no bin: the counts of a cell add up to its steps minus its edge / NaN / out-of-range values
+    inside = (cube > edges[0]) & (cube < edges[-1]) & ~np.isin(cube, edges.astype(dtype))
+    np.testing.assert_array_equal(got[:, 0].sum(axis=0), inside[:150].reshape(150, -1).sum(axis=0))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("edges", ["tenths", "kelvin"])
 def test_lds_histogram_with_edges_that_float32_cannot_represent(torch_cuda, dtype, edges):
     """The histogram path guesses the bin in the input precision and repairs the guess against the
