@@ -149,9 +149,11 @@ def cpu_baseline(T, ny_sample, nx, seed, target_s=12.0):
     return {"value": T * ny_sample * nx / dt, "unit": "grid-cell-timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{ny_sample}x{nx} latitude band of the workload grid, T={T}, fp64, {reps} passes of {dt:.2f} s "
                       f"(C/OpenMP port of the reference's numba engine, oracle/c: `omp parallel for` over the band's {ny_sample} grid rows like "
-                      "prange(NY), each cell walking time with the reference's stride of a whole grid row — cache-hostile, and on this band "
-                      "SLOWER than the vectorised numpy restatement of the dask path, whereas the reference's real numba engine is ~12x "
-                      "faster than its dask engine (internal/backend-plan.md:4): not a stand-in for numba's speed, only for its arithmetic)"}
+                      "prange(NY), each cell walking time with the reference's stride of a whole grid row, the raw data re-read once per output "
+                      f"name: 5 names -> {5 * T * ny_sample * nx / dt / cores / 1e6:.0f} M raw elements/s per core; the reference's published numba run — 4 names, "
+                      "15.2 s for 8760x721x1440 on 32 cores, internal/backend-plan.md:4 — works out to 75 M per core, so the port stands in for numba's "
+                      "speed as well as its arithmetic.  It is slower than the numpy restatement of the dask path only because that restatement "
+                      "carries none of dask's scheduling overhead: the reference's own dask engine is 12x SLOWER than its numba engine)"}
 
 
 def cpu_baseline_dask_path(T, ny_sample, nx, seed, target_s=8.0):

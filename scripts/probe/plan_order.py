@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--n", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--short", action="store_true", help="forward and reversed series only (for counter passes)")
+    ap.add_argument("--dummy-mb", type=int, default=0, help="a sacrificial HBM allocation of this size made after the cube, before any plan")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     C = a.ny * a.nx
@@ -62,6 +63,7 @@ def main():
     R = int(wdf["index_right"].max()) + 1
     csr = hip.CSR(wdf["index_right"].to_numpy(), wdf["cell_id"].to_numpy(), wdf["weight"].to_numpy(), R, C)
     code = hip.F64 if a.dtype == "f64" else hip.F32
+    dummy = torch.empty(a.dummy_mb << 20, dtype=torch.uint8, device="cuda") if a.dummy_mb else None
     plans = [hip.FusedPlan(a.T, C, code, ib, ob, cols) for _ in range(a.n)]
     print(plans[0].describe(), flush=True)
     outs = [p.run(cube, csr) for p in plans]          # warm: workspaces allocated, results buffers kept
