@@ -673,7 +673,21 @@ static int build_chunks(afhip_plan* pl, int vec) {
     if (hist) per_cu = 96;   // ... except for the histogram kernel (above)
     if (const char* e = getenv("AFHIP_WGS_PER_CU")) per_cu = std::max(1, atoi(e));   // experiment knob
     const int64_t want_wgs = (int64_t)cu_count(pl->device) * per_cu * (WG / pl->wg);
-    const int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
+    int64_t want_chunks = std::max<int64_t>(1, (want_wgs + pl->tiles - 1) / pl->tiles);
+    // Plans with several output periods: up to one time chunk per period.  Cutting ON period boundaries adds no slot and no traffic
+    // (the "fewer chunks are better" of round 1 was measured at P = 1, where every cut adds a slot), and the period-end stores are
+    // what such plans pay for: with the stores compiled out the configs[1] plan runs P = 12 and P = 73 exactly as fast as P = 1
+    // (3.14 ms), with them 3.69 and 4.30 — 150 MB of stores for 0.55 ms, box-dependent (0.22 ms on another box).  The more chunks, the
+    // fewer period ends a workgroup carries in the middle of its stream: P = 365 5.24 -> 4.94 ms, P = 73 3.76 -> 3.46, weekly f32
+    // 1.72 -> 1.67, the reference's own benchmark shape 5.64 -> 5.53 (profiles/r03_period_end_stores.txt).  lay_chunks still
+    // packs periods shorter than 64 steps together; the histogram kernel keeps its own rule.
+    // Plans that already get eight chunks or more keep them (configs[2]'s shape, 14 chunks for 40 years: 40 measured 0.5 % behind).
+    bool period_chunks = false;
+    if (P > 1 && !hist && want_chunks < 8 && !getenv("AFHIP_WGS_PER_CU") && !getenv("AFHIP_NO_PERIOD_CHUNKS")) {
+        const int64_t by_period = std::min<int64_t>(P, std::max<int64_t>(1, (int64_t)262144 / std::max<int64_t>(pl->tiles, 1)));
+        // (a handful of period chunks makes a handful of occupancy rounds with a costly last one: P = 4 measured 2-4 % behind one chunk)
+        if (by_period >= 8) { want_chunks = by_period; period_chunks = true; }
+    }
     int rc = lay_chunks(pl, want_chunks);
     if (rc) return rc;
     // Rounds.  A CU holds `resident` workgroups of this variant at once; a grid of more workgroups than the chip holds runs in
@@ -681,7 +695,8 @@ static int build_chunks(afhip_plan* pl, int vec) {
     // 2,028 tiles as ONE chunk against 1,536 resident workgroups = 1.32 rounds) ran at 0.65 of the HBM peak, as three chunks
     // (3.96 rounds) at 0.79 (profiles/r03_ref_shape_arms.txt).  When the grid does not fit the chip at once, take the chunk
     // count (of the next few) whose last round is fullest; a grid that fits keeps the fewest chunks, which measured best.
-    if (!getenv("AFHIP_NO_ROUND_FILL") && !getenv("AFHIP_WGS_PER_CU")) {
+    // (period-aligned chunks are many and short: their last round weighs little, and the search below would cut periods to fill it)
+    if (!period_chunks && !getenv("AFHIP_NO_ROUND_FILL") && !getenv("AFHIP_WGS_PER_CU")) {
         const int64_t capacity = (int64_t)resident_wgs_per_cu(pl) * cu_count(pl->device);
         auto fill = [&](int64_t total) { const int64_t rounds = (total + capacity - 1) / capacity; return (double)total / (double)(rounds * capacity); };
         int64_t total = pl->tiles * (int64_t)pl->chunks.size();

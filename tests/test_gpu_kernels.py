@@ -560,6 +560,43 @@ def test_many_periods_and_grid_limits(torch_cuda):
         np.testing.assert_allclose(out["res"][0, r].cpu().numpy(), want_r, rtol=1e-14, equal_nan=True)
 
 
+def test_many_period_plans_take_one_time_chunk_per_period(torch_cuda, monkeypatch):
+    """Plans with eight or more output periods on a grid that would otherwise stream as a few long chunks are cut into one time
+    chunk per period (no extra slot: whole periods stay together, so every per-cell value is bit-identical to the few-chunk
+    layout); fewer periods keep round 2's rule (`afhip_api.hip:build_chunks`, profiles/r03_period_end_stores.txt)."""
+    from aggfly_amd import hip
+    torch = torch_cuda
+    T, ny, nx = 12 * 64, 512, 512                                   # 512 tiles of 256 threads x 2 cells: round 2's rule makes two chunks
+    g = torch.Generator(device="cuda").manual_seed(31)
+    d = (15 + 12 * torch.randn((T, ny, nx), generator=g, device="cuda", dtype=torch.float32))
+    d[5, 3, 7] = float("nan")
+    ib = np.arange(0, T + 1, 16, dtype=np.int64)                     # 48 inner groups of 16 steps
+    cols = [dict(inner="mean", transform="pow", transform_arg=2.0, outer="sum"), dict(inner="dd", inner_args=(10, 30, 0), outer="sum")]
+
+    def chunks_slots(plan):
+        txt = plan.describe()
+        return int(txt.split("chunks=")[1].split()[0]), int(txt.split("out_slots=")[1].split()[0])
+
+    ob12 = np.arange(0, 49, 4, dtype=np.int64)                       # 12 periods of 64 steps
+    new = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob12, cols)
+    assert chunks_slots(new) == (12, 12), new.describe()
+    monkeypatch.setenv("AFHIP_NO_PERIOD_CHUNKS", "1")
+    old = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob12, cols)
+    monkeypatch.delenv("AFHIP_NO_PERIOD_CHUNKS")
+    assert chunks_slots(old)[0] < 8 and chunks_slots(old)[1] == 12, old.describe()      # whole periods either way
+    got = new.run_temporal(d).cpu().numpy()
+    np.testing.assert_array_equal(got, old.run_temporal(d).cpu().numpy())
+    ob4 = np.arange(0, 49, 12, dtype=np.int64)                       # four periods: too few chunks to be worth their last round
+    few = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob4, cols)
+    assert chunks_slots(few)[0] < 8 and chunks_slots(few)[1] == 4, few.describe()
+    # the oracle on the first four grid rows (2,048 cells), on the same values as float64: the plan was built without the
+    # reference's float32 intermediates (`rounding`), so its arithmetic is float64 from the first add on
+    band = d[:, :4, :].cpu().numpy().astype(np.float64)
+    want = _oracle_two_level(band, ib, ob12, cols)
+    np.testing.assert_array_equal(got[1][:, :4 * nx], want[1])       # dd -> sum: bit-exact
+    np.testing.assert_allclose(got[0][:, :4 * nx], want[0], rtol=4e-16, equal_nan=True)      # mean^2 -> sum
+
+
 def test_caller_workspace_and_side_stream(torch_cuda):
     """The ABI's ownership rules: work is enqueued on the caller's stream and may use a
     caller-owned workspace; results equal the plan-owned / default-stream run."""
