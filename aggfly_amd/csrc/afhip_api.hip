@@ -195,7 +195,77 @@ struct afhip_csr {
     DevBuf<int32_t> seg_dst;
     DevBuf<int32_t> split_row;      // [n_split] regions that were cut
     DevBuf<int32_t> split_ptr;      // [n_split + 1] their pieces: scratch rows R + [split_ptr[i], split_ptr[i+1])
+    // host copies of the table (the run tables of the region-fused period ends are built from them on first use)
+    std::vector<int64_t> h_indptr;
+    std::vector<int32_t> h_cols;
+    std::vector<double> h_w;
+    // Region-fused period ends (FusedArgs::rf_w): per wave-tile size (64 * vec cells) the runs of consecutive cells whose e-th table
+    // entry (e = 0, 1, in table order) names the same region.  ok = false: a cell sits in more than two regions, or the runs are so
+    // short that per-run sums would not be fewer bytes than per-cell values — the plan keeps the per-cell route.
+    struct RfTab {
+        bool built = false, ok = false;
+        int64_t n_runs = 0;
+        DevBuf<double> w2;            // [n_cells][2]
+        DevBuf<int32_t> tile;         // [wave tiles][2][2]
+        DevBuf<uint16_t> run;         // [n_runs]
+        DevBuf<int64_t> reg_ptr;      // [R + 1]
+        DevBuf<int32_t> reg_runs;     // [n_runs] run ids by region, ascending inside a region
+    };
+    RfTab rf[3];                    // vec = 1, 2, 4
+    std::mutex rf_mu;
 };
+
+// Builds (once) the run tables for wave tiles of 64 * vec cells.  Returns the table, or nullptr when the route does not apply.
+static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
+    const int slot = vec == 1 ? 0 : (vec == 2 ? 1 : (vec == 4 ? 2 : -1));
+    if (slot < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(csr->rf_mu);
+    afhip_csr::RfTab& t = csr->rf[slot];
+    if (t.built) return t.ok ? &t : nullptr;
+    t.built = true;
+    const int64_t C = csr->n_cells, R = csr->R, tc = (int64_t)64 * vec, nt = (C + tc - 1) / tc;
+    std::vector<int32_t> reg((size_t)C * 2, -1);
+    std::vector<double> w2((size_t)C * 2, 0.0);
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t j = csr->h_indptr[(size_t)r]; j < csr->h_indptr[(size_t)r + 1]; ++j) {
+            const size_t c = (size_t)csr->h_cols[(size_t)j];
+            const int e = reg[2 * c] < 0 ? 0 : (reg[2 * c + 1] < 0 ? 1 : 2);
+            if (e == 2) return nullptr;                              // a third region on one cell: per-cell route
+            reg[2 * c + e] = (int32_t)r; w2[2 * c + e] = csr->h_w[(size_t)j];
+        }
+    // (+ 4 empty tiles: the waves of the last workgroup that start beyond the grid look their tile up too)
+    std::vector<int32_t> tile((size_t)(nt + 4) * 4, 0), run_region;
+    std::vector<uint16_t> run;
+    for (int64_t ti = 0; ti < nt; ++ti)
+        for (int e = 0; e < 2; ++e) {
+            const int64_t c_lo = ti * tc, c_hi = std::min(C, c_lo + tc);
+            tile[(size_t)(ti * 2 + e) * 2] = (int32_t)run.size();
+            int64_t start = -1; int32_t key = -1;
+            auto close = [&](int64_t c_end) {
+                if (key >= 0) { run.push_back((uint16_t)((start - c_lo) | ((c_end - start - 1) << 8))); run_region.push_back(key); }
+            };
+            for (int64_t c = c_lo; c < c_hi; ++c) {
+                const int32_t k = reg[(size_t)(2 * c + e)];
+                if (k != key) { close(c); key = k; start = c; }
+            }
+            close(c_hi);
+            tile[(size_t)(ti * 2 + e) * 2 + 1] = (int32_t)run.size() - tile[(size_t)(ti * 2 + e) * 2];
+        }
+    t.n_runs = (int64_t)run.size();
+    if (t.n_runs == 0 || t.n_runs > INT32_MAX) return nullptr;
+    // worth it only when the runs are clearly fewer than the cells (every run writes K + 1 sums where a cell writes K values)
+    if (t.n_runs * 3 > C) return nullptr;
+    std::vector<int64_t> reg_ptr((size_t)R + 1, 0);
+    for (int32_t r : run_region) ++reg_ptr[(size_t)r + 1];
+    for (int64_t r = 0; r < R; ++r) reg_ptr[(size_t)r + 1] += reg_ptr[(size_t)r];
+    std::vector<int32_t> reg_runs((size_t)t.n_runs);
+    { std::vector<int64_t> at(reg_ptr.begin(), reg_ptr.end() - 1);
+      for (int64_t q = 0; q < t.n_runs; ++q) reg_runs[(size_t)at[(size_t)run_region[(size_t)q]]++] = (int32_t)q; }
+    DeviceGuard g(csr->device);
+    if (t.w2.upload(w2) || t.tile.upload(tile) || t.run.upload(run) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
+    t.ok = true;
+    return &t;
+}
 
 struct afhip_plan {
     int device = 0;                       // the device the plan's tables and scratch live on (current device at afhip_plan_create)
@@ -213,6 +283,9 @@ struct afhip_plan {
     std::vector<int32_t> slot_ptr;        // [P+1]
     int64_t n_slots = 0;
     const Variant* variant = nullptr;
+    const Variant* variant_rf = nullptr;   // its twin with the region-fused period ends compiled in (null: none in the menu)
+    bool rf_plan_ok = false;               // the plan's columns and slots allow the route (the table decides the rest at run time)
+    int last_route = 0;                    // 1: the last afhip_plan_run took the region-fused route (afhip_plan_describe tells)
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
@@ -292,6 +365,7 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
     auto* h = new afhip_csr();
     h->device = current_device();
     h->R = R; h->nnz = nnz; h->n_cells = n_cells;
+    h->h_indptr.assign(indptr, indptr + R + 1); h->h_cols = c32; h->h_w.assign(w, w + nnz);
     std::vector<int64_t> seg_ptr;
     std::vector<int32_t> seg_dst, split_row, split_ptr(1, 0);
     seg_ptr.reserve((size_t)R + 1); seg_dst.reserve((size_t)R);
@@ -1022,6 +1096,31 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     }
     pl->variant = v;
     if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
+    // Region-fused period ends (FusedArgs::rf_w): the twin variant, if the menu has one, and what the plan itself must satisfy —
+    // sum-like outer reducers without float32 rounding of the final value (the period value must enter the weighted sum as it
+    // leaves the accumulator), at most one slot per period (shared validity needs the whole period's value), several periods
+    // (with one the stores sit at the kernel's end and cost nothing: the headline stays on the route it was measured on).
+    {
+        int n = 0;
+        const Variant* tab = variants_table(&n);
+        for (int i = 0; i < n && !pl->variant_rf; ++i) {
+            const Variant& t = tab[i];
+            if (t.rf && t.dtype == v->dtype && t.pipe == v->pipe && t.vec == v->vec && t.stat == v->stat && t.nthr == v->nthr && t.kmax == v->kmax &&
+                t.depth == v->depth && t.nt == v->nt && t.tki == v->tki && t.sl == v->sl && t.hb == v->hb && t.ha == v->ha && t.pair == v->pair &&
+                t.ss == v->ss && t.quad == v->quad)
+                pl->variant_rf = &t;
+        }
+        bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && pl->K <= 6 && !getenv("AFHIP_NO_REGION_FUSED");
+        for (const ColOp& c : pl->cols) ok = ok && c.outer == OUT_SUM && !(c.rounding & AFHIP_ROUND_FINAL);
+        for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
+        // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
+        // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
+        // float32 forms without threshold slots gain 3 - 30 %; float32 with a threshold slot (the configs[1] plan on float32
+        // storage: 1.93 vs 1.72 - 1.85 ms) and the pair / four-row lean forms (the emit is inlined once per group copy; those have no
+        // twins in the menu) do not.
+        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED")) ok = desc->dtype == AFHIP_F64 || pl->nthr == 0;
+        pl->rf_plan_ok = ok;
+    }
 
     pl->gtab.assign(2 * ((size_t)desc->G1 + 2), 0);
     for (int64_t g = 0; g < desc->G1; ++g) {
@@ -1102,7 +1201,8 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
                      plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
-                     plan->packed ? (plan->pk.nw == 2 ? " packed-counts16" : " packed-counts32") : "",
+                     plan->packed ? (plan->pk.nw == 2 ? " packed-counts16" : " packed-counts32")
+                                  : (plan->last_route == 1 ? " last-run=region-fused" : (plan->rf_plan_ok ? " region-fused-capable" : "")),
                      (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
     return n + 1;
@@ -1118,7 +1218,7 @@ static int check_cube_device(const afhip_plan* pl, const void* cube_dev, const c
     return AFHIP_OK;
 }
 
-static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st) {
+static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st, const afhip_csr::RfTab* rf = nullptr) {
     if (pl->chunks.empty()) return AFHIP_OK;
     for (int j = 0; j < pl->K; ++j)
         if (pl->cols[(size_t)j].tf == TF_INTER && !pl->cols[(size_t)j].inter)
@@ -1150,7 +1250,15 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     for (int j = 0; j < MAX_COLS; ++j) { fa.pk_word[j] = pl->pk.word[j]; fa.pk_shift[j] = pl->pk.shift[j]; }
     dim3 grid((unsigned)pl->tiles, (unsigned)pl->chunks.size());
     void* args[] = {&fa};
-    const size_t lds = plan_lds_bytes(pl);
+    size_t lds = plan_lds_bytes(pl);
+    const void* fn = pl->variant->fn;
+    if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area, a staging block per wave behind the other LDS
+        fn = pl->variant_rf->fn;
+        lds = (lds + 15) / 16 * 16;
+        fa.rf_w = rf->w2.p; fa.rf_tile = rf->tile.p; fa.rf_run = rf->run.p; fa.rf_out = partial; fa.rf_nruns = rf->n_runs;
+        fa.rf_lds_off = (int32_t)lds;
+        lds += (size_t)(pl->wg / 64) * 64 * pl->variant->vec * (size_t)(pl->K + 3) * sizeof(double);
+    }
     if (pl->variant->hb) {
         fa.hb_n = pl->hb_n; fa.hb_c1 = pl->hb_c1; fa.hb_c0 = pl->hb_c0;
         fa.hb_c1f = (float)pl->hb_c1; fa.hb_c0f = (float)pl->hb_c0;
@@ -1167,7 +1275,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         fa.hb_wf = (float)pl->hb_w; fa.hb_lo0f = (float)pl->hb_lo0; fa.hb_glf = (float)pl->hb_gl; fa.hb_ghf = (float)pl->hb_gh;
         fa.hb_c0b = pl->hb_c0b; fa.hb_c0bf = (float)pl->hb_c0b;
     }
-    HIP_TRY(hipLaunchKernel(pl->variant->fn, grid, dim3((unsigned)pl->wg), args, lds, st));
+    HIP_TRY(hipLaunchKernel(fn, grid, dim3((unsigned)pl->wg), args, lds, st));
     return AFHIP_OK;
 }
 
@@ -1296,13 +1404,30 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         for (auto& e : plan->ev) if (!e) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventRecord(plan->ev[0], st));
     }
+    const bool exact = plan->desc.exact_order != 0 || spmm_serial_env();
+    // region-fused period ends: the plan allows it, no per-cell output is wanted, and the table's runs exist (built on first use) and
+    // fit the partial area (n_runs * 3 <= cells and K + 1 <= 2 K ... checked in bytes)
+    const afhip_csr::RfTab* rf = nullptr;
+    if (plan->rf_plan_ok && !exact && !cells_dev && !plan->packed) {
+        rf = rf_table(const_cast<afhip_csr*>(csr), plan->variant->vec);
+        if (rf && plan->n_slots * rf->n_runs * (K + 1) * 8 > plan->ws_partial) rf = nullptr;
+        if (rf && 64 * (size_t)plan->variant->vec * (size_t)(K + 3) * 8 * (size_t)(plan->wg / 64) + plan_lds_bytes(plan) > 64 * 1024) rf = nullptr;
+    }
     const bool prof = !plan->prof_ev.empty() && (size_t)(2 * plan->prof_count + 1) < plan->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count)], st));
-    if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
+    if ((rc = launch_temporal(plan, cube_dev, partial, st, rf))) return rc;
     if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
-    const bool exact = plan->desc.exact_order != 0 || spmm_serial_env();
-    if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {
+    plan->last_route = rf ? 1 : 0;
+    if (rf) {
+        // a region's runs added in run order -> sums[r][p][K + 1] (no pieces: rows [0, R) only)
+        const int64_t n = csr->R * P * (K + 1);
+        if (n) {
+            hipLaunchKernelGGL(k_rf_reduce, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, (const double*)partial, rf->reg_ptr.p, rf->reg_runs.p,
+                               plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
+            HIP_TRY(hipGetLastError());
+        }
+    } else if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {
         // bin-count plan, no per-cell output wanted: the weighted sums gather the packed counts directly
         // (every period has at most one slot: single-level plans are never split); long rows in segments unless exact
         const int64_t nv = exact ? csr->R : csr->nseg, nq = nv * P;

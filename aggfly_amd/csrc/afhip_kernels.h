@@ -125,6 +125,19 @@ struct FusedArgs {
     // registers through the time loop; the full records do not (they were re-read, three scalar loads and their waits, per column
     // and group: 13 s_load per two-row group on a four-column polynomial)
     uint32_t ccode[MAX_COLS];
+    // Region-fused period ends (rf_w != null; afhip_api.hip: rf_table): instead of one value per (slot, column, cell) the kernel
+    // writes one weighted sum per (slot, RUN, column) — a run = consecutive cells of a wave's tile whose e-th table entry names the
+    // same region (e = 0, 1: a cell sits in at most two regions, else the plan keeps the per-cell route).  Per period end a wave
+    // stages w_e * where(valid, x_k, 0) and w_e * valid of its cells in a wave-private LDS block and one lane per run adds the
+    // run's cells in cell order; k_rf_reduce then adds a region's runs in run order.  The per-cell period values — 0.4 GB per
+    // launch on the reference's own benchmark shape, stores that cost its streaming kernel 6 % — are never written, and the
+    // gather kernel over them does not run.
+    const double* rf_w;            // device [C][2]: weight of the cell's first / second table entry (0: none)
+    const int32_t* rf_tile;        // device [wave tiles][2][2]: {first run, runs} of entry e in wave tile t (64 * VEC cells)
+    const uint16_t* rf_run;        // device [runs]: (first cell of the run in its wave tile) | (cells - 1) << 8
+    double* rf_out;                // device [n_slots][runs][K + 1]
+    int64_t rf_nruns;
+    int32_t rf_lds_off, rf_pad;    // byte offset of the staging blocks in the dynamic LDS (one block of 64 * VEC * (K + 1) doubles per wave)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -591,6 +604,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % GL == 0),
                   "short-group mode: direct loads, sum (+ min + max), no threshold slots");
     static_assert(!LEAN || PAIR, "the lean group end is a short-group form");
+    // FEAT bit 11: region-fused period ends compiled in (FusedArgs::rf_w).  A twin of the plain variant: the staging code at the
+    // period end raises the register count by ~7 (one wave per SIMD less on the float32 two-cell forms), so only plans that take
+    // the route run it; with rf_w == null it behaves like its twin.
+    constexpr bool RF = (FEAT & 2048) != 0;
+    static_assert(!RF || !(SL || HB), "region-fused period ends: two-level plans only");
     const int64_t C = a.C;
     const int K = a.K;
     const int lane = threadIdx.x & 63;
@@ -813,6 +831,65 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     };
 
+    // ---- region-fused period end (FusedArgs::rf_w): the period's K values of this lane's cells -> per-run weighted sums ----
+    // val[j][i]: column j of cell i (NaN = missing).  Everything below is in a fixed order: products rounded before the adds
+    // (like spatial.py:183-185), a run's cells added in cell order by ONE lane, so the sums do not depend on the launch shape.
+    auto rf_emit = [&](const double (&val)[KMAX][VEC], int at_slot, int zoff) {
+        // zoff is 0, but only known at run time (it comes from the group table word): every address below is formed from it, so
+        // that none of them is loop-invariant — hoisted out of the time loop they would sit in vector registers for the whole kernel
+        const int ln = lane + zoff;
+        const int64_t cl = c_ld + zoff;
+        // staged per cell: where(valid, x_k, 0) for the K columns, the valid flag and the cell's two weights (read here, by the lane
+        // that owns the cell, in one coalesced load: fetched inside the per-run loop — a serial walk — they cost more than the stores
+        // this route saves: the reference's benchmark shape 5.98 instead of 5.35 ms)
+        const int K1 = K + 1, S = K + 3;
+        const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        typedef __attribute__((address_space(3))) double* lds_f64_t;      // (32-bit LDS addresses: ds_read / ds_write, one register each)
+        lds_f64_t stage = (lds_f64_t)(lds_ptr_t)(dynlds + a.rf_lds_off) + wave * (64 * VEC) * S;
+        const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)((c0 + zoff - (int64_t)ln * VEC) / (64 * VEC)));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            bool valid = active;                                     // (lanes beyond the grid re-read valid cells: nothing of theirs counts)
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < K) valid = valid && (val[j][i] == val[j][i]);
+            lds_f64_t row = stage + (ln * VEC + i) * S;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < K) row[j] = valid ? val[j][i] : 0.0;
+            row[K] = valid ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 w = *(const d2*)(a.rf_w + (cl + i) * 2);
+            lds_f64_t row = stage + (ln * VEC + i) * S;
+            row[K + 1] = w.x;
+            row[K + 2] = w.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = 0; e < 2; ++e) {
+            const int32_t* td = a.rf_tile + (wt * 2 + e) * 2;
+            const int first = ld_uniform(td), nr = ld_uniform(td + 1);
+            for (int r = ln; r < nr; r += 64) {
+                const uint32_t u = a.rf_run[first + r];
+                const int len = (int)(u >> 8) + 1;
+                const lds_f64_t row0 = stage + (int)(u & 0xffu) * S;
+                double* dst = a.rf_out + ((int64_t)at_slot * a.rf_nruns + first + r) * K1;
+                for (int k = 0; k < K1; ++k) {                       // one running sum at a time, the run's cells in cell order
+                    double acc = 0.0;
+                    for (int c = 0; c < len; ++c) acc = __dadd_rn(acc, __dmul_rn(row0[c * S + K + 1 + e], row0[c * S + k]));
+                    dst[k] = acc;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the block is re-staged at the next period end)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
     // ---- end of an inner group: column values, transforms, outer accumulation ----
     auto group_end = [&](bool emit_slot, int nsteps, double inv_n, int zoff, int gidx) {
         const bool empty = nsteps == 0;
@@ -984,6 +1061,15 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                 }
             }
             if (emit_slot) {
+                if (RF && a.rf_w != nullptr) {
+                    KEEP_BRANCH();
+                    double val[KMAX][VEC];
+#pragma unroll
+                    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) val[j][i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                    if constexpr (RF) rf_emit(val, slot, zoff);
+                } else {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
                     if (j < K) {
@@ -994,6 +1080,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                             if (active) dst[i] = val;
                         }
                     }
+                }
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) nanacc[i] = 0ull;
@@ -1165,7 +1252,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         if constexpr (SL) {
             ++slot;
         } else if (emit_slot) {
-            if (active) {
+            if (RF && a.rf_w != nullptr) {
+                KEEP_BRANCH();
+                if constexpr (RF) rf_emit(os, slot, zoff);
+            } else if (active) {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
                     if (j < K) {

@@ -468,6 +468,28 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_rf_reduce: the second half of the region-fused period ends (FusedArgs::rf_w).  The streaming kernel left one weighted sum per
+// (slot, run, column) — a run = consecutive cells of one wave tile in one region; this kernel adds a region's runs in run order
+// (= cell order): sums[r][p][k] = sum over the runs of region r of rf_out[slot(p)][run][k]; a period without a slot (empty
+// resample bin) gives zeros, i.e. no weight.  One thread per (region, period, column).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_out, const int64_t* __restrict__ reg_ptr,
+                                                  const int32_t* __restrict__ reg_runs, const int32_t* __restrict__ slot_ptr,
+                                                  double* __restrict__ sums, int64_t R, int64_t P, int K1, int64_t n_runs) {
+    const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
+    if (tid >= R * P * K1) return;
+    const int k = (int)(tid % K1);
+    const int64_t rp = tid / K1, r = rp / P, p = rp - r * P;
+    const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
+    double acc = 0.0;
+    if (s1 != s0) {
+        const double* base = rf_out + (int64_t)s0 * n_runs * K1 + k;
+        for (int64_t q = reg_ptr[r]; q < reg_ptr[r + 1]; ++q) acc = __dadd_rn(acc, base[(int64_t)reg_runs[q] * K1]);
+    }
+    sums[tid] = acc;
+}
+
 // The pieces of a cut region, added in row order: sums[split_row[i]][q] = sum over scratch rows R + [split_ptr[i], split_ptr[i+1]).
 __global__ __launch_bounds__(WG) void k_csr_combine_segments(double* __restrict__ sums, const int32_t* __restrict__ split_row,
                                                              const int32_t* __restrict__ split_ptr, int64_t R, int64_t Q, int64_t n_split) {

@@ -27,6 +27,7 @@ struct Variant {
     int ss;           // ... with the lean group end: 1 = columns mean | sum | min | max | sine_dd -> (integer power) -> sum | mean;
                       //     2 = every column a plain sine_dd -> sum | mean (the tightest form)
     int quad;         // 1: ... for inner groups of exactly FOUR rows (6-hourly data) instead of two; lean form only
+    int rf;           // 1: region-fused period ends compiled in (the twin of the variant with the same other fields)
     const void* fn;
     const char* name;
 };
@@ -38,7 +39,7 @@ const Variant* variants_table(int* n);   // generated (variants_table.hip)
 //         e.g. 1404 LDS ring, 4 cells per lane, depth 4;  108 direct loads, 1 cell per lane, 8 rows in flight
 inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning, int vec = 0,
                                    bool all_bins = false, bool single_level = false, bool partition = false, bool arith = false,
-                                   bool pairs = false, int lean = 0, int depth_hint = 0, bool quads = false) {
+                                   bool pairs = false, int lean = 0, int depth_hint = 0, bool quads = false, bool rf = false) {
     const Variant* best = nullptr;
     long best_cost = 0;
     int n = 0;
@@ -51,7 +52,7 @@ inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int 
     }
     for (int i = 0; i < n; ++i) {
         const Variant& v = tab[i];
-        if (v.dtype != dtype || v.stat < stat || v.nthr < nthr || v.kmax < K) continue;
+        if (v.dtype != dtype || v.stat < stat || v.nthr < nthr || v.kmax < K || (v.rf != 0) != rf) continue;
         if ((v.tki && !(all_bins && nthr > 0)) || (v.sl && !single_level) || (v.hb && !partition) || (v.ha && !arith)) continue;
         if (v.pair && !((pairs || quads) && nthr == 0)) continue;
         if ((v.pair && (v.quad != 0) != quads) || (quads && !v.pair)) continue;    // a four-row plan takes four-row variants only, and vice versa

@@ -807,6 +807,82 @@ def test_slot_gather_spatial_stage_against_the_panel_route_and_the_oracle(torch_
     monkeypatch.delenv("AFHIP_SLOT_SPMM_SUB")
 
 
+@pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32"])
+def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkeypatch, kind):
+    """Plans with several output periods, sum-like outer reducers and no per-cell output reduce their cells by region INSIDE the
+    streaming kernel at every period end (FusedArgs::rf_w: per-run weighted sums from a wave-private LDS block, k_rf_reduce adds a
+    region's runs) — the per-cell period values are never written.  Same numbers as the routes that do write them
+    (AFHIP_NO_REGION_FUSED=1: k_csr_spmm_slots; exact_order: table order) to rounding, and as the oracle's spatial stage on the
+    plan's own per-cell values; NaN cells (shared validity), zero-weight regions, an empty period, border cells that sit in two
+    regions, the last partly filled tile.  Tables whose regions are a few cells (runs too short to pay) and plans the route does not
+    cover (outer mean, one period; float32 with threshold slots and the pair / four-row lean forms, where it measured behind)
+    stay on the per-cell routes."""
+    from aggfly_amd import hip
+    ny, nx, R = 71, 130, 40                                          # 9,230 cells: a last tile that is partly filled
+    tab = synth.weights_table(ny, nx, R, seed=41, zero_frac=0.05)
+    C = ny * nx
+    ridx, cidx, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+    nR = int(ridx.max()) + 1
+    assert tab.groupby("cell_id").size().max() == 2                  # border cells belong to two regions
+    csr = hip.CSR(ridx, cidx, w, nR, C)
+    poly = [dict(inner="mean", transform="pow", transform_arg=float(e), outer="sum") for e in (1, 2, 3, 4)]
+    if kind.startswith("hourly"):
+        dtype = np.float64 if kind.endswith("f64") else np.float32
+        T, spd = 24 * 60, 24
+        cube = _cube(T, ny, nx, dtype, seed=42)
+        # float64: the configs[1] columns (a threshold slot + the polynomial); float32 plans with threshold slots stay on the
+        # per-cell route (measured behind), so the float32 case is the polynomial alone — the reference's own benchmark plan
+        cols = ([dict(inner="dd", inner_args=(10, 30, 0), outer="sum")] if dtype == np.float64 else []) + poly
+    else:
+        dtype, spd = np.float32, 8                                   # three-hourly steps: min / max sources beside the mean
+        T = spd * 60
+        cube = _cube(T, ny, nx, dtype, seed=43)
+        cols = [dict(inner="max", outer="sum"), dict(inner="min", transform="pow", transform_arg=2.0, outer="sum"), dict(inner="mean", outer="sum")]
+    code = hip.F64 if dtype == np.float64 else hip.F32
+    d = torch_cuda.from_numpy(cube).cuda()
+    ib = synth.hourly_bounds(T, spd)                                 # 60 inner groups
+    # periods short enough to stay whole on this small grid (a period cut into several slots rules the route out): twelve or
+    # six periods, the second one empty
+    ob = (np.array([0, 5, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50, 55, 60], dtype=np.int64) if spd == 24
+          else np.array([0, 9, 9, 20, 33, 47, 60], dtype=np.int64))
+    K = len(cols)
+    plan = hip.FusedPlan(T, C, code, ib, ob, cols)
+    assert "region-fused-capable" in plan.describe(), plan.describe()
+    fused = plan.run(d, csr)
+    assert "last-run=region-fused" in plan.describe(), plan.describe()
+    monkeypatch.setenv("AFHIP_NO_REGION_FUSED", "1")
+    plain = hip.FusedPlan(T, C, code, ib, ob, cols)
+    monkeypatch.delenv("AFHIP_NO_REGION_FUSED")
+    assert "region-fused" not in plain.describe(), plain.describe()
+    slots = plain.run(d, csr)
+    for key in ("num", "den", "res"):
+        np.testing.assert_allclose(fused[key].cpu().numpy(), slots[key].cpu().numpy(), rtol=1e-12, atol=1e-9 if key == "num" else 0,
+                                   equal_nan=True, err_msg=key)
+    assert np.isnan(fused["res"].cpu().numpy()[:, :, 1]).all() and (fused["den"].cpu().numpy()[:, 1] == 0).all()      # the empty period
+    # per-cell values of the same plan (asking for them takes the per-cell route) through the oracle's spatial stage
+    with_cells = plan.run(d, csr, want_cells=True)
+    assert "last-run=region-fused" not in plan.describe()
+    cells = with_cells["cells"].cpu().numpy()                        # [K, P, C]
+    nums, den, _ = spatial_num_den({f"k{k}": cells[k].T for k in range(K)}, tab, np.arange(C))
+    np.testing.assert_allclose(fused["den"].cpu().numpy(), den, rtol=1e-12)
+    for k in range(K):
+        np.testing.assert_allclose(fused["num"][k].cpu().numpy(), nums[f"k{k}"], rtol=1e-12, atol=1e-9)
+    if kind == "hourly_f64":
+        ex = hip.FusedPlan(T, C, code, ib, ob, cols, exact_order=True).run(d, csr)
+        np.testing.assert_allclose(fused["res"].cpu().numpy(), ex["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+        # what the route does not cover keeps the per-cell routes: an outer mean, a single period, regions of a handful of cells
+        for bad_cols, bad_ob, bad_code in (([dict(inner="mean", outer="mean")] + poly, ob, code), (cols, np.array([0, 60], dtype=np.int64), code),
+                                           (cols, ob, hip.F32)):
+            pl = hip.FusedPlan(T, C, bad_code, ib, bad_ob, bad_cols)
+            assert "region-fused" not in pl.describe(), pl.describe()
+        tiny = synth.weights_table(ny, nx, 2500, seed=44)
+        tcsr = hip.CSR(tiny["index_right"].to_numpy(), tiny["cell_id"].to_numpy(), tiny["weight"].to_numpy(), int(tiny["index_right"].max()) + 1, C)
+        a = plan.run(d, tcsr)
+        assert "last-run=region-fused" not in plan.describe(), plan.describe()
+        b = plain.run(d, tcsr)
+        np.testing.assert_array_equal(a["res"].cpu().numpy(), b["res"].cpu().numpy())
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(2 * 150, 6, 20), (2 * 150, 5, 7)])
 def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
