@@ -18,6 +18,11 @@
 //                     (_scatter_block, spatial.py:181-186), then k_panel_divide
 //                     (spatial.py:127-133).
 //
+// Runs without per-cell output skip the middle kernel: k_csr_spmm_slots gathers the period partials directly (slot merge,
+// validity and weighted sums in one pass), and plans with several output periods reduce their cells by region INSIDE
+// k_fused_temporal at every period end (FusedArgs::rf_w, rf_emit; k_rf_reduce adds a region's runs) — the per-cell period
+// values are then never written.
+//
 // No MFMA anywhere: the path is a streaming scan plus a sparse segmented sum.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -331,8 +331,12 @@ def run_other_configs(torch, steps=10, warmup=10):      # the first ~10 launches
             kms = plan.profile_end()
             k_ms = float(np.mean(kms))
             hbm = T * C * elem / (k_ms * 1e-3) / 1e9
+            desc = plan.describe()
+            route = ("region-fused period ends (weighted sums per region inside the temporal kernel) + k_rf_reduce" if "last-run=region-fused" in desc
+                     else ("packed counts gathered directly" if "packed-counts" in desc else "period partials + k_csr_spmm_slots"))
             row = {"config": c["name"], "workload": c["workload"], "dtype": c["dtype"], "steps": steps,
-                   "ms_per_step": dt / steps * 1e3, "value": T * C * steps / dt, "kernel": plan.describe().split()[0].replace("variant=", ""),
+                   "ms_per_step": dt / steps * 1e3, "value": T * C * steps / dt,
+                   "kernel": desc.split()[0].replace("variant=", "") + ("_rf" if "last-run=region-fused" in desc else ""), "spatial_route": route,
                    "kernel_ms_mean": k_ms, "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
                    "algorithmic_bytes_per_launch": T * C * elem, "regions": R, "nnz": int(csr.nnz)}
             vc = valu.get(c["name"])
@@ -582,7 +586,7 @@ def main():
             # its bounding roofline, kernel time and whole-pass time
             line["roofline"]["other"] = {
                 r["config"]: ({"bound": r["bound"], "frac": r["frac"], "hbm_frac": r.get("hbm_frac", r["frac"]), "kernel_ms_mean": r["kernel_ms_mean"],
-                               "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "kernel": r["kernel"]} if "error" not in r else {"error": r["error"]})
+                               "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "kernel": r["kernel"], "spatial_route": r.get("spatial_route")} if "error" not in r else {"error": r["error"]})
                 for r in line["other_configs"]}
             if not args.no_ingest:
                 try:

@@ -243,6 +243,11 @@ int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cell
 /* Whole path: temporal stage, shared validity, CSR weighted sums, divide.
  * num_dev [K, R, P], den_dev [R, P], res_dev [K, R, P] float64 (num/den may be NULL);
  * cells_dev optional as above (NULL to skip materialising it).
+ * Routes (results equal to rounding; exact_order plans always take the first): with cells_dev, or exact_order — slot merge into a
+ * cell-major panel, then weighted sums in table order; without — one gather over the period partials (no panel), or, for plans with
+ * several output periods whose table allows it, weighted sums per region formed inside the temporal kernel at every period end (the
+ * per-cell period values are then never written); bin-count plans gather their packed records.  The CSR handle caches the tables of
+ * the last route on first use (it is entered through a const pointer but guarded by its own lock).
  * If kernel_ms is not NULL the call records HIP events on `stream` around the temporal
  * kernel and around the whole sequence, synchronises the stream, and writes
  * kernel_ms[0] = temporal kernel ms, kernel_ms[1] = whole sequence ms. */
