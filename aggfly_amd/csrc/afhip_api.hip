@@ -1097,8 +1097,8 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->variant = v;
     if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
     // Region-fused period ends (FusedArgs::rf_w): the twin variant, if the menu has one, and what the plan itself must satisfy —
-    // sum-like outer reducers without float32 rounding of the final value (the period value must enter the weighted sum as it
-    // leaves the accumulator), at most one slot per period (shared validity needs the whole period's value), several periods
+    // two-level columns without float32 rounding of the final value (the period value must enter the weighted sum as it leaves
+    // the accumulator; an outer mean's division by the period's group count is applied to the region sums, k_rf_reduce), at most one slot per period (shared validity needs the whole period's value), several periods
     // (with one the stores sit at the kernel's end and cost nothing: the headline stays on the route it was measured on).
     {
         int n = 0;
@@ -1111,7 +1111,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
                 pl->variant_rf = &t;
         }
         bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && pl->K <= 6 && !getenv("AFHIP_NO_REGION_FUSED");
-        for (const ColOp& c : pl->cols) ok = ok && c.outer == OUT_SUM && !(c.rounding & AFHIP_ROUND_FINAL);
+        for (const ColOp& c : pl->cols) ok = ok && c.outer != OUT_FIRST && !(c.rounding & AFHIP_ROUND_FINAL);
         for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
         // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
         // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
@@ -1423,8 +1423,10 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         // a region's runs added in run order -> sums[r][p][K + 1] (no pieces: rows [0, R) only)
         const int64_t n = csr->R * P * (K + 1);
         if (n) {
+            uint32_t mean_mask = 0;
+            for (int j = 0; j < plan->K; ++j) if (plan->cols[(size_t)j].outer == OUT_MEAN) mean_mask |= 1u << j;
             hipLaunchKernelGGL(k_rf_reduce, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, (const double*)partial, rf->reg_ptr.p, rf->reg_runs.p,
-                               plan->d_slot_ptr.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
+                               plan->d_slot_ptr.p, plan->d_ob.p, mean_mask, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
             HIP_TRY(hipGetLastError());
         }
     } else if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {

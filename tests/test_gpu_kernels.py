@@ -815,7 +815,7 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     (AFHIP_NO_REGION_FUSED=1: k_csr_spmm_slots; exact_order: table order) to rounding, and as the oracle's spatial stage on the
     plan's own per-cell values; NaN cells (shared validity), zero-weight regions, an empty period, border cells that sit in two
     regions, the last partly filled tile.  Tables whose regions are a few cells (runs too short to pay) and plans the route does not
-    cover (outer mean, one period; float32 with threshold slots and the pair / four-row lean forms, where it measured behind)
+    cover (float32 rounding of the final value, one period; float32 with threshold slots and the pair / four-row lean forms, where it measured behind)
     stay on the per-cell routes."""
     from aggfly_amd import hip
     ny, nx, R = 71, 130, 40                                          # 9,230 cells: a last tile that is partly filled
@@ -837,7 +837,8 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         dtype, spd = np.float32, 8                                   # three-hourly steps: min / max sources beside the mean
         T = spd * 60
         cube = _cube(T, ny, nx, dtype, seed=43)
-        cols = [dict(inner="max", outer="sum"), dict(inner="min", transform="pow", transform_arg=2.0, outer="sum"), dict(inner="mean", outer="sum")]
+        cols = [dict(inner="max", outer="max"), dict(inner="min", transform="pow", transform_arg=2.0, outer="sum"), dict(inner="mean", outer="mean"),
+                dict(inner="mean", outer="dd", outer_args=(10, 30, 0)), dict(inner="min", outer="min")]
     code = hip.F64 if dtype == np.float64 else hip.F32
     d = torch_cuda.from_numpy(cube).cuda()
     ib = synth.hourly_bounds(T, spd)                                 # 60 inner groups
@@ -870,9 +871,9 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     if kind == "hourly_f64":
         ex = hip.FusedPlan(T, C, code, ib, ob, cols, exact_order=True).run(d, csr)
         np.testing.assert_allclose(fused["res"].cpu().numpy(), ex["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
-        # what the route does not cover keeps the per-cell routes: an outer mean, a single period, regions of a handful of cells
-        for bad_cols, bad_ob, bad_code in (([dict(inner="mean", outer="mean")] + poly, ob, code), (cols, np.array([0, 60], dtype=np.int64), code),
-                                           (cols, ob, hip.F32)):
+        # what the route does not cover keeps the per-cell routes: a rounded final value, a single period, float32 with a threshold slot, regions of a handful of cells
+        for bad_cols, bad_ob, bad_code in (([dict(inner="mean", outer="sum", rounding=hip.ROUND_FINAL)] + poly, ob, code),
+                                           (cols, np.array([0, 60], dtype=np.int64), code), (cols, ob, hip.F32)):
             pl = hip.FusedPlan(T, C, bad_code, ib, bad_ob, bad_cols)
             assert "region-fused" not in pl.describe(), pl.describe()
         tiny = synth.weights_table(ny, nx, 2500, seed=44)
