@@ -645,6 +645,42 @@ def test_concurrent_host_threads_share_cached_plans(torch_cuda):
     assert not alone[0].drop(columns=["geoid", "time"]).equals(alone[1].drop(columns=["geoid", "time"]))     # the cubes do differ
 
 
+def test_weekly_panel_takes_the_region_fused_period_ends(torch_cuda):
+    """`aggregate_dataset` with many output periods on a grid large enough to stream in whole periods (13 weeks of hourly float64
+    data on 160 x 256 cells, 30 regions): the cached plan reduces its cells by region inside the streaming kernel at every period
+    end (afhip_kernels.h: rf_emit) — checked through the public API against the oracle's whole pipeline (temporal stage, power
+    transform, shared validity, weighted means, long frame) at the 1e-10 of the other API tests, and from four host threads at
+    once (they share the plan, the CSR handle and its lazily built run tables)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from aggfly_amd import engine as eng
+    T, ny, nx = 24 * 91, 160, 256
+    time = pd.date_range("2001-01-01", periods=T, freq="h")           # a Monday: 13 whole weeks
+    lat, lon = 20 + 0.25 * np.arange(ny), 230 + 0.25 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, 30, seed=19, zero_frac=0.05)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    spec = dict(dd=[("aggregate", {"calc": "dd", "groupby": "date", "ddargs": [10, 30, 0]}), ("aggregate", {"calc": "sum", "groupby": "week"})],
+                t=[("aggregate", {"calc": "mean", "groupby": "date"}), ("transform", {"transform": "power", "exp": np.arange(1, 3)}),
+                   ("aggregate", {"calc": "mean", "groupby": "week"})])
+    cubes = [synth.temperature_cube(T, ny, nx, dtype=np.float64, seed=200 + i, ocean_frac=0.1, scattered_nan=20) for i in range(2)]
+    dss = [af.Dataset(af.DataArray(c, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=True).to_device()
+           for c in cubes]
+    w = af.weights_from_objects(dss[0], gr, table=tab)
+    eng._PLAN_CACHE.clear(); eng._CSR_CACHE.clear()
+    got = [af.aggregate_dataset(dataset=d, weights=w, **spec) for d in dss]
+    plans = list(eng._PLAN_CACHE.values())
+    assert len(plans) == 1 and "last-run=region-fused" in plans[0].describe(), [p.describe() for p in plans]
+    ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
+    for c, df in zip(cubes, got):
+        want = ra.aggregate_dataset(ow, ra.ODataset(c, time, lat, lon, True), engine="numba", **spec)
+        cols = [k for k in want.columns if k not in ("geoid", "time")]
+        assert list(df.columns) == list(want.columns) and len(df) == len(want) and (df["time"].values == want["time"].values).all()
+        np.testing.assert_allclose(df[cols].values, want[cols].values, rtol=1e-10, atol=1e-10, equal_nan=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        together = list(ex.map(lambda d: af.aggregate_dataset(dataset=d, weights=w, **spec), dss * 2))
+    for a, b in zip(got * 2, together):
+        pd.testing.assert_frame_equal(a, b, check_exact=True)
+
+
 def test_handles_are_bound_to_the_cubes_device_from_a_fresh_thread(torch_cuda):
     """Handles belong to a device (include/aggfly_hip.h "Devices").  A fresh host thread starts on device 0 whatever card
     its parent selected — the threaded caller the reference supports (`nb_kernels.py:271-305` under dask's pool) would, on
