@@ -159,3 +159,60 @@ def test_random_specs_match_oracle(torch_cuda, seed):
         assert got[cols].shape == want[cols].shape, (spec, list(got.columns), list(want.columns))
         np.testing.assert_allclose(got[cols].values.astype(float), want[cols].values.astype(float), rtol=1e-10, atol=1e-10,
                                    equal_nan=True, err_msg=repr(spec))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_specs_on_the_region_fused_route(torch_cuda, seed):
+    """The same kind of fuzz on shapes that reach the region-fused period ends (afhip_kernels.h: rf_emit): 3-hourly data with weekly
+    or monthly panels on a 48 x 80 grid with a dozen regions — periods short enough to stay whole on a small grid, regions large enough
+    for their runs to pay.  Random inner reducers (incl. threshold slots on float64), integer powers, outer sum / mean / min / max /
+    dd, up to three names per call; the whole public path against the oracle, and the route really taken wherever the plan
+    qualifies (float64, or float32 without threshold slots; at least two periods)."""
+    from aggfly_amd import engine as eng
+    rng = np.random.default_rng(7000 + seed)
+    dtype = np.float64 if seed % 2 == 0 else np.float32
+    spd, ndays, ny, nx = 8, int(rng.integers(60, 100)), 48, 80
+    T = spd * ndays
+    cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=300 + seed, steps_per_day=spd, ocean_frac=0.1, scattered_nan=30)
+    time = pd.date_range("2001-01-01 00:00", periods=T, freq="3h")
+    lon360 = bool(seed % 3 == 0)
+    lat, lon = 10 + 0.5 * np.arange(ny), (200.0 if lon360 else -60.0) + 0.5 * np.arange(nx)
+    tab = synth.weights_table(ny, nx, 12, seed=seed, secondary=bool(seed % 2), zero_frac=0.1)
+    gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
+    ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=lon360).to_device()
+    w = af.weights_from_objects(ds, gr, table=tab)
+    ow = ra.OWeights(tab, np.arange(ny * nx), gr.shp["geoid"], "geoid", "nan")
+    ods = ra.ODataset(cube.astype(np.float64), time, lat, lon, lon360)
+    taken = 0
+    for trial in range(4):
+        g2 = str(rng.choice(["week", "month"]))
+        spec, thr = {}, False
+        for v in range(int(rng.integers(1, 4))):
+            # (eight rows per date group: the direct-load path, whose variants have region-fused twins)
+            inner = str(rng.choice(["mean", "sum", "min", "max", "nanmean"] + (["dd", "bins"] if dtype == np.float64 else [])))
+            p1 = {"calc": inner, "groupby": "date"}
+            if inner in ("dd", "bins"):
+                p1["ddargs"] = _dd(rng, False)
+                thr = True
+            steps = [("aggregate", p1)]
+            if rng.random() < 0.5 and inner not in ("dd", "bins"):
+                steps.append(("transform", {"transform": "power", "exp": np.arange(1, int(rng.integers(2, 4)))}))
+            outer = str(rng.choice(["sum", "mean", "min", "max", "dd"]))
+            p2 = {"calc": outer, "groupby": g2}
+            if outer == "dd":
+                p2["ddargs"] = _dd(rng, False)
+            steps.append(("aggregate", p2))
+            spec[f"v{v}"] = steps
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = ra.aggregate_dataset(ow, ods, engine="numba", **spec)
+        eng._PLAN_CACHE.clear()
+        got = af.aggregate_dataset(dataset=ds, weights=w, **spec)
+        assert list(got.columns) == list(want.columns) and len(got) == len(want), spec
+        assert (got["geoid"].values == want["geoid"].values).all() and (got["time"].values == want["time"].values).all(), spec
+        cols = [c for c in got.columns if c not in ("geoid", "time")]
+        np.testing.assert_allclose(got[cols].values.astype(float), want[cols].values.astype(float), rtol=1e-10, atol=1e-10,
+                                   equal_nan=True, err_msg=repr(spec))
+        descs = [p.describe() for p in eng._PLAN_CACHE.values()]
+        assert not any("region-fused-capable" in d for d in descs), (descs, spec)      # a capable plan that ran took the route (this table allows it)
+        taken += sum("last-run=region-fused" in d for d in descs)
+    assert taken >= 1, "no trial of this seed reached the region-fused route"
