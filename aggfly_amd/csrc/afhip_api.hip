@@ -1111,7 +1111,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
                 pl->variant_rf = &t;
         }
         bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && pl->K <= 6 && !getenv("AFHIP_NO_REGION_FUSED");
-        for (const ColOp& c : pl->cols) ok = ok && c.outer != OUT_FIRST && !(c.rounding & AFHIP_ROUND_FINAL);
+        for (const ColOp& c : pl->cols) ok = ok && !(c.rounding & AFHIP_ROUND_FINAL);      // (identity outers too: a daily panel of daily means)
         for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
         // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
         // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and

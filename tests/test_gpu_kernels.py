@@ -876,6 +876,24 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
                                            (cols, np.array([0, 60], dtype=np.int64), code), (cols, ob, hip.F32)):
             pl = hip.FusedPlan(T, C, bad_code, ib, bad_ob, bad_cols)
             assert "region-fused" not in pl.describe(), pl.describe()
+        # a single-level plan on the generic variants — a daily panel of daily statistics, 60 periods of one group — takes the route too
+        daily = [dict(inner="mean"), dict(inner="max"), dict(inner="dd", inner_args=(10, 30, 0))]
+        dp = hip.FusedPlan(T, C, code, ib, np.arange(61, dtype=np.int64), daily)
+        fd = dp.run(d, csr)
+        assert "last-run=region-fused" in dp.describe(), dp.describe()
+        xd = hip.FusedPlan(T, C, code, ib, np.arange(61, dtype=np.int64), daily, exact_order=True).run(d, csr)
+        np.testing.assert_allclose(fd["res"].cpu().numpy(), xd["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(fd["den"].cpu().numpy(), xd["den"].cpu().numpy(), rtol=1e-12)
+        # ... a cell that sits in three regions (a junction of polygons): the run tables hold two entries per cell
+        r3 = np.concatenate([ridx, [(ridx[cidx == 4000][0] + 1) % nR, (ridx[cidx == 4000][0] + 2) % nR]])
+        c3 = np.concatenate([cidx, [4000, 4000]])
+        w3 = np.concatenate([w, [0.25, 0.125]])
+        o3 = np.argsort(r3, kind="stable")
+        assert np.bincount(c3).max() >= 3
+        jcsr = hip.CSR(r3[o3], c3[o3], w3[o3], nR, C)
+        a = plan.run(d, jcsr)
+        assert "last-run=region-fused" not in plan.describe(), plan.describe()
+        np.testing.assert_array_equal(a["res"].cpu().numpy(), plain.run(d, jcsr)["res"].cpu().numpy())
         tiny = synth.weights_table(ny, nx, 2500, seed=44)
         tcsr = hip.CSR(tiny["index_right"].to_numpy(), tiny["cell_id"].to_numpy(), tiny["weight"].to_numpy(), int(tiny["index_right"].max()) + 1, C)
         a = plan.run(d, tcsr)
