@@ -249,6 +249,41 @@ def test_c3_forty_years_hourly_f32(torch_cuda):
     np.testing.assert_allclose(fast["res"].cpu().numpy(), out["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
 
 
+def test_ref_global_quarter_degree_monthly_polynomial_f32(torch_cuda):
+    """The reference's own published benchmark shape (`benchmarks/bench_engine.py:19-23,60-69`): one year of hourly float32 on the global
+    0.25 degree grid (8760 x 721 x 1440, 36.4 GB), mean@date -> power[1..4] -> sum@month, 3,100 regions.  Sampled cells against the
+    oracle on the float64-cast input, sampled regions in table order from the exact_order plan's own per-cell values, and the default
+    plan — twelve time chunks, one per month, with the region-fused period ends (the per-cell monthly values are never written) —
+    against the exact plan at 1e-12."""
+    torch = torch_cuda
+    _need(torch, 60)
+    T, ny, nx = 8760, 721, 1440
+    cube = _fill(torch, T, ny, nx, torch.float32, 51, 24)
+    ib = synth.hourly_bounds(T)
+    ob = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])]).astype(np.int64)
+    cols = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
+    tab = synth.weights_table(ny, nx, 3100, seed=53, zero_frac=0.01)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, ny * nx)
+    exact = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, cols, exact_order=True)
+    out = exact.run(cube, csr, want_cells=True)
+    pick, host = _sample_cells(torch, cube, 48, 52)
+    got = out["cells"][:, :, torch.from_numpy(pick).cuda()].cpu().numpy()       # [K, 12, cells]
+    m = cport.resample(host, ib, "mean")
+    for k, e in enumerate((1, 2, 3, 4)):
+        want = cport.resample(np.power(m, e), ob, "sum").reshape(12, -1)
+        np.testing.assert_allclose(got[k], want, rtol=4e-16, atol=0, equal_nan=True)
+    assert _check_sampled_regions(torch, out, tab, R, 32, 54) == 32
+    del out
+    fast_plan = hip.FusedPlan(T, ny * nx, hip.F32, ib, ob, cols)
+    assert "chunks=12 " in fast_plan.describe() and "region-fused-capable" in fast_plan.describe(), fast_plan.describe()
+    fast = fast_plan.run(cube, csr)
+    assert "last-run=region-fused" in fast_plan.describe(), fast_plan.describe()
+    want = exact.run(cube, csr)
+    for key in ("num", "den", "res"):
+        np.testing.assert_allclose(fast[key].cpu().numpy(), want[key].cpu().numpy(), rtol=1e-12, equal_nan=True, err_msg=key)
+
+
 def test_c4_cmip6_daily_bins_251_years(torch_cuda):
     """configs[3]: daily tas 1850-2100 on a noleap calendar (T = 91,615), 180 x 288 cells, 13 bins/yr."""
     torch = torch_cuda
