@@ -807,7 +807,7 @@ def test_slot_gather_spatial_stage_against_the_panel_route_and_the_oracle(torch_
     monkeypatch.delenv("AFHIP_SLOT_SPMM_SUB")
 
 
-@pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32"])
+@pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32", "hourly_f64_lognormal"])
 def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkeypatch, kind):
     """Plans with several output periods, sum-like outer reducers and no per-cell output reduce their cells by region INSIDE the
     streaming kernel at every period end (FusedArgs::rf_w: per-run weighted sums from a wave-private LDS block, k_rf_reduce adds a
@@ -819,7 +819,14 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     stay on the per-cell routes."""
     from aggfly_amd import hip
     ny, nx, R = 71, 130, 40                                          # 9,230 cells: a last tile that is partly filled
-    tab = synth.weights_table(ny, nx, R, seed=41, zero_frac=0.05)
+    if kind.endswith("lognormal"):
+        # region sizes over three decades (one region of a third of the grid, spanning dozens of wave tiles; regions of one cell)
+        tab = synth.weights_table(ny, nx, 60, seed=45, skew="lognormal", zero_frac=0.05)
+        sizes = tab.groupby("index_right").size()
+        assert sizes.max() > 2000 and sizes.min() <= 4
+        kind = "hourly_f64"
+    else:
+        tab = synth.weights_table(ny, nx, R, seed=41, zero_frac=0.05)
     C = ny * nx
     ridx, cidx, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
     nR = int(ridx.max()) + 1
