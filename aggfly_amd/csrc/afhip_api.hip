@@ -1115,10 +1115,11 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
         // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
         // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
-        // float32 forms without threshold slots gain 3 - 30 %; float32 with a threshold slot (the configs[1] plan on float32
-        // storage: 1.93 vs 1.72 - 1.85 ms) and the pair / four-row lean forms (the emit is inlined once per group copy; those have no
-        // twins in the menu) do not.
-        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED")) ok = desc->dtype == AFHIP_F64 || pl->nthr == 0;
+        // float32 forms without threshold slots gain 3 - 50 % from two periods on; float32 with a threshold slot (the configs[1] plan
+        // on float32 storage) is level at 12 periods and ahead from ~24 (whole step -2.5 % at 24, -14 % at 52, -19 % at 73, -33 % at
+        // 365); the pair / four-row lean forms (their emit is inlined once per group copy, their prefetched rows are live across it)
+        // have no twins in the menu.
+        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED")) ok = desc->dtype == AFHIP_F64 || pl->nthr == 0 || desc->P >= 24;
         pl->rf_plan_ok = ok;
     }
 

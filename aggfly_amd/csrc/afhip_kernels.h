@@ -878,16 +878,17 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         for (int e = 0; e < 2; ++e) {
             const int32_t* td = a.rf_tile + (wt * 2 + e) * 2;
             const int first = ld_uniform(td), nr = ld_uniform(td + 1);
-            for (int r = ln; r < nr; r += 64) {
+            // one lane per (run, column): each sum walks its run's cells in cell order (the order never depends on which lane adds it),
+            // and the lanes of a wave share the walk of a run between the K + 1 columns instead of one lane doing them in turn
+            double* out0 = a.rf_out + ((int64_t)at_slot * a.rf_nruns + first) * K1;
+            for (int t = ln; t < nr * K1; t += 64) {
+                const int r = t / K1, k = t - r * K1;
                 const uint32_t u = a.rf_run[first + r];
                 const int len = (int)(u >> 8) + 1;
                 const lds_f64_t row0 = stage + (int)(u & 0xffu) * S;
-                double* dst = a.rf_out + ((int64_t)at_slot * a.rf_nruns + first + r) * K1;
-                for (int k = 0; k < K1; ++k) {                       // one running sum at a time, the run's cells in cell order
-                    double acc = 0.0;
-                    for (int c = 0; c < len; ++c) acc = __dadd_rn(acc, __dmul_rn(row0[c * S + K + 1 + e], row0[c * S + k]));
-                    dst[k] = acc;
-                }
+                double acc = 0.0;
+                for (int c = 0; c < len; ++c) acc = __dadd_rn(acc, __dmul_rn(row0[c * S + K + 1 + e], row0[c * S + k]));
+                out0[t] = acc;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the block is re-staged at the next period end)

@@ -875,6 +875,18 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     np.testing.assert_allclose(fused["den"].cpu().numpy(), den, rtol=1e-12)
     for k in range(K):
         np.testing.assert_allclose(fused["num"][k].cpu().numpy(), nums[f"k{k}"], rtol=1e-12, atol=1e-9)
+    if kind == "hourly_f32":
+        # float32 with a threshold slot: from 24 periods on (level with the per-cell route at 12, ahead from there) — 30 periods of two days
+        tcols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")] + poly
+        ob30 = np.arange(0, 61, 2, dtype=np.int64)
+        p30 = hip.FusedPlan(T, C, code, ib, ob30, tcols)
+        f30 = p30.run(d, csr)
+        assert "last-run=region-fused" in p30.describe(), p30.describe()
+        assert "region-fused" not in hip.FusedPlan(T, C, code, ib, ob, tcols).describe()          # 13 periods: the per-cell route
+        x30 = hip.FusedPlan(T, C, code, ib, ob30, tcols, exact_order=True).run(d, csr)
+        for key in ("num", "den", "res"):
+            np.testing.assert_allclose(f30[key].cpu().numpy(), x30[key].cpu().numpy(), rtol=1e-12, atol=1e-9 if key == "num" else 0,
+                                       equal_nan=True, err_msg=key)
     if kind == "hourly_f64":
         ex = hip.FusedPlan(T, C, code, ib, ob, cols, exact_order=True).run(d, csr)
         np.testing.assert_allclose(fused["res"].cpu().numpy(), ex["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
