@@ -921,6 +921,44 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         np.testing.assert_array_equal(a["res"].cpu().numpy(), b["res"].cpu().numpy())
 
 
+def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeypatch):
+    """The region-fused period ends add a run's cells in cell order and a region's runs in run order; runs are cut per wave TILE (64
+    cells per lane-cell), not per workgroup or chunk — so single-wave or four-wave workgroups, one time chunk per period or two
+    periods per chunk, a caller-owned workspace or the plan's own: the same bits."""
+    from aggfly_amd import hip
+    torch = torch_cuda
+    T, ny, nx = 24 * 24, 160, 512                                    # 320 tiles of 256 threads: four-wave workgroups by default
+    g = torch.Generator(device="cuda").manual_seed(61)
+    d = 15 + 12 * torch.randn((T, ny, nx), generator=g, device="cuda", dtype=torch.float64)
+    d[7, 5, 9] = float("nan")
+    tab = synth.weights_table(ny, nx, 50, seed=62, zero_frac=0.04)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, ny * nx)
+    ib = synth.hourly_bounds(T)
+    ob = np.arange(0, 25, 3, dtype=np.int64)                         # eight periods of three days
+    cols = [dict(inner="dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="mean", transform="pow", transform_arg=3.0, outer="sum"),
+            dict(inner="max", outer="mean")]
+
+    def run(env, workspace=False):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = hip.FusedPlan(T, ny * nx, hip.F64, ib, ob, cols)
+        for k in env:
+            monkeypatch.delenv(k)
+        ws = torch.empty(plan.workspace_bytes(), dtype=torch.uint8, device="cuda") if workspace else None
+        out = plan.run(d, csr, workspace=ws)
+        assert "last-run=region-fused" in plan.describe(), plan.describe()
+        return plan.describe(), {k: out[k].cpu().numpy() for k in ("num", "den", "res")}
+
+    base_desc, base = run({})
+    assert "wg=256" in base_desc and "chunks=8 " in base_desc, base_desc
+    for env, ws, must in (({"AFHIP_FORCE_WG": "64"}, False, "wg=64"), ({"AFHIP_NO_PERIOD_CHUNKS": "1", "AFHIP_NO_ROUND_FILL": "1"}, False, "chunks=4 "), ({}, True, "wg=256")):
+        desc, got = run(env, ws)
+        assert must in desc, desc
+        for k in base:
+            np.testing.assert_array_equal(got[k], base[k], err_msg=f"{env} {k}")
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(2 * 150, 6, 20), (2 * 150, 5, 7)])
 def test_pair_plans_lean_and_generic_group_ends(torch_cuda, dtype, shape):
