@@ -200,8 +200,8 @@ struct afhip_csr {
     std::vector<int32_t> h_cols;
     std::vector<double> h_w;
     // Region-fused period ends (FusedArgs::rf_w): per wave-tile size (64 * vec cells) the runs of consecutive cells whose e-th table
-    // entry (e = 0, 1, in table order) names the same region.  ok = false: a cell sits in more than two regions, or the runs are so
-    // short that per-run sums would not be fewer bytes than per-cell values — the plan keeps the per-cell route.
+    // entry (e = 0, 1, in table order) names the same region; the third, fourth ... entries of a cell (junctions of polygons) are kept
+    // as "extras" by region.  ok = false: the tables could not be built (no runs at all, or an upload failed).
     struct RfTab {
         bool built = false, ok = false;
         int64_t n_runs = 0;
@@ -210,6 +210,12 @@ struct afhip_csr {
         DevBuf<uint16_t> run;         // [n_runs]
         DevBuf<int64_t> reg_ptr;      // [R + 1]
         DevBuf<int32_t> reg_runs;     // [n_runs] run ids by region, ascending inside a region
+        // cells in three or more regions: their entries beyond the second ("extras"), by region in table order
+        int64_t n_xcells = 0;
+        DevBuf<int32_t> xidx;         // [n_cells] index among the cells with extras, -1 = none (empty when the table has none)
+        DevBuf<int64_t> xreg_ptr;     // [R + 1]
+        DevBuf<int32_t> xcell;        // [extras] index of the entry's cell among the cells with extras
+        DevBuf<double> xw;            // [extras]
     };
     RfTab rf[3];                    // vec = 1, 2, 4
     std::mutex rf_mu;
@@ -226,13 +232,23 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
     const int64_t C = csr->n_cells, R = csr->R, tc = (int64_t)64 * vec, nt = (C + tc - 1) / tc;
     std::vector<int32_t> reg((size_t)C * 2, -1);
     std::vector<double> w2((size_t)C * 2, 0.0);
-    for (int64_t r = 0; r < R; ++r)
+    std::vector<int32_t> xidx, xcell;
+    std::vector<int64_t> xreg_ptr((size_t)R + 1, 0);
+    std::vector<double> xw;
+    for (int64_t r = 0; r < R; ++r) {
         for (int64_t j = csr->h_indptr[(size_t)r]; j < csr->h_indptr[(size_t)r + 1]; ++j) {
             const size_t c = (size_t)csr->h_cols[(size_t)j];
             const int e = reg[2 * c] < 0 ? 0 : (reg[2 * c + 1] < 0 ? 1 : 2);
-            if (e == 2) return nullptr;                              // a third region on one cell: per-cell route
+            if (e == 2) {                                            // a third (fourth ...) region on this cell: an extra of region r
+                if (xidx.empty()) xidx.assign((size_t)C, -1);
+                if (xidx[c] < 0) xidx[c] = (int32_t)t.n_xcells++;
+                xcell.push_back(xidx[c]); xw.push_back(csr->h_w[(size_t)j]);
+                continue;
+            }
             reg[2 * c + e] = (int32_t)r; w2[2 * c + e] = csr->h_w[(size_t)j];
         }
+        xreg_ptr[(size_t)r + 1] = (int64_t)xcell.size();
+    }
     // (+ 4 empty tiles: the waves of the last workgroup that start beyond the grid look their tile up too)
     std::vector<int32_t> tile((size_t)(nt + 4) * 4, 0), run_region;
     std::vector<uint16_t> run;
@@ -253,8 +269,8 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
         }
     t.n_runs = (int64_t)run.size();
     if (t.n_runs == 0 || t.n_runs > INT32_MAX) return nullptr;
-    // worth it only when the runs are clearly fewer than the cells (every run writes K + 1 sums where a cell writes K values)
-    if (t.n_runs * 3 > C) return nullptr;
+    // (no condition on how short the runs are: the route measured ahead down to regions of five cells — monthly f64 3.65 against 3.95 ms
+    // with 60,000 regions on 215 x 1440 —; afhip_plan_run only checks that the run sums fit the area of the per-cell values)
     std::vector<int64_t> reg_ptr((size_t)R + 1, 0);
     for (int32_t r : run_region) ++reg_ptr[(size_t)r + 1];
     for (int64_t r = 0; r < R; ++r) reg_ptr[(size_t)r + 1] += reg_ptr[(size_t)r];
@@ -263,6 +279,7 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
       for (int64_t q = 0; q < t.n_runs; ++q) reg_runs[(size_t)at[(size_t)run_region[(size_t)q]]++] = (int32_t)q; }
     DeviceGuard g(csr->device);
     if (t.w2.upload(w2) || t.tile.upload(tile) || t.run.upload(run) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
+    if (t.n_xcells && (t.xidx.upload(xidx) || t.xreg_ptr.upload(xreg_ptr) || t.xcell.upload(xcell) || t.xw.upload(xw))) return nullptr;
     t.ok = true;
     return &t;
 }
@@ -1113,6 +1130,11 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && pl->K <= 6 && !getenv("AFHIP_NO_REGION_FUSED");
         for (const ColOp& c : pl->cols) ok = ok && !(c.rounding & AFHIP_ROUND_FINAL);      // (identity outers too: a daily panel of daily means)
         for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
+        // ... and per-cell period values that would be a noticeable share of the traffic: P K 8 bytes per cell against T elem.  Below
+        // ~0.2 % there is nothing to win and the emit still costs: configs[2]'s shape (40 annual values of 2 columns from 350,640
+        // hourly steps: 0.05 %) measured 0.25 % behind, the one-period headline (0.06 %) 0.6 %; the shapes that gain sit at 0.5 % and up.
+        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED"))
+            ok = (double)desc->P * pl->K * 8.0 >= 0.002 * (double)desc->T * (desc->dtype == AFHIP_F32 ? 4.0 : 8.0);
         // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
         // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
         // float32 forms without threshold slots gain 3 - 50 % from two periods on; float32 with a threshold slot (the configs[1] plan
@@ -1257,6 +1279,8 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
         fn = pl->variant_rf->fn;
         lds = (lds + 15) / 16 * 16;
         fa.rf_w = rf->w2.p; fa.rf_tile = rf->tile.p; fa.rf_run = rf->run.p; fa.rf_out = partial; fa.rf_nruns = rf->n_runs;
+        fa.rf_x = rf->n_xcells ? rf->xidx.p : nullptr; fa.rf_nx = rf->n_xcells;
+        fa.rf_ex = partial + pl->n_slots * rf->n_runs * (pl->K + 1);           // behind the run sums
         fa.rf_lds_off = (int32_t)lds;
         lds += (size_t)(pl->wg / 64) * 64 * pl->variant->vec * (size_t)(pl->K + 3) * sizeof(double);
     }
@@ -1411,7 +1435,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     const afhip_csr::RfTab* rf = nullptr;
     if (plan->rf_plan_ok && !exact && !cells_dev && !plan->packed) {
         rf = rf_table(const_cast<afhip_csr*>(csr), plan->variant->vec);
-        if (rf && plan->n_slots * rf->n_runs * (K + 1) * 8 > plan->ws_partial) rf = nullptr;
+        if (rf && plan->n_slots * (rf->n_runs + rf->n_xcells) * (K + 1) * 8 > plan->ws_partial) rf = nullptr;
         if (rf && 64 * (size_t)plan->variant->vec * (size_t)(K + 3) * 8 * (size_t)(plan->wg / 64) + plan_lds_bytes(plan) > 64 * 1024) rf = nullptr;
     }
     const bool prof = !plan->prof_ev.empty() && (size_t)(2 * plan->prof_count + 1) < plan->prof_ev.size();
@@ -1427,7 +1451,8 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
             uint32_t mean_mask = 0;
             for (int j = 0; j < plan->K; ++j) if (plan->cols[(size_t)j].outer == OUT_MEAN) mean_mask |= 1u << j;
             hipLaunchKernelGGL(k_rf_reduce, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, (const double*)partial, rf->reg_ptr.p, rf->reg_runs.p,
-                               plan->d_slot_ptr.p, plan->d_ob.p, mean_mask, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
+                               plan->d_slot_ptr.p, plan->d_ob.p, mean_mask, (const double*)(partial + plan->n_slots * rf->n_runs * (K + 1)), rf->n_xcells,
+                               rf->xreg_ptr.p, rf->xcell.p, rf->xw.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
             HIP_TRY(hipGetLastError());
         }
     } else if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {

@@ -132,7 +132,7 @@ struct FusedArgs {
     uint32_t ccode[MAX_COLS];
     // Region-fused period ends (rf_w != null; afhip_api.hip: rf_table): instead of one value per (slot, column, cell) the kernel
     // writes one weighted sum per (slot, RUN, column) — a run = consecutive cells of a wave's tile whose e-th table entry names the
-    // same region (e = 0, 1: a cell sits in at most two regions, else the plan keeps the per-cell route).  Per period end a wave
+    // same region (e = 0, 1; a cell's third, fourth ... entries are "extras", below).  Per period end a wave
     // stages w_e * where(valid, x_k, 0) and w_e * valid of its cells in a wave-private LDS block and one lane per run adds the
     // run's cells in cell order; k_rf_reduce then adds a region's runs in run order.  The per-cell period values — 0.4 GB per
     // launch on the reference's own benchmark shape, stores that cost its streaming kernel 6 % — are never written, and the
@@ -142,6 +142,11 @@ struct FusedArgs {
     const uint16_t* rf_run;        // device [runs]: (first cell of the run in its wave tile) | (cells - 1) << 8
     double* rf_out;                // device [n_slots][runs][K + 1]
     int64_t rf_nruns;
+    // cells that sit in MORE than two regions (junctions of polygons): their third, fourth ... entries are "extras" — such a cell
+    // also writes its validated period values to rf_ex[slot][rf_x[cell]][K + 1], and k_rf_reduce adds the extras of a region from there
+    const int32_t* rf_x;           // device [C]: index of the cell among the cells with extras, -1 = none; null: the table has none
+    double* rf_ex;                 // device [n_slots][rf_nx][K + 1]
+    int64_t rf_nx;
     int32_t rf_lds_off, rf_pad;    // byte offset of the staging blocks in the dynamic LDS (one block of 64 * VEC * (K + 1) doubles per wave)
 };
 
@@ -863,6 +868,16 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             for (int j = 0; j < KMAX; ++j)
                 if (j < K) row[j] = valid ? val[j][i] : 0.0;
             row[K] = valid ? 1.0 : 0.0;
+            if (a.rf_x != nullptr) {                                 // (uniform) the table has cells in three or more regions
+                const int xi = active ? a.rf_x[cl + i] : -1;
+                if (xi >= 0) {                                       // rare lanes: the cell's values for its extra entries
+                    double* ex = a.rf_ex + ((int64_t)at_slot * a.rf_nx + xi) * K1;
+#pragma unroll
+                    for (int j = 0; j < KMAX; ++j)
+                        if (j < K) ex[j] = valid ? val[j][i] : 0.0;
+                    ex[K] = valid ? 1.0 : 0.0;
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {

@@ -471,8 +471,9 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
 // ---------------------------------------------------------------------------------------
 // k_rf_reduce: the second half of the region-fused period ends (FusedArgs::rf_w).  The streaming kernel left one weighted sum per
 // (slot, run, column) — a run = consecutive cells of one wave tile in one region; this kernel adds a region's runs in run order
-// (= cell order): sums[r][p][k] = sum over the runs of region r of rf_out[slot(p)][run][k]; a period without a slot (empty
-// resample bin) gives zeros, i.e. no weight.  One thread per (region, period, column).
+// (= cell order): sums[r][p][k] = sum over the runs of region r of rf_out[slot(p)][run][k] (+ the region's "extra" entries: the third,
+// fourth ... table entries of cells that sit in more than two regions, weighted here from the values those cells wrote); a period
+// without a slot (empty resample bin) gives zeros, i.e. no weight.  One thread per (region, period, column).
 // ---------------------------------------------------------------------------------------
 // Columns whose outer reducer is the mean (bit k of mean_mask) are divided by the period's inner-group count here: the count is the
 // same for every cell of a period, so sum_c w_c (s_c / n) = (sum_c w_c s_c) / n up to the rounding of the division (the per-cell
@@ -480,6 +481,8 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
 __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_out, const int64_t* __restrict__ reg_ptr,
                                                   const int32_t* __restrict__ reg_runs, const int32_t* __restrict__ slot_ptr,
                                                   const int64_t* __restrict__ outer_bounds, uint32_t mean_mask,
+                                                  const double* __restrict__ ex, int64_t nx, const int64_t* __restrict__ xreg_ptr,
+                                                  const int32_t* __restrict__ xcell, const double* __restrict__ xw,
                                                   double* __restrict__ sums, int64_t R, int64_t P, int K1, int64_t n_runs) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
     if (tid >= R * P * K1) return;
@@ -490,6 +493,10 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
     if (s1 != s0) {
         const double* base = rf_out + (int64_t)s0 * n_runs * K1 + k;
         for (int64_t q = reg_ptr[r]; q < reg_ptr[r + 1]; ++q) acc = __dadd_rn(acc, base[(int64_t)reg_runs[q] * K1]);
+        if (nx) {       // the region's entries on cells that sit in three or more regions (their third, fourth ... entries), in table order
+            const double* xb = ex + (int64_t)s0 * nx * K1 + k;
+            for (int64_t q = xreg_ptr[r]; q < xreg_ptr[r + 1]; ++q) acc = __dadd_rn(acc, __dmul_rn(xw[q], xb[(int64_t)xcell[q] * K1]));
+        }
         if ((mean_mask >> k) & 1u) acc = acc / (double)(outer_bounds[p + 1] - outer_bounds[p]);
     }
     sums[tid] = acc;

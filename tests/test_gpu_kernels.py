@@ -5,6 +5,7 @@ reference's numba kernels, float64 accumulation, no FMA contraction); 1e-10 rela
 sine_dd (device acos/sin/atan/cos vs libm), as BASELINE.json's north_star states.
 """
 import numpy as np
+import pandas as pd
 import pytest
 
 from oracle import cport
@@ -814,7 +815,7 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     region's runs) — the per-cell period values are never written.  Same numbers as the routes that do write them
     (AFHIP_NO_REGION_FUSED=1: k_csr_spmm_slots; exact_order: table order) to rounding, and as the oracle's spatial stage on the
     plan's own per-cell values; NaN cells (shared validity), zero-weight regions, an empty period, border cells that sit in two
-    regions, the last partly filled tile.  Tables whose regions are a few cells (runs too short to pay) and plans the route does not
+    regions, cells in up to five regions (the "extras"), regions of a few cells, the last partly filled tile.  Plans the route does not
     cover (float32 rounding of the final value, one period; float32 with threshold slots and the pair / four-row lean forms, where it measured behind)
     stay on the per-cell routes."""
     from aggfly_amd import hip
@@ -903,22 +904,37 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         xd = hip.FusedPlan(T, C, code, ib, np.arange(61, dtype=np.int64), daily, exact_order=True).run(d, csr)
         np.testing.assert_allclose(fd["res"].cpu().numpy(), xd["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
         np.testing.assert_allclose(fd["den"].cpu().numpy(), xd["den"].cpu().numpy(), rtol=1e-12)
-        # ... a cell that sits in three regions (a junction of polygons): the run tables hold two entries per cell
-        r3 = np.concatenate([ridx, [(ridx[cidx == 4000][0] + 1) % nR, (ridx[cidx == 4000][0] + 2) % nR]])
-        c3 = np.concatenate([cidx, [4000, 4000]])
-        w3 = np.concatenate([w, [0.25, 0.125]])
+        # cells that sit in three, four and five regions (junctions of polygons; the run tables hold two entries per cell, the rest
+        # are "extras" that k_rf_reduce adds from the values those cells write on the side): 300 random cells get up to three more
+        # regions each, one of them a NaN ("ocean") cell and one in a zero-weight region
+        rj = np.random.default_rng(46)
+        jc = rj.choice(C, 300, replace=False)
+        jc[0] = int(np.flatnonzero(np.isnan(cube).all(axis=0).reshape(-1))[0])
+        more_c = np.repeat(jc, rj.integers(1, 4, 300))
+        more_r = rj.integers(0, nR, len(more_c))
+        r3 = np.concatenate([ridx, more_r]); c3 = np.concatenate([cidx, more_c]); w3 = np.concatenate([w, rj.uniform(0.05, 0.9, len(more_c))])
+        keep = ~pd.DataFrame({"r": r3, "c": c3}).duplicated().to_numpy()        # a (region, cell) pair appears once in a weights table
+        r3, c3, w3 = r3[keep], c3[keep], w3[keep]
         o3 = np.argsort(r3, kind="stable")
-        assert np.bincount(c3).max() >= 3
+        assert np.bincount(c3).max() >= 4
         jcsr = hip.CSR(r3[o3], c3[o3], w3[o3], nR, C)
         a = plan.run(d, jcsr)
-        assert "last-run=region-fused" not in plan.describe(), plan.describe()
-        np.testing.assert_array_equal(a["res"].cpu().numpy(), plain.run(d, jcsr)["res"].cpu().numpy())
+        assert "last-run=region-fused" in plan.describe(), plan.describe()
+        b = plain.run(d, jcsr)
+        for key in ("num", "den", "res"):
+            np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-12, atol=1e-9 if key == "num" else 0, equal_nan=True, err_msg=key)
+        jtab = pd.DataFrame({"index_right": r3[o3], "cell_id": c3[o3], "weight": w3[o3]})
+        nums, den, _ = spatial_num_den({f"k{k}": cells[k].T for k in range(K)}, jtab, np.arange(C))
+        np.testing.assert_allclose(a["den"].cpu().numpy(), den, rtol=1e-12)
+        for k in range(K):
+            np.testing.assert_allclose(a["num"][k].cpu().numpy(), nums[f"k{k}"], rtol=1e-12, atol=1e-9)
+        # regions of a handful of cells (runs of two or three cells): still the route — it measured ahead down to five-cell regions
         tiny = synth.weights_table(ny, nx, 2500, seed=44)
         tcsr = hip.CSR(tiny["index_right"].to_numpy(), tiny["cell_id"].to_numpy(), tiny["weight"].to_numpy(), int(tiny["index_right"].max()) + 1, C)
         a = plan.run(d, tcsr)
-        assert "last-run=region-fused" not in plan.describe(), plan.describe()
+        assert "last-run=region-fused" in plan.describe(), plan.describe()
         b = plain.run(d, tcsr)
-        np.testing.assert_array_equal(a["res"].cpu().numpy(), b["res"].cpu().numpy())
+        np.testing.assert_allclose(a["res"].cpu().numpy(), b["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
 
 
 def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeypatch):
