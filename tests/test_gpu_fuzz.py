@@ -178,6 +178,14 @@ def test_random_specs_on_the_region_fused_route(torch_cuda, seed):
     lon360 = bool(seed % 3 == 0)
     lat, lon = 10 + 0.5 * np.arange(ny), (200.0 if lon360 else -60.0) + 0.5 * np.arange(nx)
     tab = synth.weights_table(ny, nx, 12, seed=seed, secondary=bool(seed % 2), zero_frac=0.1)
+    if seed % 4 >= 2:
+        # junctions of polygons: 3 % of the cells get one to three more regions each (cells in up to five regions: the route's "extras")
+        nreg = int(tab.index_right.max()) + 1
+        jc = np.repeat(rng.choice(ny * nx, ny * nx // 33, replace=False), 3)[: int(rng.integers(ny * nx // 33, 3 * (ny * nx // 33)))]
+        more = pd.DataFrame({"cell_id": jc, "index_right": rng.integers(0, nreg, len(jc)), "weight": rng.uniform(0.05, 0.9, len(jc))})
+        tab = (pd.concat([tab[["cell_id", "index_right", "weight"]], more]).drop_duplicates(["index_right", "cell_id"])
+               .sort_values(["index_right", "cell_id"], kind="stable").reset_index(drop=True))
+        assert tab.groupby("cell_id").size().max() >= 3
     gr = af.GeoRegions(pd.DataFrame({"geoid": [f"r{i}" for i in range(int(tab.index_right.max()) + 1)]}))
     ds = af.Dataset(af.DataArray(cube, ["time", "latitude", "longitude"], {"time": time, "latitude": lat, "longitude": lon}), lon_is_360=lon360).to_device()
     w = af.weights_from_objects(ds, gr, table=tab)
@@ -185,7 +193,7 @@ def test_random_specs_on_the_region_fused_route(torch_cuda, seed):
     ods = ra.ODataset(cube.astype(np.float64), time, lat, lon, lon360)
     taken = 0
     for trial in range(4):
-        g2 = str(rng.choice(["week", "month"]))
+        g2 = ["week", "month"][trial % 2]          # (months of 240 steps are cut into several slots on this small grid: per-cell route)
         spec, thr = {}, False
         for v in range(int(rng.integers(1, 4))):
             # (eight rows per date group: the direct-load path, whose variants have region-fused twins)
