@@ -1444,6 +1444,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
     plan->last_route = rf ? 1 : 0;
+    bool divided = false;           // the count gather wrote num / den / res itself
     if (rf) {
         // a region's runs added in run order -> sums[r][p][K + 1] (no pieces: rows [0, R) only)
         const int64_t n = csr->R * P * (K + 1);
@@ -1460,9 +1461,12 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         // (every period has at most one slot: single-level plans are never split); long rows in segments unless exact
         const int64_t nv = exact ? csr->R : csr->nseg, nq = nv * P;
         if (nq) {
+            // rows that are never cut (exact order, or a table without long rows): the gather finishes the panel itself, no divide kernel
+            divided = (exact || csr->n_split == 0) && nv == csr->R && !getenv("AFHIP_NO_COUNTS_DIVIDE");
             hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st,
                                exact ? csr->indptr.p : csr->seg_ptr.p, exact ? (const int32_t*)nullptr : csr->seg_dst.p, csr->cols.p,
-                               csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk);
+                               csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk,
+                               divided ? num_dev : (double*)nullptr, divided ? den_dev : (double*)nullptr, divided ? res_dev : (double*)nullptr);
             HIP_TRY(hipGetLastError());
             if (!exact && csr->n_split) {
                 const int64_t n = csr->n_split * Q;
@@ -1479,7 +1483,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         if ((rc = launch_spmm(csr, panel, plan->sums, Q, st, exact))) return rc;
     }
     const int64_t n = K > 0 ? csr->R * P : 0;                 // one thread per (region, period)
-    if (n) {
+    if (n && !divided) {
         hipLaunchKernelGGL(k_panel_divide, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, plan->sums, num_dev,
                            den_dev, res_dev, csr->R, P, (int)K);
         HIP_TRY(hipGetLastError());

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
                                                         const int32_t* __restrict__ cols,
                                                         const double* __restrict__ w, const void* __restrict__ packed,
                                                         const int32_t* __restrict__ slot_ptr, double* __restrict__ out,
-                                                        int64_t R, int64_t P, int K, int64_t C, const PackFmt pk) {
+                                                        int64_t R, int64_t P, int K, int64_t C, const PackFmt pk,
+                                                        double* __restrict__ num = nullptr, double* __restrict__ den = nullptr,
+                                                        double* __restrict__ res = nullptr) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;       // = r * P + p: a wave walks the periods of one region
     if (tid >= R * P) return;
     const int64_t r = tid / P, p = tid - r * P;
@@ -251,6 +253,20 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
             ld_record(packed, pk, s0, C, cols[j], q);
             feed(w[j], q);
         }
+    }
+    if (res != nullptr) {
+        // no row of this table is cut into segments (the host checked): the thread holds the K + 1 sums of its (region, period) and
+        // finishes the panel itself — k_panel_divide's arithmetic (spatial.py:127-133) without writing the sums and reading them back
+        const int64_t RP = R * P, rp = r * P + p;
+        const double de = acc[MAX_COLS];
+        if (den) den[rp] = de;
+#pragma unroll
+        for (int k = 0; k < MAX_COLS; ++k) {
+            if (k >= K) continue;
+            if (num) num[(int64_t)k * RP + rp] = acc[k];
+            res[(int64_t)k * RP + rp] = (de != 0.0) ? acc[k] / de : nan64();
+        }
+        return;
     }
 #pragma unroll
     for (int k = 0; k < MAX_COLS; ++k)
