@@ -392,7 +392,9 @@ extern "C" int afhip_csr_create(const int64_t* indptr, const int64_t* cols, cons
     for (int64_t r = 0; r < R; ++r) {
         const int64_t j0 = indptr[r], j1 = indptr[r + 1], len = j1 - j0;
         h->max_row = std::max(h->max_row, len);
-        if (len <= seg) {
+        // (rows up to four segments long stay whole: cutting a 150-entry county in two bought nothing and cost every step of an
+        // annual panel a segment-merge launch and, with it, the divide fused into the gather)
+        if (len <= 4 * seg) {
             seg_ptr.push_back(j0); seg_dst.push_back((int32_t)r);
         } else {
             const int64_t want = std::min(SPMM_MAX_PIECES, (len + seg - 1) / seg);
@@ -1334,13 +1336,17 @@ static bool slot_spmm_off() { return env_flag("AFHIP_NO_SLOT_SPMM"); }
 // (segment, period) in one pass; then the pieces of cut rows.  The lanes per (segment, period) follow the table's mean
 // segment length — 64 for county-sized rows on a fine grid (and then bit-identical to combine + k_csr_spmm_wave), 8 for
 // tables whose regions hold a handful of cells.
-static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double* partial, hipStream_t st) {
+static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double* partial, hipStream_t st,
+                             double* num_dev, double* den_dev, double* res_dev, bool* divided) {
     const int64_t P = pl->desc.P, K = pl->K, Q = (K + 1) * P;
     if (csr->nseg * P == 0) return AFHIP_OK;
     SlotSpmmArgs sa{};
     sa.seg_ptr = csr->seg_ptr.p; sa.dst = csr->seg_dst.p; sa.cols = csr->cols.p; sa.w = csr->w.p;
     sa.partial = partial; sa.slot_ptr = pl->d_slot_ptr.p; sa.outer_bounds = pl->d_ob.p; sa.out = pl->sums;
     sa.nseg = csr->nseg; sa.P = P; sa.C = pl->desc.n_cells; sa.K = (int32_t)K;
+    // no row of the table is cut: a segment IS a region, and the lane that holds its K + 1 sums finishes the panel (no divide kernel)
+    *divided = csr->n_split == 0 && csr->nseg == csr->R && !getenv("AFHIP_NO_SLOTS_DIVIDE");
+    if (*divided) { sa.num = num_dev; sa.den = den_dev; sa.res = res_dev; sa.R = csr->R; }
     for (int j = 0; j < pl->K; ++j) {
         sa.outer[j] = pl->cols[(size_t)j].outer;
         sa.round_final[j] = (pl->cols[(size_t)j].rounding & AFHIP_ROUND_FINAL) ? 1 : 0;
@@ -1477,7 +1483,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         }
     } else if (!exact && !cells_dev && !plan->packed && K > 0 && !slot_spmm_off()) {
         // no per-cell output wanted, no table-order promise: the weighted sums gather the slots directly (no panel)
-        if ((rc = launch_spmm_slots(plan, csr, partial, st))) return rc;
+        if ((rc = launch_spmm_slots(plan, csr, partial, st, num_dev, den_dev, res_dev, &divided))) return rc;
     } else {
         if ((rc = launch_combine(plan, partial, cells_dev, panel, st))) return rc;
         if ((rc = launch_spmm(csr, panel, plan->sums, Q, st, exact))) return rc;

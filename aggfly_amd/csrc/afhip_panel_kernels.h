@@ -386,6 +386,12 @@ struct SlotSpmmArgs {
     int32_t K, pad;
     int32_t outer[MAX_COLS];
     int32_t round_final[MAX_COLS];
+    // res != null (no row of the table is cut into segments: segment v IS region dst[v]): the lane that holds the K + 1 sums writes
+    // num[K][R][P], den[R][P], res[K][R][P] itself (k_panel_divide's arithmetic, spatial.py:127-133)
+    double* num;
+    double* den;
+    double* res;
+    int64_t R;
 };
 
 template <int KB, int SUB>
@@ -476,6 +482,18 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
             if (k < K || k == KB) acc[k] = __dadd_rn(acc[k], __shfl_xor(acc[k], m, 64));
     }
     if (sl == 0 && live) {
+        if (a.res != nullptr) {
+            const int64_t RP = a.R * a.P, rp = (int64_t)a.dst[v] * a.P + p;
+            const double de = acc[KB];
+            if (a.den) a.den[rp] = de;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k >= K) continue;
+                if (a.num) a.num[(int64_t)k * RP + rp] = acc[k];
+                a.res[(int64_t)k * RP + rp] = (de != 0.0) ? acc[k] / de : nan64();
+            }
+            return;
+        }
         double* o = a.out + ((int64_t)a.dst[v] * a.P + p) * (K + 1);
 #pragma unroll
         for (int k = 0; k < KB; ++k)
