@@ -173,7 +173,7 @@ struct DevBuf {
 
 }  // namespace
 
-// Long rows are cut into segments that are summed by separate threads / waves and then added in row order
+// Long rows (more than four segment lengths) are cut into segments that are summed by separate threads / waves and then added in row order
 // (k_csr_combine_segments): real admin-2 tables span four decades of row lengths, and one lane walking a 10^5-entry row
 // alone would be the whole kernel's tail.  The segment length follows the table: ~nnz / 4096 entries (64 .. 1024, a
 // multiple of 64), so that a table dominated by a few huge rows still spreads over the chip (a 55 k-entry table whose
