@@ -1141,8 +1141,9 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
         // float32 forms without threshold slots gain 3 - 50 % from two periods on; float32 with a threshold slot (the configs[1] plan
         // on float32 storage) is level at 12 periods and ahead from ~24 (whole step -2.5 % at 24, -14 % at 52, -19 % at 73, -33 % at
-        // 365); the pair / four-row lean forms (their emit is inlined once per group copy, their prefetched rows are live across it)
-        // have no twins in the menu.
+        // 365).  Of the short-group forms the lean four-row ones and the six-column lean pair form have twins (6-hourly monthly
+        // polynomial: step 0.97 against 1.13 - 1.33 ms; polynomial of the daily mean of (tmin, tmax) pairs 4.75 against 5.12); the
+        // sine-only pair form (monthly sine_dd: 4.45 against 4.26) and the one- / two-column pair forms have none.
         if (ok && !getenv("AFHIP_FORCE_REGION_FUSED")) ok = desc->dtype == AFHIP_F64 || pl->nthr == 0 || desc->P >= 24;
         pl->rf_plan_ok = ok;
     }

@@ -808,7 +808,7 @@ def test_slot_gather_spatial_stage_against_the_panel_route_and_the_oracle(torch_
     monkeypatch.delenv("AFHIP_SLOT_SPMM_SUB")
 
 
-@pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32", "hourly_f64_lognormal"])
+@pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32", "hourly_f64_lognormal", "six_hourly_f32", "six_hourly_f64", "pairs_poly_f32"])
 def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkeypatch, kind):
     """Plans with several output periods, sum-like outer reducers and no per-cell output reduce their cells by region INSIDE the
     streaming kernel at every period end (FusedArgs::rf_w: per-run weighted sums from a wave-private LDS block, k_rf_reduce adds a
@@ -841,6 +841,14 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         # float64: the configs[1] columns (a threshold slot + the polynomial); float32 plans with threshold slots stay on the
         # per-cell route (measured behind), so the float32 case is the polynomial alone — the reference's own benchmark plan
         cols = ([dict(inner="dd", inner_args=(10, 30, 0), outer="sum")] if dtype == np.float64 else []) + poly
+    elif kind.startswith("six_hourly") or kind.startswith("pairs"):
+        # short inner groups: the lean four-row form (every one of them has a twin) and the six-column lean pair form (plans of three
+        # columns and more; the sine-only and one- / two-column pair forms stay on the per-cell route)
+        dtype = np.float64 if kind.endswith("f64") else np.float32
+        spd = 4 if kind.startswith("six") else 2
+        T = spd * 60
+        cube = _cube(T, ny, nx, dtype, seed=47)
+        cols = poly if spd == 2 else [dict(inner="mean", transform="pow", transform_arg=float(e), outer="sum") for e in (1, 3)] + [dict(inner="max", outer="sum")]
     else:
         dtype, spd = np.float32, 8                                   # three-hourly steps: min / max sources beside the mean
         T = spd * 60
@@ -857,6 +865,12 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     K = len(cols)
     plan = hip.FusedPlan(T, C, code, ib, ob, cols)
     assert "region-fused-capable" in plan.describe(), plan.describe()
+    if kind.startswith("six_hourly"):
+        assert "_quad" in plan.describe(), plan.describe()
+    if kind.startswith("pairs"):
+        assert "_pair_lean" in plan.describe(), plan.describe()
+        sine_only = hip.FusedPlan(T, C, code, ib, ob, [dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum")])
+        assert "_pair_ss" in sine_only.describe() and "region-fused" not in sine_only.describe(), sine_only.describe()
     fused = plan.run(d, csr)
     assert "last-run=region-fused" in plan.describe(), plan.describe()
     monkeypatch.setenv("AFHIP_NO_REGION_FUSED", "1")
