@@ -482,7 +482,12 @@ class FusedPlan:
 
     def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None, workspace=None):
         """-> dict(num[K,R,P], den[R,P], res[K,R,P], cells?, kernel_ms?).  ``workspace``: an optional
-        caller-owned uint8 HBM tensor of at least ``workspace_bytes()`` (else the plan owns one)."""
+        caller-owned uint8 HBM tensor of at least ``workspace_bytes()`` (else the plan owns one).
+
+        ``want_cells=False`` (what `aggregate_dataset` asks for) lets the library skip the per-cell values: one gather over the
+        period partials finishes the panel, and plans with several output periods reduce their cells by region inside the
+        streaming kernel at every period end (``describe()`` names the route of the last run); ``want_cells=True`` and
+        ``exact_order`` plans build the cell-major panel and sum in the table's order.  Same numbers to rounding either way."""
         torch = _torch()
         cube = self._check_cube(cube)
         dev = cube.device
