@@ -370,12 +370,12 @@ __device__ __forceinline__ double sine_arc(double d, double x, double alpha, sin
 //   F(a) = (sqrt(1 - a^2) - a acos(a)) / pi        (F(-a) = F(a) + a folds the sign of z into the max() term;
 // the max() term alone is the reference's value on either side of the window).
 // F has ONE singularity on [0, 1], the (1 - a)^(3/2) branch point at a = 1:  F(a) = (1 - a)^(3/2) P2(a)  with P2 analytic for
-// |1 - a| < 2 — and nearly constant on [0, 1] (0.300 .. 0.318).  P2 is a table of cubics: row k = round(256 a) holds the cubic in
-// da = a - k / 256 (scripts/fit/sine_p2_fit.py: mpmath, Chebyshev nodes, 2.3e-15 from P2), so the arc is ONE square root
-// (t = sqrt(1 - a), t^3 = t (1 - a)), four instructions for (k, da, row address), three FMAs and one 32-byte LDS row: 17 fp64 /
-// integer instructions + v_rsq_f64, where acos from sine_theta and g - a theta took 23 (and the degree-14 asin of round 2, 44).
-// It is better conditioned, too: no cancellation g - a theta next to a = 1.
-constexpr int SINE_P2_N = 256;                                   // = AFHIP_SINE_P2_N of the generated table
+// |1 - a| < 2 — and nearly constant on [0, 1] (0.300 .. 0.318).  P2 is a table of cubics (scripts/fit/sine_p2_fit.py: mpmath,
+// Chebyshev nodes), so the arc is ONE square root and one 32-byte LDS row, where acos from sine_theta and g - a theta took 23 fp64 /
+// integer instructions (and the degree-14 asin of round 2, 44).  It is better conditioned, too: no cancellation g - a theta next
+// to a = 1.  Three layouts of the table were built in round 3: rows in a (centred cubics, 17 + rsq), rows in x = 4 (1 - a)
+// (absolute cubics, 13 + rsq) and — the one in the tree — rows in th = 2 sqrt(1 - a), 512 on [0, 2] (11 + rsq; sine_pair_g).
+constexpr int SINE_P2_N = 512;                                   // = AFHIP_SINE_P2_N of the generated table
 constexpr int SINE_P2_BYTES = (SINE_P2_N + 1) * 32 + 32;         // (+ a pad row: multiple of 64 bytes)
 struct alignas(32) SineP2Row { double c0, c1, c2, c3; };
 typedef const __attribute__((address_space(3))) SineP2Row* sine_p2_t;
@@ -392,12 +392,12 @@ __device__ __forceinline__ double max_tiny(double x) {
 }
 // one threshold strictly inside a (tmin, tmax) pair: alpha F(a) = u sqrt(om) P2(1 - om), u = alpha - |thr - tavg| in (0, alpha],
 // om = u / alpha = 1 - a — without the reciprocal of alpha: with rng = 2 alpha, u2 = 2 u and the seed z ~ rsq(u2 rng),
-//   th = u2 z (3 - (u2 rng) z^2) = 2 sqrt(om)   (one Newton step on the seed, in product form),   x = th^2 = 4 om,
-//   alpha F = (u2 th) G(x),   G(x) = P2(1 - x / 4) / 4: cubic rows in x itself (scripts/fit/sine_p2_fit.py),
-// returned as the two factors w = su2 th and p = G(x).  12 VALU + rsq; `su2` is u2 carrying the sign the caller wants on the
+//   th = u2 z (3 - (u2 rng) z^2) = 2 sqrt(om)   (one Newton step on the seed, in product form),   th^2 = 4 om,
+//   alpha F = (u2 th) H(th),   H(th) = P2(1 - th^2 / 4) / 4: cubic rows in th itself (scripts/fit/sine_p2_fit.py),
+// returned as the two factors w = su2 th and p = H(th).  11 VALU + rsq; `su2` is u2 carrying the sign the caller wants on the
 // product (only |su2| enters v and th).
 __device__ __forceinline__ void sine_pair_g(double su2, double rng, sine_p2_t tab, double& w, double& p) {
-    static_assert(SINE_P2_N == 256, "the index trick adds 2^46 = 2^52 / 64");
+    static_assert(SINE_P2_N == 512, "the index trick adds 2^44 = 2^52 / 256");
     double v;                                                    // |su2| rng + tiny: u may round to 0 (thr one ulp inside the window); rsq(0) = inf
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_fma_f64 %0, |%1|, %2, %3" : "=v"(v) : "v"(su2), "v"(rng), "s"(1e-300));
@@ -408,12 +408,12 @@ __device__ __forceinline__ void sine_pair_g(double su2, double rng, sine_p2_t ta
     const double a = v * z;
     const double e = __fma_rn(-a, z, 3.0);
     const double th = (__builtin_fabs(su2) * z) * e;
-    const double x = th * th;
-    const double ti = x + 70368744177664.0;                      // + 2^46 (ulp 2^-6): the sum's low word is k = round(64 x)
+    // the table is indexed by th itself (H(th) = G(th^2), 512 cubics on [0, 2]: no x = th * th; the first table of round 3 was in x)
+    const double ti = th + 17592186044416.0;                     // + 2^44 (ulp 2^-8): the sum's low word is k = round(256 th)
     const uint32_t k = (uint32_t)__double2loint(ti);
     sine_p2_t row = (sine_p2_t)(uintptr_t)lshl_add((uint32_t)(uintptr_t)tab, k, 5);
     const double c0 = row->c0, c1 = row->c1, c2 = row->c2, c3 = row->c3;
-    p = __fma_rn(__fma_rn(__fma_rn(c3, x, c2), x, c1), x, c0);
+    p = __fma_rn(__fma_rn(__fma_rn(c3, th, c2), th, c1), th, c0);
     w = su2 * th;
 }
 // cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
