@@ -750,8 +750,12 @@ static int build_chunks(afhip_plan* pl, int vec) {
     const auto& ib = pl->ib;
     const auto& ob = pl->ob;
     const int64_t G1 = pl->desc.G1, P = pl->desc.P, T = pl->desc.T, C = pl->desc.n_cells;
-    // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups
-    pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count(pl->device)) ? 64 : WG;
+    // single-wave workgroups when 256-thread tiles cannot give every CU a few workgroups — and on large grids too, unless every
+    // workgroup copies a sine table into LDS first (pair-mode sine_dd at 64 threads: 3.23 -> 5.80 ms).  The bare streaming read of
+    // this access shape is fastest in single-wave workgroups (scripts/probe/read_bw.hip: 7.02 against 6.69 TB/s at four rows in
+    // flight, profiles/r03_read_ceiling.txt) and the plans follow it by less: configs[1] f64 3.142 -> 3.131 ms, f32 1.713 -> 1.693,
+    // C1 f32 1.577 -> 1.558, the reference's benchmark shape 5.336 -> 5.281 (same box, arms alternated; 128 threads: 3.234).
+    pl->wg = ((C + (int64_t)WG * vec - 1) / ((int64_t)WG * vec) < (int64_t)cu_count(pl->device) || !pl->has_sine) ? 64 : WG;
     // the LDS-histogram kernel: single-wave workgroups and MANY time chunks.  It is short of bytes in flight (waves park 65 % of
     // their cycles on memory at 4.2 waves per SIMD, VALU and LDS far from busy: profiles/r03_c4_bound_pmc.txt), and the more,
     // smaller workgroups the grid offers the fuller the CUs stay: configs[3] f32 3.15 ms (7 chunks of 256 threads) -> 2.84 ms

@@ -953,11 +953,11 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
 
 def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeypatch):
     """The region-fused period ends add a run's cells in cell order and a region's runs in run order; runs are cut per wave TILE (64
-    cells per lane-cell), not per workgroup or chunk — so single-wave or four-wave workgroups, one time chunk per period or two
+    cells per lane-cell), not per workgroup or chunk — so single-wave (the default) or four-wave workgroups, one time chunk per period or two
     periods per chunk, a caller-owned workspace or the plan's own: the same bits."""
     from aggfly_amd import hip
     torch = torch_cuda
-    T, ny, nx = 24 * 24, 160, 512                                    # 320 tiles of 256 threads: four-wave workgroups by default
+    T, ny, nx = 24 * 24, 160, 512                                    # 1280 single-wave tiles
     g = torch.Generator(device="cuda").manual_seed(61)
     d = 15 + 12 * torch.randn((T, ny, nx), generator=g, device="cuda", dtype=torch.float64)
     d[7, 5, 9] = float("nan")
@@ -981,8 +981,8 @@ def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeyp
         return plan.describe(), {k: out[k].cpu().numpy() for k in ("num", "den", "res")}
 
     base_desc, base = run({})
-    assert "wg=256" in base_desc and "chunks=8 " in base_desc, base_desc
-    for env, ws, must in (({"AFHIP_FORCE_WG": "64"}, False, "wg=64"), ({"AFHIP_NO_PERIOD_CHUNKS": "1", "AFHIP_NO_ROUND_FILL": "1"}, False, "chunks=4 "), ({}, True, "wg=256")):
+    assert "wg=64" in base_desc and "chunks=8 " in base_desc, base_desc
+    for env, ws, must in (({"AFHIP_FORCE_WG": "256"}, False, "wg=256"), ({"AFHIP_NO_PERIOD_CHUNKS": "1", "AFHIP_NO_ROUND_FILL": "1"}, False, "chunks=4 "), ({}, True, "wg=64")):
         desc, got = run(env, ws)
         assert must in desc, desc
         for k in base:
