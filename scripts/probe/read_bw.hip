@@ -57,6 +57,52 @@ __global__ void k_read(const uint32_t* __restrict__ base, size_t row_dw, int T, 
     out[(size_t)blockIdx.y * (row_dw / W) + col / W] = acc;
 }
 
+// the same walk with raw buffer loads on a uniform row pointer (the production kernel's ld_stream_row) and an explicit cache-policy
+// operand: aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1.  REMAP: 0 = blockIdx.x is the tile; 1 = every XCD (blockIdx.x % 8) walks its own
+// contiguous eighth of the tiles; 2 = tiles in groups of 8 per XCD (4 KB of a row per XCD at 8-byte lanes)
+template <int AUX, int D, int REMAP>
+__global__ void k_read_buf(const uint32_t* __restrict__ base, size_t row_dw, int T, int rows_per_chunk, uint32_t* __restrict__ out) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    uint32_t b = blockIdx.x;
+    const uint32_t nb = gridDim.x;
+    if constexpr (REMAP == 1) { const uint32_t per = (nb + 7) / 8; b = (b % 8) * per + b / 8; if (b >= nb) return; }
+    if constexpr (REMAP == 2) { const uint32_t g = b / 64, r = b % 64; b = g * 64 + (r % 8) * 8 + r / 8; if (b >= nb) return; }
+    const size_t lane = (size_t)b * blockDim.x + threadIdx.x;
+    const size_t col = lane * 2;
+    if (col >= row_dw) return;
+    const int t0 = blockIdx.y * rows_per_chunk, t1 = min(T, t0 + rows_per_chunk);
+    const uint32_t* row = base + (size_t)t0 * row_dw;
+    const uint32_t voff = (uint32_t)(col * 4);
+    uint32_t acc = 0;
+    int t = t0;
+    for (; t + D <= t1; t += D) {
+        u2 v[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row + (size_t)j * row_dw), 0, -1, 0x00020000);
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, AUX);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc += v[j].x + v[j].y;
+        row += (size_t)D * row_dw;
+    }
+    for (; t < t1; ++t, row += row_dw) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), 0, -1, 0x00020000);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, AUX);
+        acc += v.x + v.y;
+    }
+    out[(size_t)blockIdx.y * (row_dw / 2) + lane] = acc;
+}
+
+template <int AUX, int REMAP>
+static void launch_buf(const uint32_t* base, size_t row_dw, int T, uint32_t* out, hipStream_t s) {
+    const size_t lanes = row_dw / 2;
+    dim3 grid((unsigned)((lanes + 63) / 64), 1);
+    if (REMAP == 1) grid.x = (grid.x + 7) / 8 * 8;
+    if (REMAP == 2) grid.x = (grid.x + 63) / 64 * 64;
+    hipLaunchKernelGGL((k_read_buf<AUX, 4, REMAP>), grid, dim3(64), 0, s, base, row_dw, T, T, out);
+}
+
 __global__ void k_fill(uint32_t* p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (uint32_t)(i * 2654435761u);
 }
@@ -131,6 +177,26 @@ int main(int argc, char** argv) {
             std::sort(ms.begin(), ms.end());
             const float med = ms[ms.size() / 2];
             std::printf("%-8d %-6d %-4d %-5d %-7d %9.3f %9.3f %9.1f\n", a.W, a.D, a.nt, a.wg, a.chunks, med, ms[0], n * 4 / 1e6 / med);
+            std::fflush(stdout);
+        }
+        struct B { const char* name; void (*fn)(const uint32_t*, size_t, int, uint32_t*, hipStream_t); };
+        const B bufs[] = {{"buffer aux=0 (plain)", launch_buf<0, 0>}, {"buffer aux=1 (sc0)", launch_buf<1, 0>}, {"buffer aux=2 (nt)", launch_buf<2, 0>},
+                          {"buffer aux=3 (sc0 nt)", launch_buf<3, 0>}, {"buffer aux=16 (sc1)", launch_buf<16, 0>}, {"buffer aux=17 (sc0 sc1)", launch_buf<17, 0>},
+                          {"buffer aux=18 (sc1 nt)", launch_buf<18, 0>}, {"buffer aux=19 (sc0 sc1 nt)", launch_buf<19, 0>},
+                          {"buffer nt, XCD-contiguous eighths", launch_buf<2, 1>}, {"buffer nt, 8 tiles per XCD", launch_buf<2, 2>}};
+        for (const B& b : bufs) {                                // 8-byte lanes, depth 4, 64 threads, one chunk
+            std::vector<float> ms;
+            for (int r = 0; r < 9; ++r) {
+                CK(hipEventRecord(e0, s));
+                b.fn(cube, row_dw, T, out, s);
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                float m; CK(hipEventElapsedTime(&m, e0, e1));
+                if (r >= 2) ms.push_back(m);
+            }
+            CK(hipGetLastError());
+            std::sort(ms.begin(), ms.end());
+            std::printf("%-40s %9.3f %9.3f %9.1f\n", b.name, ms[ms.size() / 2], ms[0], n * 4 / 1e6 / ms[ms.size() / 2]);
             std::fflush(stdout);
         }
         std::printf("-- pass %d done\n", pass + 1);
