@@ -679,7 +679,7 @@ static int lower_columns(afhip_plan* pl) {
                     auto up = [](double t) { float f = (float)t; return (double)f < t ? std::nextafterf(f, INFINITY) : f; };
                     co.s0dn = dn(co.s0); co.s0up = up(co.s0); co.s1dn = dn(co.s1); co.s1up = up(co.s1);
                 }
-                co.swidth = co.s1 - co.s0;
+                co.swidth = co.s1 - co.s0; co.swidth2 = 2.0 * co.swidth;
                 pl->has_sine = true;
                 if (c.inner_args[2] != 0.0 && c.inner_args[2] != 1.0)
                     return fail(AFHIP_E_INVALID, "column %d: sine_dd flag must be 0 or 1 (temporal.py:324)", j);

@@ -71,7 +71,7 @@ struct ColOp {
     double s0, s1;             // sine_dd thresholds
     double s0x2, s1x2;         // 2 * s0, 2 * s1 (exact): the cooling form's 2 thr - tmax - tmin starts from them
     float s0dn, s0up, s1dn, s1up;  // s0 / s1 rounded down / up to float: for float tmin, tmax   tmin < s <=> tmin < up,  s < tmax <=> tmax > dn
-    double swidth;                 // s1 - s0
+    double swidth, swidth2;        // s1 - s0, 2 (s1 - s0)
     double tf_arg;             // exponent (TF_POW) or knot (TF_HINGE)
     double o0, o1, obase;      // outer dd/bins thresholds
 };
@@ -932,8 +932,10 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const double tavg = mean[i];
-                bool in0, in1;
-                if constexpr (PAIR && GL == 2 && sizeof(TIn) == 4) {       // float data: exact float compares against the rounded thresholds
+                bool in0 = false, in1 = false;
+                if constexpr (PAIR && GL == 2 && LEAN) {
+                    // (the lean pair form tests its windows on 2 thr - s, below)
+                } else if constexpr (PAIR && GL == 2 && sizeof(TIn) == 4) {       // float data: exact float compares against the rounded thresholds
                     in0 = (plo[i] < co.s0up) && (phi[i] > co.s0dn);
                     in1 = (plo[i] < co.s1up) && (phi[i] > co.s1dn);
                 } else {
@@ -941,20 +943,40 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     in1 = (mn[i] < co.s1) && (co.s1 < mx[i]);
                 }
                 double xv;
-                if constexpr (PAIR && GL == 2) {
+                if constexpr (PAIR && GL == 2 && LEAN) {
+                    // the lean form in DOUBLED units: D = 2 (thr - tavg) = 2 thr - s with one rounding (= 2 d bit for bit), rng = 2 alpha
+                    // exact, so  tmin < thr < tmax  <=>  |D| < rng  is ONE compare per threshold instead of two (were RN(2 thr - s)
+                    // to land on rng from inside, half an ulp away, the arc it skips is exactly 0: u2 = RN(rng - |D|) = 0), u2 is one
+                    // add, and the column's two max() terms are one clamp of width 2 (s1 - s0), halved exactly:
+                    // max(t - s0, 0) - max(t - s1, 0) = clamp(t - s0, 0, s1 - s0) — the reference's (t - s0) - (t - s1) for t >= s1 is
+                    // s1 - s0 up to its own two roundings (1e-16 relative; sine_dd's contract is 1e-10)
+                    const double rng = mx[i] - mn[i];
+                    const double D0 = __fma_rn(s[i], -1.0, co.s0x2), D1 = __fma_rn(s[i], -1.0, co.s1x2);
+                    const bool i0 = fabs(D0) < rng, i1 = fabs(D1) < rng;
+                    double c2;
+                    if (co.skind == 0) { KEEP_BRANCH(); c2 = min_vs(max0_neg(D0), co.swidth2); }
+                    else c2 = min_vs(max0(D1), co.swidth2);
+                    xv = c2 * 0.5;      // (folding this product and the day's add into the column's sum into one fma: built, level; r03_session2_experiments.txt)
+                    if (i0 || i1) {
+                        // cooling: + part(s0) - part(s1); heating: the reverse; the sign rides on u2 = +-(rng - |D|)
+                        double w, p, su;
+                        if (i0) {
+                            if (co.skind == 0) { KEEP_BRANCH(); su = rng - fabs(D0); } else su = fabs(D0) - rng;
+                            sine_pair_g(su, rng, sine_p2, w, p);
+                            xv = __fma_rn(w, p, xv);
+                        }
+                        if (i1) {
+                            if (co.skind == 0) { KEEP_BRANCH(); su = rng - fabs(D1); } else su = fabs(D1) - rng;
+                            sine_pair_g(su, rng, sine_p2, w, p);
+                            xv = __fma_rn(-w, p, xv);
+                        }
+                    }
+                } else if constexpr (PAIR && GL == 2) {
                     // tavg is the mid-range: part = max(+-(tavg - thr), 0) + [inside] alpha F(|thr - tavg| / alpha)  (sine_pair_g)
                     // thr - tavg = thr - s / 2 (s / 2 is exact: one rounding either way)
                     const double d0 = __fma_rn(s[i], -0.5, co.s0), d1 = __fma_rn(s[i], -0.5, co.s1);
-                    if constexpr (LEAN) {
-                        // the two max() terms of a column, s0 < s1 (host-checked for this variant): max(t - s0, 0) - max(t - s1, 0)
-                        // = clamp(t - s0, 0, s1 - s0) — the reference's (t - s0) - (t - s1) for t >= s1 is s1 - s0 up to its
-                        // own two roundings (1e-16 relative; sine_dd's contract is 1e-10)
-                        if (co.skind == 0) { KEEP_BRANCH(); xv = min_vs(max0_neg(d0), co.swidth); }
-                        else xv = min_vs(max0(d1), co.swidth);
-                    } else {
-                        if (co.skind == 0) { KEEP_BRANCH(); xv = max0_neg(d0) - max0_neg(d1); }
-                        else xv = max0(d1) - max0(d0);
-                    }
+                    if (co.skind == 0) { KEEP_BRANCH(); xv = max0_neg(d0) - max0_neg(d1); }
+                    else xv = max0(d1) - max0(d0);
                     if (in0 || in1) {
                         const double rng = mx[i] - mn[i];               // = 2 alpha, exact
                         // cooling: + part(s0) - part(s1); heating: the reverse.  (ONE arc site for both thresholds — a lane's window
