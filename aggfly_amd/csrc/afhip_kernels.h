@@ -395,14 +395,15 @@ __device__ __forceinline__ double max_tiny(double x) {
 //   th = u2 z (3 - (u2 rng) z^2) = 2 sqrt(om)   (one Newton step on the seed, in product form),   th^2 = 4 om,
 //   alpha F = (u2 th) H(th),   H(th) = P2(1 - th^2 / 4) / 4: cubic rows in th itself (scripts/fit/sine_p2_fit.py),
 // returned as the two factors w = su2 th and p = H(th).  11 VALU + rsq; `su2` is u2 carrying the sign the caller wants on the
-// product (only |su2| enters v and th).
+// product (only |su2| enters v and th); `rng` may come with either sign (the sine-only lean form hands over tmax - tmin of an UNORDERED
+// pair: only |rng| is read).
 __device__ __forceinline__ void sine_pair_g(double su2, double rng, sine_p2_t tab, double& w, double& p) {
     static_assert(SINE_P2_N == 512, "the index trick adds 2^44 = 2^52 / 256");
     double v;                                                    // |su2| rng + tiny: u may round to 0 (thr one ulp inside the window); rsq(0) = inf
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_fma_f64 %0, |%1|, %2, %3" : "=v"(v) : "v"(su2), "v"(rng), "s"(1e-300));
+    asm("v_fma_f64 %0, |%1|, |%2|, %3" : "=v"(v) : "v"(su2), "v"(rng), "s"(1e-300));
 #else
-    v = __builtin_fma(__builtin_fabs(su2), rng, 1e-300);
+    v = __builtin_fma(__builtin_fabs(su2), __builtin_fabs(rng), 1e-300);
 #endif
     const double z = __builtin_amdgcn_rsq(v);
     const double a = v * z;
@@ -950,9 +951,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     // add, and the column's two max() terms are one clamp of width 2 (s1 - s0), halved exactly:
                     // max(t - s0, 0) - max(t - s1, 0) = clamp(t - s0, 0, s1 - s0) — the reference's (t - s0) - (t - s1) for t >= s1 is
                     // s1 - s0 up to its own two roundings (1e-16 relative; sine_dd's contract is 1e-10)
-                    const double rng = mx[i] - mn[i];
+                    // (rd: the sine-only form keeps the pair unordered — its min and max are never formed — so the range is |rd|, an abs
+                    // modifier on every instruction that reads it)
+                    const double rd = mx[i] - mn[i];
                     const double D0 = __fma_rn(s[i], -1.0, co.s0x2), D1 = __fma_rn(s[i], -1.0, co.s1x2);
-                    const bool i0 = fabs(D0) < rng, i1 = fabs(D1) < rng;
+                    const bool i0 = fabs(D0) < fabs(rd), i1 = fabs(D1) < fabs(rd);
                     double c2;
                     if (co.skind == 0) { KEEP_BRANCH(); c2 = min_vs(max0_neg(D0), co.swidth2); }
                     else c2 = min_vs(max0(D1), co.swidth2);
@@ -961,13 +964,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         // cooling: + part(s0) - part(s1); heating: the reverse; the sign rides on u2 = +-(rng - |D|)
                         double w, p, su;
                         if (i0) {
-                            if (co.skind == 0) { KEEP_BRANCH(); su = rng - fabs(D0); } else su = fabs(D0) - rng;
-                            sine_pair_g(su, rng, sine_p2, w, p);
+                            if (co.skind == 0) { KEEP_BRANCH(); su = fabs(rd) - fabs(D0); } else su = fabs(D0) - fabs(rd);
+                            sine_pair_g(su, rd, sine_p2, w, p);
                             xv = __fma_rn(w, p, xv);
                         }
                         if (i1) {
-                            if (co.skind == 0) { KEEP_BRANCH(); su = rng - fabs(D1); } else su = fabs(D1) - rng;
-                            sine_pair_g(su, rng, sine_p2, w, p);
+                            if (co.skind == 0) { KEEP_BRANCH(); su = fabs(rd) - fabs(D1); } else su = fabs(D1) - fabs(rd);
+                            sine_pair_g(su, rd, sine_p2, w, p);
                             xv = __fma_rn(-w, p, xv);
                         }
                     }
@@ -1326,6 +1329,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             for (int i = 0; i < VEC; ++i) {
                 const TIn u = r[0].v[i], v = r[1].v[i];
                 pnan[i] = u != u || v != v;
+                if constexpr (GL == 2 && LEAN_SINE) {
+                    // every column a plain sine_dd: the lean group end reads only the pair's sum and |difference| (sine_column) —
+                    // no min, no max; mn / mx hold the pair as it came
+                    mn[i] = (double)u; mx[i] = (double)v;
+                    s[i] = mn[i] + mx[i];
+                    continue;
+                }
                 // v_min / v_max straight on the loaded values: the builtins first canonicalise both operands (v_max x, x)
                 // against signalling NaNs; a group with any NaN is a NaN group anyway
                 TIn lo, hi;
