@@ -687,7 +687,13 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         if (a.sine_tab != nullptr) {            // uniform: the host sets it iff a column is sine_dd (and then sizes the LDS for it)
             typedef double d2 __attribute__((ext_vector_type(2)));
             constexpr int bytes = ((FEAT & 128) != 0 && (FEAT & 1024) == 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
-            for (int e = tid; e < bytes / 16; e += bd) ((d2*)base)[e] = ((const d2*)a.sine_tab)[e];
+            // (the sine-only lean form works in DOUBLED units — clamp, arcs and the column's sum — and halves once per period end:
+            // its copy of the table is 2 H, every step an exact scaling of the undoubled one)
+            for (int e = tid; e < bytes / 16; e += bd) {
+                d2 t = ((const d2*)a.sine_tab)[e];
+                if constexpr (LEAN_SINE) t *= 2.0;
+                ((d2*)base)[e] = t;
+            }
             __syncthreads();
         }
         sine_tab = (sine_tab_t)(lds_ptr_t)base;
@@ -959,7 +965,9 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     double c2;
                     if (co.skind == 0) { KEEP_BRANCH(); c2 = min_vs(max0_neg(D0), co.swidth2); }
                     else c2 = min_vs(max0(D1), co.swidth2);
-                    xv = c2 * 0.5;      // (folding this product and the day's add into the column's sum into one fma: built, level; r03_session2_experiments.txt)
+                    // (folding the halving and the day's add into the column's sum into one fma: built, level; r03_session2_experiments.txt)
+                    if constexpr (LEAN_SINE) xv = c2;       // doubled units all the way: the table in LDS is 2 H, the emit halves
+                    else xv = c2 * 0.5;
                     if (i0 || i1) {
                         // cooling: + part(s0) - part(s1); heating: the reverse; the sign rides on u2 = +-(rng - |D|)
                         double w, p, su;
@@ -1113,7 +1121,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < KMAX; ++j)
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) val[j][i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                        for (int i = 0; i < VEC; ++i) val[j][i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : (LEAN_SINE ? os[j][i] * 0.5 : os[j][i]);
                     if constexpr (RF) rf_emit(val, slot, zoff);
                 } else {
 #pragma unroll
@@ -1122,7 +1130,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                         double* dst = a.partial + ((int64_t)slot * K + j) * C + c0;
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
-                            const double val = ((nanacc[i] >> lane) & 1ull) ? nan64() : os[j][i];
+                            const double val = ((nanacc[i] >> lane) & 1ull) ? nan64() : (LEAN_SINE ? os[j][i] * 0.5 : os[j][i]);
                             if (active) dst[i] = val;
                         }
                     }
