@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-cell-timesteps/s of the fused transform + weighted reduce.
 
-    python bench.py --gpus N --steps K --warmup W [--shard time|cells]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--shard time|cells]      (N > 1: starts its own N ranks as a child torchrun)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (or under a launcher's environment)
 
 Workload (BASELINE.json configs[1], shapes per SURVEY.md §8d): one year of hourly ERA5-like
 2 m temperature on the 0.25 deg US-counties extent (T = 8760, 215 x 1440 = 309,600 cells,
@@ -354,6 +354,36 @@ def run_other_configs(torch, steps=10, warmup=10):      # the first ~10 launches
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks ourselves, one process per GPU, as a
+    CHILD `python -m torch.distributed.run` (never an exec: nothing here has touched the GPU, and the parent only waits),
+    pass its output through and return its exit code.  This is the parallel form of the reference's sequential per-year loop
+    (`aggfly/cli/pipeline.py:138-149`): rank r takes year r.  With fewer GPUs than ranks the launch is refused here, in one
+    line, unless AGGFLY_BENCH_BACKEND=gloo asks for a rehearsal.  AGGFLY_BENCH_DRY_LAUNCH=1 prints the child command as JSON
+    and starts nothing (tests)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    if os.environ.get("AGGFLY_BENCH_DRY_LAUNCH"):
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    if os.environ.get("AGGFLY_BENCH_BACKEND") != "gloo":
+        import torch          # counting devices does not initialise the GPU
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            print(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible. RCCL needs one GPU per rank; a number measured with ranks sharing a "
+                  "card is not a scaling result. Set AGGFLY_BENCH_BACKEND=gloo to rehearse the N > 1 code path on fewer cards.", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,6 +400,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the store -> HBM figure (N = 1, after other_configs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist

@@ -136,6 +136,105 @@ def test_world3_time_shards_with_gaps_on_the_boundaries():
     assert sorted(out) == [(0, "ok"), (1, "ok"), (2, "ok")], out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# world_size 8: the BASELINE splits as the 8-GPU node will see them, rehearsed on gloo with oracle cells
+# ----------------------------------------------------------------------------------------------------------------------
+def _case8(name):
+    """-> (cube, time, tab, ny, nx, inner freq, outer freq, periods expected)"""
+    from aggfly_amd.cfcalendar import cf_range
+    if name == "years40":            # configs[2]: 40 annual periods, five per rank
+        ny, nx, time = 3, 4, pd.date_range("1980-01-01", "2019-12-31", freq="D")
+        return ny, nx, time, "1D", "YE", 40
+    if name == "years251_noleap":    # configs[3]: 251 noleap years -> 32,32,32,31,31,31,31,31: the padded gather
+        ny, nx, time = 3, 4, cf_range("1850-01-01", 251 * 365, "D", "noleap")
+        return ny, nx, time, "1D", "YE", 251
+    if name == "months12":           # the reference's benchmark shape: 12 months -> 2,2,2,2,1,1,1,1
+        ny, nx, time = 4, 5, pd.date_range("2001-01-01", periods=8760, freq="h")
+        return ny, nx, time, "1D", "ME", 12
+    if name == "years5":             # fewer periods than ranks: three ranks hold no period at all
+        ny, nx, time = 3, 4, pd.date_range("2001-01-01", "2005-12-31", freq="D")
+        return ny, nx, time, "1D", "YE", 5
+    if name == "bands215":           # configs[0], [1], [4]: ONE period -> the counties extent's 215 grid rows in 8 bands
+        ny, nx, time = 215, 6, pd.date_range("2001-01-01", periods=72, freq="h")
+        return ny, nx, time, "1D", "YE", 1
+    raise KeyError(name)
+
+
+def _res8(cube, time, tab, ncells, inner, outer):
+    """res[K=2, R, P] of mean@inner -> pow(1, 2) -> sum@outer + the weighted average, all by the oracle; an empty share -> P = 0."""
+    R = int(tab["index_right"].max()) + 1
+    if len(time) == 0:
+        return np.empty((2, R, 0)), time
+    ib, lab = resample_groups(time, inner)
+    ob, labels = resample_groups(lab, outer)
+    m = cport.resample(cube, ib, "mean")
+    cells = np.stack([cport.resample(np.power(m, e), ob, "sum").reshape(len(labels), -1) for e in (1, 2)])
+    nums, den, ids = spatial_num_den({f"k{k}": cells[k].T for k in range(2)}, tab, np.arange(ncells))
+    num = np.zeros((2, R, len(labels))); d = np.zeros((R, len(labels)))
+    num[:, ids] = np.stack([nums["k0"], nums["k1"]]); d[ids] = den
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(d[None] != 0, num / d[None], np.nan), labels, num, d
+
+
+def _worker8(rank, ws, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        ny, nx, time, inner, outer, P_want = _case8(name)
+        cube = synth.temperature_cube(len(time), ny, nx, seed=71, ocean_frac=0.1, scattered_nan=20)
+        tab = synth.weights_table(ny, nx, 7, seed=72, secondary=True)
+        want, labels, _, _ = _res8(cube, time, tab, ny * nx, inner, outer)
+        assert want.shape[2] == P_want
+        if name == "bands215":
+            y0, y1 = D.split_even(ny, rank, ws)
+            assert y1 - y0 == (27 if rank < 7 else 26)
+            rows, cols, w = tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy()
+            br, bc, bw = D.band_csr_triplets(rows, cols, w, ny, nx, y0, y1)
+            R = int(rows.max()) + 1
+            num, den = np.zeros((2, R, 1)), np.zeros((R, 1))
+            if len(br):
+                btab = pd.DataFrame({"index_right": br, "cell_id": bc, "weight": bw})
+                _, _, n_b, d_b = _res8(np.ascontiguousarray(cube[:, y0:y1, :]), time, btab, (y1 - y0) * nx, inner, outer)
+                num[:, :n_b.shape[1]] = n_b; den[:d_b.shape[0]] = d_b
+            _, _, res = D.reduce_num_den(torch.from_numpy(num), torch.from_numpy(den))
+            np.testing.assert_allclose(res.numpy(), want, rtol=1e-13, equal_nan=True)
+        else:
+            k_lo, k_hi, p_lo, p_hi, P = D.time_shard_bounds(time, outer, rank, ws)
+            assert P == P_want
+            counts = [D.split_even(P, r, ws)[1] - D.split_even(P, r, ws)[0] for r in range(ws)]
+            if name == "years251_noleap":
+                assert counts == [32, 32, 32, 31, 31, 31, 31, 31] and k_hi - k_lo == counts[rank] * 365
+            if name == "months12":
+                assert counts == [2, 2, 2, 2, 1, 1, 1, 1]
+            if name == "years5":
+                assert counts == [1, 1, 1, 1, 1, 0, 0, 0] and (k_hi > k_lo) == (rank < 5)
+            local = _res8(cube[k_lo:k_hi], time[k_lo:k_hi], tab, ny * nx, inner, outer)
+            block = D.place_by_label(torch.from_numpy(local[0]), local[1] if len(local[1]) else labels[:0], labels, p_lo, p_hi)
+            full = D.gather_panel(block, counts).numpy()
+            np.testing.assert_array_equal(full, want)                 # whole periods per rank: bit-identical, padding trimmed
+        q.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()[-800:]}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["years40", "years251_noleap", "months12", "years5", "bands215"])
+def test_world8_baseline_splits(name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, name, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(out) == [(r, "ok") for r in range(8)], out
+
+
 def test_place_by_label():
     from aggfly_amd.cfcalendar import cf_range
     labels = pd.date_range("2001-01-31", periods=12, freq="ME")

@@ -302,12 +302,16 @@ def test_bench_two_rank_rehearsal_reports_backend_and_devices(torch_cuda, tmp_pa
     bench = os.path.join(root, "bench.py")
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]
     small = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--ny", "40", "--nx", "64", "--T", "720", "--regions", "30"]
-    env = {k: v for k, v in os.environ.items() if k != "AGGFLY_BENCH_BACKEND"}
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr
+    # the driver's own command line — `python bench.py --gpus 2`, no torchrun around it — is refused the same way, in one line ...
+    r = subprocess.run([sys.executable, bench] + small, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr and "Traceback" not in r.stderr
     for shard, scaling in (("time", "weak"), ("cells", "strong")):
-        r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small + ["--shard", shard], capture_output=True, text=True,
-                           timeout=600, env=dict(env, AGGFLY_BENCH_BACKEND="gloo"))
+        # ... and as a rehearsal starts its own two ranks (time arm) / runs under an outer torchrun (cell arm): same line either way
+        cmd = ([sys.executable, bench] if shard == "time" else launch + ["--master-port", str(_free_port()), bench]) + small + ["--shard", shard]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, AGGFLY_BENCH_BACKEND="gloo"))
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["backend"] == "gloo" and line["devices_visible"] == 1 and line["devices_used"] == 1 and line["ranks"] == 2
@@ -331,12 +335,11 @@ def test_bench_two_ranks_on_two_gpus_use_rccl(torch_cuda, tmp_path):
         pytest.skip("needs two visible GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bench = os.path.join(root, "bench.py")
-    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]
     small = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--ny", "40", "--nx", "64", "--T", "720", "--regions", "30"]
-    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "AGGFLY_DIST_BACKEND")}
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "AGGFLY_DIST_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
     for shard, scaling in (("time", "weak"), ("cells", "strong")):
-        r = subprocess.run(launch + ["--master-port", str(_free_port()), bench] + small + ["--shard", shard], capture_output=True, text=True,
-                           timeout=600, env=env)
+        # the plain command the driver runs: bench.py starts its own ranks (a child torchrun)
+        r = subprocess.run([sys.executable, bench] + small + ["--shard", shard], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["backend"] == "nccl" and line["ranks"] == 2 and line["devices_used"] == 2 and "warning" not in line, line

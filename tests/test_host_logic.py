@@ -380,16 +380,50 @@ def test_choose_backend_compares_with_the_local_world(monkeypatch):
 
 def test_bench_refuses_ranks_without_their_own_gpu():
     """bench.py --gpus N: N ranks on fewer visible GPUs must not silently share a card and fall back to gloo — the run is
-    refused (non-zero exit) unless AGGFLY_BENCH_BACKEND=gloo asks for a rehearsal; --gpus N outside a launcher is refused too."""
+    refused (non-zero exit, one line, no JSON) unless AGGFLY_BENCH_BACKEND=gloo asks for a rehearsal, both as the plain
+    command (which would start its own ranks) and as a rank under a launcher's environment."""
     import subprocess
     bench = os.path.join(ROOT, "bench.py")
-    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "AGGFLY_BENCH_DRY_LAUNCH", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode != 0 and "torch.distributed.run" in r.stderr
+    assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr and "Traceback" not in r.stderr and r.stdout.strip() == ""
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert r.returncode != 0 and "RCCL needs one GPU per rank" in r.stderr and "AGGFLY_BENCH_BACKEND=gloo" in r.stderr
     assert r.stdout.strip() == ""                                     # no JSON line from a refused run
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE is 4" in r.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N ...` — the driver's command line, no torchrun around it — starts the N ranks itself as a CHILD
+    `python -m torch.distributed.run` on 127.0.0.1 with a free port and the same arguments (AGGFLY_BENCH_DRY_LAUNCH shows the
+    command and starts nothing); as a gloo rehearsal without any GPU the child's ranks really start and fail loudly at the
+    engine's door (no CPU fallback), and the parent hands their exit code on."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("AGGFLY_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    args = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run([sys.executable, bench] + args, capture_output=True, text=True, timeout=300, env=dict(env, AGGFLY_BENCH_DRY_LAUNCH="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout)["launch"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    at = cmd.index(bench)
+    assert cmd[at + 1:] == args                                       # the ranks get the command line unchanged
+    # one rank per GPU needs no launch at all
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--help"], capture_output=True, text=True, timeout=300, env=dict(env, AGGFLY_BENCH_DRY_LAUNCH="1"))
+    assert r.returncode == 0 and "launch" not in r.stdout
+    import torch
+    if torch.cuda.is_available():
+        return                                                        # (the GPU suite runs the real thing: tests/test_gpu_sharded.py)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--ny", "8", "--nx", "8", "--T", "48", "--regions", "3"],
+                       capture_output=True, text=True, timeout=600, env=dict(env, AGGFLY_BENCH_BACKEND="gloo"))
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "no HIP device visible" in r.stderr or "No HIP GPUs" in r.stderr or "HipEngineError" in r.stderr, r.stderr[-1500:]
 
 
 def test_plan_and_csr_caches_are_keyed_by_device(monkeypatch):
