@@ -206,8 +206,8 @@ struct afhip_csr {
         bool built = false, ok = false;
         int64_t n_runs = 0;
         DevBuf<double> w2;            // [n_cells][2]
+        DevBuf<int32_t> key;          // [n_cells][2] region of the cell's first / second entry, -1 = none (the scan form of the period end)
         DevBuf<int32_t> tile;         // [wave tiles][2][2]
-        DevBuf<uint16_t> run;         // [n_runs]
         DevBuf<int64_t> reg_ptr;      // [R + 1]
         DevBuf<int32_t> reg_runs;     // [n_runs] run ids by region, ascending inside a region
         // cells in three or more regions: their entries beyond the second ("extras"), by region in table order
@@ -250,24 +250,21 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
         xreg_ptr[(size_t)r + 1] = (int64_t)xcell.size();
     }
     // (+ 4 empty tiles: the waves of the last workgroup that start beyond the grid look their tile up too)
+    // runs of a tile, numbered in cell order (the kernel derives the same numbering from the keys: a run starts where the key changes
+    // to a region, or at the tile's first cell)
     std::vector<int32_t> tile((size_t)(nt + 4) * 4, 0), run_region;
-    std::vector<uint16_t> run;
     for (int64_t ti = 0; ti < nt; ++ti)
         for (int e = 0; e < 2; ++e) {
             const int64_t c_lo = ti * tc, c_hi = std::min(C, c_lo + tc);
-            tile[(size_t)(ti * 2 + e) * 2] = (int32_t)run.size();
-            int64_t start = -1; int32_t key = -1;
-            auto close = [&](int64_t c_end) {
-                if (key >= 0) { run.push_back((uint16_t)((start - c_lo) | ((c_end - start - 1) << 8))); run_region.push_back(key); }
-            };
+            tile[(size_t)(ti * 2 + e) * 2] = (int32_t)run_region.size();
+            int32_t key = -1;
             for (int64_t c = c_lo; c < c_hi; ++c) {
                 const int32_t k = reg[(size_t)(2 * c + e)];
-                if (k != key) { close(c); key = k; start = c; }
+                if (k != key || c == c_lo) { if (k >= 0) run_region.push_back(k); key = k; }
             }
-            close(c_hi);
-            tile[(size_t)(ti * 2 + e) * 2 + 1] = (int32_t)run.size() - tile[(size_t)(ti * 2 + e) * 2];
+            tile[(size_t)(ti * 2 + e) * 2 + 1] = (int32_t)run_region.size() - tile[(size_t)(ti * 2 + e) * 2];
         }
-    t.n_runs = (int64_t)run.size();
+    t.n_runs = (int64_t)run_region.size();
     if (t.n_runs == 0 || t.n_runs > INT32_MAX) return nullptr;
     // (no condition on how short the runs are: the route measured ahead down to regions of five cells — monthly f64 3.65 against 3.95 ms
     // with 60,000 regions on 215 x 1440 —; afhip_plan_run only checks that the run sums fit the area of the per-cell values)
@@ -278,7 +275,7 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
     { std::vector<int64_t> at(reg_ptr.begin(), reg_ptr.end() - 1);
       for (int64_t q = 0; q < t.n_runs; ++q) reg_runs[(size_t)at[(size_t)run_region[(size_t)q]]++] = (int32_t)q; }
     DeviceGuard g(csr->device);
-    if (t.w2.upload(w2) || t.tile.upload(tile) || t.run.upload(run) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
+    if (t.key.upload(reg) || t.w2.upload(w2) || t.tile.upload(tile) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
     if (t.n_xcells && (t.xidx.upload(xidx) || t.xreg_ptr.upload(xreg_ptr) || t.xcell.upload(xcell) || t.xw.upload(xw))) return nullptr;
     t.ok = true;
     return &t;
@@ -320,17 +317,21 @@ struct afhip_plan {
     DevBuf<int32_t> d_slot_ptr;
     // workspace
     int64_t ws_partial = 0, ws_panel = 0;   // byte sizes
-    void* own_ws = nullptr;
-    int64_t own_ws_bytes = 0;
-    double* sums = nullptr;
-    int64_t sums_bytes = 0;
+    void* own_ws = nullptr;                 // plan-owned scratch (callers that hand no workspace): grown by a new hipMalloc, the
+    int64_t own_ws_bytes = 0;               // outgrown block is `retired` until the plan is destroyed — no hipFree (a device-wide
+    std::vector<void*> retired;             // synchronisation) ever sits on the run path
+    double* sums = nullptr;                 // [rows][P][K + 1] of the current run: behind partial + panel in the run's workspace
+    int last_ws = 0;                        // 1: the last run used a caller-owned workspace, 2: plan-owned (afhip_plan_describe tells)
+    // experiment knobs, read once when the plan is created (never on the run path)
+    bool no_slot_spmm = false, no_slots_divide = false, no_counts_divide = false;
+    int slot_spmm_sub = 0, slot_spmm_order = -1;      // AFHIP_SLOT_SPMM_ORDER=v|p: SlotSpmmArgs::p_major forced off / on
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
     std::vector<hipEvent_t> prof_ev;
     int64_t prof_count = 0;
     ~afhip_plan() {      // run with `device` current (afhip_plan_destroy): the members below free their buffers after this body
         if (own_ws) (void)hipFree(own_ws);
-        if (sums) (void)hipFree(sums);
+        for (void* q : retired) (void)hipFree(q);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : prof_ev) if (e) (void)hipEventDestroy(e);
     }
@@ -341,6 +342,16 @@ struct afhip_plan {
 // ---------------------------------------------------------------------------------------
 extern "C" const char* afhip_last_error(void) { return g_err.c_str(); }
 extern "C" int afhip_abi_version(void) { return AFHIP_ABI_VERSION; }
+
+extern "C" int afhip_build_info(char* buf, int buf_len) {
+    int n = 0, arms = 0, rf = 0;
+    const Variant* tab = variants_table(&n);
+    for (int i = 0; i < n; ++i) { arms += tab[i].production ? 0 : 1; rf += tab[i].rf ? 1 : 0; }
+    char tmp[160];
+    const int len = snprintf(tmp, sizeof tmp, "menu=%s variants=%d arms=%d region_fused_twins=%d abi=%d", variants_menu(), n, arms, rf, AFHIP_ABI_VERSION);
+    if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
+    return len + 1;
+}
 
 extern "C" int afhip_device_count(void) {
     int n = 0;
@@ -438,8 +449,7 @@ extern "C" int afhip_csr_device(const afhip_csr* csr) { return csr ? csr->device
 static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
 static bool spmm_serial_env() { static const bool v = env_flag("AFHIP_SPMM_SERIAL") || env_flag("AGGFLY_HIP_EXACT_ORDER"); return v; }
 
-// rows of the sums buffer a spatial stage needs: the regions + the scratch rows of cut regions
-static int64_t spmm_rows(const afhip_csr* csr) { return csr->R + csr->n_extra; }
+static int64_t spmm_rows(const afhip_csr* csr);
 
 // out[r][q] = sum_j w[j] * X[col[j]][q] for every region r (rows [0, R) of `out`, which holds spmm_rows(csr) x Q doubles).
 //   exact:  one thread per (r, q) walks the whole row in table order — bit-identical to np.add.at (spatial.py:185);
@@ -568,6 +578,38 @@ extern "C" int afhip_panel_divide(const double* num_dev, const double* den_dev, 
     hipLaunchKernelGGL(k_divide_num_den, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, num_dev, den_dev, res_dev, n, R * P);
     HIP_TRY(hipGetLastError());
     return AFHIP_OK;
+}
+
+// The box's streaming-read ceiling for a time-major cube: `launches` back-to-back launches of k_read_probe over [T][row_bytes],
+// HIP events around each, one synchronisation at the end.
+extern "C" int afhip_read_probe(const void* cube_dev, int64_t T, int64_t row_bytes, int launches, float* ms_out, void* stream) {
+    if (!cube_dev || !ms_out || T <= 0 || row_bytes <= 0 || row_bytes % 8 != 0 || launches <= 0 || launches > 1000)
+        return fail(AFHIP_E_INVALID, "read_probe: NULL argument, rows that are not multiples of 8 bytes, or a launch count outside 1..1000");
+    const int64_t lanes = row_bytes / 8, blocks = (lanes + 63) / 64;
+    if (blocks > 0x7fffffff) return fail(AFHIP_E_INVALID, "read_probe: rows too long for one launch");
+    GUARD_DEVICE(pointer_device(cube_dev));
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&out, (size_t)lanes * sizeof(uint32_t)));
+    std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
+    int rc = AFHIP_OK;
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { rc = fail(AFHIP_E_HIP, "read_probe: hipEventCreate failed"); break; }
+    if (!rc) {
+        (void)hipEventRecord(ev[0], st);
+        for (int i = 0; i < launches; ++i) {
+            hipLaunchKernelGGL(k_read_probe, dim3((unsigned)blocks), dim3(64), 0, st, (const uint32_t*)cube_dev, row_bytes / 4, T, out);
+            (void)hipEventRecord(ev[(size_t)i + 1], st);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventSynchronize(ev[(size_t)launches]);
+        if (e != hipSuccess) rc = fail(AFHIP_E_HIP, "read_probe: %s", hipGetErrorString(e));
+        for (int i = 0; !rc && i < launches; ++i)
+            if (hipEventElapsedTime(&ms_out[i], ev[(size_t)i], ev[(size_t)i + 1]) != hipSuccess) rc = fail(AFHIP_E_HIP, "read_probe: event query failed");
+    }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(out);
+    return rc;
 }
 
 extern "C" int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, double arg,
@@ -724,6 +766,20 @@ static int lower_columns(afhip_plan* pl) {
     pl->nthr = (int)pl->thr.size();
     pl->K = K;
     return AFHIP_OK;
+}
+
+// the variant with the region-fused period ends compiled in and every other field equal (null: the menu has none)
+static const Variant* twin_of(const Variant* v) {
+    int n = 0;
+    const Variant* tab = variants_table(&n);
+    for (int i = 0; i < n; ++i) {
+        const Variant& t = tab[i];
+        if (t.rf && t.dtype == v->dtype && t.pipe == v->pipe && t.vec == v->vec && t.stat == v->stat && t.nthr == v->nthr && t.kmax == v->kmax &&
+            t.depth == v->depth && t.nt == v->nt && t.tki == v->tki && t.sl == v->sl && t.hb == v->hb && t.ha == v->ha && t.pair == v->pair &&
+            t.ss == v->ss && t.quad == v->quad)
+            return &t;
+    }
+    return nullptr;
 }
 
 // Chunking.  target_len = time steps a workgroup should stream; a long period is cut on
@@ -959,17 +1015,18 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // ... and the same for groups of exactly four rows (6-hourly data), in the lean form only (FEAT bit 10)
     int glen = 0;
     if (desc->G1 > 0 && pl->nthr == 0 && (pl->stat == 1 || pl->stat == 2) && !getenv("AFHIP_NO_PAIR_MODE")) {
-        for (int L : {2, 4}) {
+        for (int L : {2, 3, 4}) {
             bool all = desc->T == (int64_t)L * desc->G1;
             for (int64_t g = 0; all && g < desc->G1; ++g) all = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == L;
             if (all) glen = L;
         }
     }
-    if (glen == 4 && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
+    if ((glen == 4 || glen == 3) && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
     // (its loads address a row by a 32-bit byte offset per lane: rows of 4 GiB and more take the general path)
     if ((uint64_t)desc->n_cells * (desc->dtype == AFHIP_F64 ? 8u : 4u) >= (1ull << 32)) glen = 0;
-    bool pairs = glen == 2 || glen == 4;                 // short-group mode (two- or four-row groups)
-    const bool quad_len = glen == 4;
+    bool pairs = glen >= 2;                              // short-group mode (two-, three- or four-row groups)
+    const bool quad_len = glen >= 3;                     // three / four rows: the lean form only, general sine closed forms
+    const int glcode = glen == 4 ? 1 : (glen == 3 ? 2 : 0);      // Variant::quad
     // pair plans whose columns are all  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  without float32 rounding
     // take the lean group end (FEAT bit 8); when every column is a plain sine_dd, its tightest form (FEAT bit 9).  A sine_dd
     // column there needs s0 < s1: its two max() terms are one clamp of width s1 - s0.
@@ -982,7 +1039,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     }
     lean_sine = lean_sine && lean;
     // four-row groups exist in the lean form only, for as many columns as its variants hold
-    if (quad_len && !(lean && find_variant(desc->dtype, 0, pl->stat, 0, pl->K, 0, 0, false, false, false, false, false, 1, 0, true)))
+    if (quad_len && !(lean && find_variant(desc->dtype, 0, pl->stat, 0, pl->K, 0, 0, false, false, false, false, false, 1, 0, glcode)))
         pairs = lean = false;
     // mean / sum columns alone (no min, max or sine): the pair path exists in the lean form only, and a light plan (one or two
     // columns) streams faster through the LDS-DMA ring, whose prefetch runs across the two-row groups (5.99 vs 5.44 TB/s on
@@ -1106,8 +1163,9 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         (C_ + (int64_t)WG * 2 - 1) / ((int64_t)WG * 2) >= (int64_t)cu_count(pl->device))
         depth_hint = 4;
     if (const char* e = getenv("AFHIP_DEPTH_HINT")) depth_hint = atoi(e);      // experiment knob
-    const bool quads = pairs && quad_len, twos = pairs && !quad_len;
-    if (quads) depth_hint = 8;                           // two groups per block
+    const int quads = (pairs && quad_len) ? glcode : 0;
+    const bool twos = pairs && !quad_len;
+    if (quads) depth_hint = glen == 3 ? 6 : 8;           // two groups per block
     const int lean_code = lean ? (lean_sine ? 2 : 1) : 0;
     const Variant* v = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, tuning, want_vec, all_bins, single_level, partition, arith, twos, lean_code, depth_hint, quads);
     if (!v && tuning > 0)   // a tuning arm is a hint: arms are compiled for the headline plan shapes only
@@ -1117,6 +1175,15 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
         delete pl;
         return fail(AFHIP_E_UNSUPPORTED, "no kernel variant for dtype=%d stat=%d slots=%d columns=%d", desc->dtype, pl->stat, pl->nthr, pl->K);
     }
+    // A single-level plan takes an `sl` variant when the menu has one (no outer accumulators: cheaper) — but those have no region-fused
+    // twin, and a plan that stores one value per group, column and cell (a daily panel of several degree-day columns) then writes and
+    // re-reads period values worth a sizeable share of the cube.  From 5 % on the general two-level variant (outer = first) with its twin
+    // is taken instead; packed bin counts (16-byte records, gathered directly) stay where they are.
+    if (v->sl && !v->tki && tuning == 0 && !desc->exact_order && !getenv("AFHIP_NO_REGION_FUSED") &&
+        (double)desc->P * pl->K * 8.0 >= 0.05 * (double)desc->T * (desc->dtype == AFHIP_F32 ? 4.0 : 8.0)) {
+        const Variant* v2 = find_variant(desc->dtype, want_pipe, pl->stat, pl->nthr, pl->K, 0, want_vec, false, false, false, false, twos, lean_code, depth_hint, quads);
+        if (v2 && v2->pipe == 0 && !v2->tki && !v2->hb && twin_of(v2)) v = v2;
+    }
     pl->variant = v;
     if ((rc = build_chunks(pl, v->vec))) { delete pl; return rc; }
     // Region-fused period ends (FusedArgs::rf_w): the twin variant, if the menu has one, and what the plan itself must satisfy —
@@ -1124,31 +1191,31 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // the accumulator; an outer mean's division by the period's group count is applied to the region sums, k_rf_reduce), at most one slot per period (shared validity needs the whole period's value), several periods
     // (with one the stores sit at the kernel's end and cost nothing: the headline stays on the route it was measured on).
     {
-        int n = 0;
-        const Variant* tab = variants_table(&n);
-        for (int i = 0; i < n && !pl->variant_rf; ++i) {
-            const Variant& t = tab[i];
-            if (t.rf && t.dtype == v->dtype && t.pipe == v->pipe && t.vec == v->vec && t.stat == v->stat && t.nthr == v->nthr && t.kmax == v->kmax &&
-                t.depth == v->depth && t.nt == v->nt && t.tki == v->tki && t.sl == v->sl && t.hb == v->hb && t.ha == v->ha && t.pair == v->pair &&
-                t.ss == v->ss && t.quad == v->quad)
-                pl->variant_rf = &t;
-        }
-        bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && pl->K <= 6 && !getenv("AFHIP_NO_REGION_FUSED");
+        pl->variant_rf = twin_of(v);
+        bool ok = pl->variant_rf != nullptr && !desc->exact_order && desc->P >= 2 && !getenv("AFHIP_NO_REGION_FUSED");
         for (const ColOp& c : pl->cols) ok = ok && !(c.rounding & AFHIP_ROUND_FINAL);      // (identity outers too: a daily panel of daily means)
         for (int64_t p = 0; ok && p < desc->P; ++p) ok = pl->slot_ptr[(size_t)p + 1] - pl->slot_ptr[(size_t)p] <= 1;
         // ... and per-cell period values that would be a noticeable share of the traffic: P K 8 bytes per cell against T elem.  Below
         // ~0.2 % there is nothing to win and the emit still costs: configs[2]'s shape (40 annual values of 2 columns from 350,640
         // hourly steps: 0.05 %) measured 0.25 % behind, the one-period headline (0.06 %) 0.6 %; the shapes that gain sit at 0.5 % and up.
-        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED"))
-            ok = (double)desc->P * pl->K * 8.0 >= 0.002 * (double)desc->T * (desc->dtype == AFHIP_F32 ? 4.0 : 8.0);
-        // Which forms gain was measured, not derived (profiles/r03_region_fused.txt; an occupancy rule could not tell them apart: the
-        // float32 polynomial wins at 5 of 7 resident workgroups, monthly sine_dd on pairs loses at the same ratio): float64 forms and
-        // float32 forms without threshold slots gain 3 - 50 % from two periods on; float32 with a threshold slot (the configs[1] plan
-        // on float32 storage) is level at 12 periods and ahead from ~24 (whole step -2.5 % at 24, -14 % at 52, -19 % at 73, -33 % at
-        // 365).  Of the short-group forms the lean four-row ones and the six-column lean pair form have twins (6-hourly monthly
-        // polynomial: step 0.97 against 1.13 - 1.33 ms; polynomial of the daily mean of (tmin, tmax) pairs 4.75 against 5.12); the
-        // sine-only pair form (monthly sine_dd: 4.45 against 4.26) and the one- / two-column pair forms have none.
-        if (ok && !getenv("AFHIP_FORCE_REGION_FUSED")) ok = desc->dtype == AFHIP_F64 || pl->nthr == 0 || desc->P >= 24;
+        const double share = (double)desc->P * pl->K * 8.0 / std::max(1.0, (double)desc->T * (desc->dtype == AFHIP_F32 ? 4.0 : 8.0));
+        const bool forced = getenv("AFHIP_FORCE_REGION_FUSED") != nullptr;
+        if (ok && !forced) ok = share >= 0.002;
+        // Which forms gain was measured, not derived (profiles/r03_region_fused.txt: an occupancy rule could not tell them apart): float64
+        // forms and float32 forms without threshold slots gain 3 - 50 % from two periods on; the lean four-row forms and the six-column
+        // lean pair form likewise (6-hourly monthly polynomial: step 0.97 against 1.13 - 1.33 ms).
+        // Round 4 (the scan form of the period end; twins for threshold-only plans and every short-group form; profiles/r04_region_fused_scan.txt):
+        // the float32-with-a-threshold-slot forms are level from 12 periods and ahead from there, a degree-day column alone gains 6 % at
+        // 12 and 52 periods and 22-25 % on a daily panel — one rule for all of them: period values of 0.2 % of the cube and more.  The
+        // two-row forms other than the six-column lean one (sine_dd from (tmin, tmax) pairs: a period end every few rows) pay only where
+        // the per-cell route's own traffic decides: monthly 4.44 against 3.77 ms (behind), weekly 5.80 against 6.20, daily 17.7 against
+        // 21.5 — from period values of 5 % of the cube.
+        const bool two_row_light = v->pair && !v->quad && !(v->ss == 1 && v->kmax == 6);
+        if (ok && !forced && two_row_light) {
+            double min_share = 0.05;
+            if (const char* e = getenv("AFHIP_RF_MIN_SHARE")) min_share = atof(e);      // experiment knob
+            ok = share >= min_share;
+        }
         pl->rf_plan_ok = ok;
     }
 
@@ -1173,6 +1240,11 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // experiment knobs, read once per plan (never on the run path)
     if (const char* e = getenv("AFHIP_XCD_REMAP")) pl->xcd_remap = atoi(e) ? 1 : 0;
     pl->counts_spmm = !getenv("AFHIP_NO_COUNTS_SPMM");
+    pl->no_slot_spmm = env_flag("AFHIP_NO_SLOT_SPMM");            // keep k_combine_slots + k_csr_spmm on every route
+    pl->no_slots_divide = getenv("AFHIP_NO_SLOTS_DIVIDE") != nullptr;
+    pl->no_counts_divide = getenv("AFHIP_NO_COUNTS_DIVIDE") != nullptr;
+    if (const char* e = getenv("AFHIP_SLOT_SPMM_ORDER")) pl->slot_spmm_order = (e[0] == 'p') ? 1 : 0;
+    if (const char* e = getenv("AFHIP_SLOT_SPMM_SUB")) { const int sb = atoi(e); if (sb == 8 || sb == 16 || sb == 32 || sb == 64) pl->slot_spmm_sub = sb; }
     pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
     for (const ColOp& c : pl->cols)
         pl->packed = pl->packed && c.src == SRC_THR && c.tf == TF_NONE && c.rounding == 0 && c.outer == OUT_FIRST;
@@ -1205,10 +1277,24 @@ extern "C" void afhip_plan_destroy(afhip_plan* plan) {
 
 extern "C" int afhip_plan_device(const afhip_plan* plan) { return plan ? plan->device : -1; }
 
+// A plan's tables and scratch live on plan->device: a cube (or a second cube, an output, a workspace) on another card would be
+// read or written across xGMI at best and, with peer access off, fault.  Refuse it before anything is launched (pointers the
+// runtime cannot classify are let through).
+static int check_ptr_device(const afhip_plan* pl, const void* ptr_dev, const char* who, const char* what) {
+    const int dev = pointer_device(ptr_dev);
+    if (dev >= 0 && dev != pl->device)
+        return fail(AFHIP_E_INVALID, "%s: %s lives on device %d but the plan was created on device %d "
+                    "(create the plan with the data's device current)", who, what, dev, pl->device);
+    return AFHIP_OK;
+}
+static int check_cube_device(const afhip_plan* pl, const void* cube_dev, const char* who) { return check_ptr_device(pl, cube_dev, who, "the cube"); }
+
 extern "C" int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* inter_dev, int dtype) {
     if (!plan || column < 0 || column >= plan->K) return fail(AFHIP_E_INVALID, "plan_bind_inter: no such column");
     if (plan->cols[(size_t)column].tf != TF_INTER) return fail(AFHIP_E_INVALID, "plan_bind_inter: column %d has no inter transform", column);
     if (!inter_dev || (dtype != AFHIP_F32 && dtype != AFHIP_F64)) return fail(AFHIP_E_INVALID, "plan_bind_inter: NULL array or bad dtype");
+    int rcd = check_ptr_device(plan, inter_dev, "plan_bind_inter", "the second cube");
+    if (rcd) return rcd;
     plan->cols[(size_t)column].inter = inter_dev;
     plan->cols[(size_t)column].inter_f32 = dtype == AFHIP_F32 ? 1 : 0;
     return AFHIP_OK;
@@ -1216,7 +1302,19 @@ extern "C" int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* i
 
 extern "C" int64_t afhip_plan_workspace_bytes(const afhip_plan* plan) {
     if (!plan) return 0;
-    return plan->ws_partial + plan->ws_panel;
+    return plan->ws_partial;
+}
+
+// rows of the sums buffer a spatial stage needs: the regions + the scratch rows of cut regions
+static int64_t spmm_rows(const afhip_csr* csr) { return csr->R + csr->n_extra; }
+static int64_t sums_bytes_of(const afhip_plan* plan, const afhip_csr* csr) {
+    const int64_t Q = (int64_t)(plan->K + 1) * plan->desc.P;
+    return (std::max<int64_t>(spmm_rows(csr) * Q, 1) * 8 + 255) / 256 * 256;
+}
+
+extern "C" int64_t afhip_plan_run_workspace_bytes(const afhip_plan* plan, const afhip_csr* csr) {
+    if (!plan || !csr) return 0;
+    return plan->ws_partial + plan->ws_panel + sums_bytes_of(plan, csr);
 }
 
 extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_len) {
@@ -1226,26 +1324,17 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     char tmp[1024];
     int n = snprintf(tmp, sizeof tmp,
                      "variant=%s pipe=%d vec=%d stat=%d slots=%d kmax=%d depth=%d | T=%lld cells=%lld K=%d G1=%lld P=%lld | "
-                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld%s | workspace=%.1f MiB",
+                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld%s | workspace=%.1f MiB%s",
                      plan->variant->name, plan->variant->pipe, plan->variant->vec, plan->variant->stat, plan->variant->nthr,
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
                      plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
                      plan->packed ? (plan->pk.nw == 2 ? " packed-counts16" : " packed-counts32")
                                   : (plan->last_route == 1 ? " last-run=region-fused" : (plan->rf_plan_ok ? " region-fused-capable" : "")),
-                     (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0));
+                     (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0),
+                     plan->last_ws == 1 ? " (caller-owned)" : (plan->last_ws == 2 ? " (plan-owned hipMalloc)" : ""));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
     return n + 1;
-}
-
-// A plan's tables and scratch live on plan->device: a cube on another card would be read across xGMI at best and, with peer
-// access off, fault.  Refuse it before anything is launched (pointers the runtime cannot classify are let through).
-static int check_cube_device(const afhip_plan* pl, const void* cube_dev, const char* who) {
-    const int dev = pointer_device(cube_dev);
-    if (dev >= 0 && dev != pl->device)
-        return fail(AFHIP_E_INVALID, "%s: the cube lives on device %d but the plan was created on device %d "
-                    "(create the plan with the cube's device current)", who, dev, pl->device);
-    return AFHIP_OK;
 }
 
 static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st, const afhip_csr::RfTab* rf = nullptr) {
@@ -1282,14 +1371,11 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     void* args[] = {&fa};
     size_t lds = plan_lds_bytes(pl);
     const void* fn = pl->variant->fn;
-    if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area, a staging block per wave behind the other LDS
+    if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area (no LDS of its own)
         fn = pl->variant_rf->fn;
-        lds = (lds + 15) / 16 * 16;
-        fa.rf_w = rf->w2.p; fa.rf_tile = rf->tile.p; fa.rf_run = rf->run.p; fa.rf_out = partial; fa.rf_nruns = rf->n_runs;
+        fa.rf_w = rf->w2.p; fa.rf_key = rf->key.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial; fa.rf_nruns = rf->n_runs;
         fa.rf_x = rf->n_xcells ? rf->xidx.p : nullptr; fa.rf_nx = rf->n_xcells;
         fa.rf_ex = partial + pl->n_slots * rf->n_runs * (pl->K + 1);           // behind the run sums
-        fa.rf_lds_off = (int32_t)lds;
-        lds += (size_t)(pl->wg / 64) * 64 * pl->variant->vec * (size_t)(pl->K + 3) * sizeof(double);
     }
     if (pl->variant->hb) {
         fa.hb_n = pl->hb_n; fa.hb_c1 = pl->hb_c1; fa.hb_c0 = pl->hb_c0;
@@ -1334,9 +1420,6 @@ static int launch_combine(afhip_plan* pl, const double* partial, double* cells, 
     return AFHIP_OK;
 }
 
-// AFHIP_NO_SLOT_SPMM=1 (experiment / test knob, read per run): keep k_combine_slots + k_csr_spmm on every route.
-static bool slot_spmm_off() { return env_flag("AFHIP_NO_SLOT_SPMM"); }
-
 // sums[row][p][K + 1] straight from partial (k_csr_spmm_slots): slot merge, shared validity and the weighted sums of every
 // (segment, period) in one pass; then the pieces of cut rows.  The lanes per (segment, period) follow the table's mean
 // segment length — 64 for county-sized rows on a fine grid (and then bit-identical to combine + k_csr_spmm_wave), 8 for
@@ -1349,8 +1432,9 @@ static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double*
     sa.seg_ptr = csr->seg_ptr.p; sa.dst = csr->seg_dst.p; sa.cols = csr->cols.p; sa.w = csr->w.p;
     sa.partial = partial; sa.slot_ptr = pl->d_slot_ptr.p; sa.outer_bounds = pl->d_ob.p; sa.out = pl->sums;
     sa.nseg = csr->nseg; sa.P = P; sa.C = pl->desc.n_cells; sa.K = (int32_t)K;
+    sa.p_major = pl->slot_spmm_order >= 0 ? pl->slot_spmm_order : (P >= 8 ? 1 : 0);
     // no row of the table is cut: a segment IS a region, and the lane that holds its K + 1 sums finishes the panel (no divide kernel)
-    *divided = csr->n_split == 0 && csr->nseg == csr->R && !getenv("AFHIP_NO_SLOTS_DIVIDE");
+    *divided = csr->n_split == 0 && csr->nseg == csr->R && !pl->no_slots_divide;
     if (*divided) { sa.num = num_dev; sa.den = den_dev; sa.res = res_dev; sa.R = csr->R; }
     for (int j = 0; j < pl->K; ++j) {
         sa.outer[j] = pl->cols[(size_t)j].outer;
@@ -1358,7 +1442,7 @@ static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double*
     }
     const int64_t mean_len = csr->nnz / std::max<int64_t>(csr->nseg, 1);
     int sub = mean_len > 32 ? 64 : (mean_len > 16 ? 32 : (mean_len > 8 ? 16 : 8));
-    if (const char* e = getenv("AFHIP_SLOT_SPMM_SUB")) { const int s = atoi(e); if (s == 8 || s == 16 || s == 32 || s == 64) sub = s; }
+    if (pl->slot_spmm_sub) sub = pl->slot_spmm_sub;
     const int64_t pairs = csr->nseg * P;
     const int64_t blocks = (pairs * sub + WG - 1) / WG;
     if (blocks > INT32_MAX) return fail(AFHIP_E_UNSUPPORTED, "plan_run: %lld (segment, period) pairs in one call", (long long)pairs);
@@ -1384,26 +1468,41 @@ static int launch_spmm_slots(afhip_plan* pl, const afhip_csr* csr, const double*
     return AFHIP_OK;
 }
 
-static int ensure_ws(afhip_plan* pl, int64_t bytes, void* user_ws, char** base) {
-    if (user_ws) { *base = (char*)user_ws; return AFHIP_OK; }
+// The scratch of a run: the caller's block when given (checked for size, alignment and device: nothing below allocates, frees
+// or synchronises then), else the plan's own, grown at need — the outgrown block is kept until afhip_plan_destroy, because
+// kernels of an earlier run on another stream may still read it and a hipFree would wait for the whole device.
+static int ensure_ws(afhip_plan* pl, int64_t bytes, void* user_ws, int64_t user_bytes, const char* who, char** base) {
+    if (user_ws) {
+        if (user_bytes < bytes)
+            return fail(AFHIP_E_INVALID, "%s: the workspace holds %lld bytes, the run needs %lld (afhip_plan_run_workspace_bytes / afhip_plan_workspace_bytes)",
+                        who, (long long)user_bytes, (long long)bytes);
+        if ((uintptr_t)user_ws % 256 != 0) return fail(AFHIP_E_INVALID, "%s: the workspace must be 256-byte aligned", who);
+        int rc = check_ptr_device(pl, user_ws, who, "the workspace");
+        if (rc) return rc;
+        *base = (char*)user_ws;
+        pl->last_ws = 1;
+        return AFHIP_OK;
+    }
     if (pl->own_ws_bytes < bytes) {
-        if (pl->own_ws) { HIP_TRY(hipFree(pl->own_ws)); pl->own_ws = nullptr; pl->own_ws_bytes = 0; }
+        if (pl->own_ws) { pl->retired.push_back(pl->own_ws); pl->own_ws = nullptr; pl->own_ws_bytes = 0; }
         HIP_TRY(hipMalloc(&pl->own_ws, (size_t)bytes));
         pl->own_ws_bytes = bytes;
     }
     *base = (char*)pl->own_ws;
+    pl->last_ws = 2;
     return AFHIP_OK;
 }
 
 extern "C" int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cells_dev,
-                                       void* workspace_dev, void* stream) {
+                                       void* workspace_dev, int64_t workspace_bytes, void* stream) {
     if (!plan || !cube_dev || !cells_dev) return fail(AFHIP_E_INVALID, "plan_run_temporal: NULL argument");
     int rcd = check_cube_device(plan, cube_dev, "plan_run_temporal");
+    if (!rcd) rcd = check_ptr_device(plan, cells_dev, "plan_run_temporal", "the per-cell output");
     if (rcd) return rcd;
     GUARD_DEVICE(plan->device);
     hipStream_t st = (hipStream_t)stream;
     char* base;
-    int rc = ensure_ws(plan, plan->ws_partial, workspace_dev, &base);
+    int rc = ensure_ws(plan, plan->ws_partial, workspace_dev, workspace_bytes, "plan_run_temporal", &base);
     if (rc) return rc;
     double* partial = (double*)base;
     if ((rc = launch_temporal(plan, cube_dev, partial, st))) return rc;
@@ -1412,30 +1511,28 @@ extern "C" int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, d
 
 extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhip_csr* csr,
                               double* num_dev, double* den_dev, double* res_dev, double* cells_dev,
-                              void* workspace_dev, void* stream, float* kernel_ms) {
+                              void* workspace_dev, int64_t workspace_bytes, void* stream, float* kernel_ms) {
     if (!plan || !cube_dev || !csr || !res_dev) return fail(AFHIP_E_INVALID, "plan_run: NULL argument");
     if (csr->n_cells != plan->desc.n_cells)
         return fail(AFHIP_E_INVALID, "plan_run: CSR has %lld cells, plan has %lld", (long long)csr->n_cells, (long long)plan->desc.n_cells);
     if (csr->device != plan->device)
         return fail(AFHIP_E_INVALID, "plan_run: the CSR lives on device %d, the plan on device %d", csr->device, plan->device);
     int rcd = check_cube_device(plan, cube_dev, "plan_run");
+    if (!rcd) rcd = check_ptr_device(plan, res_dev, "plan_run", "the result panel");
+    if (!rcd && num_dev) rcd = check_ptr_device(plan, num_dev, "plan_run", "the numerator panel");
+    if (!rcd && den_dev) rcd = check_ptr_device(plan, den_dev, "plan_run", "the denominator panel");
+    if (!rcd && cells_dev) rcd = check_ptr_device(plan, cells_dev, "plan_run", "the per-cell output");
     if (rcd) return rcd;
     GUARD_DEVICE(plan->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = plan->K, P = plan->desc.P, Q = (K + 1) * P;
-    // partial + panel live in the caller's workspace when given; the small [R][Q] sums
-    // buffer is always plan-owned (its size depends on the CSR, not on the plan)
-    const int64_t sums_bytes = (std::max<int64_t>(spmm_rows(csr) * Q, 1) * 8 + 255) / 256 * 256;
-    if (plan->sums_bytes < sums_bytes) {
-        if (plan->sums) { HIP_TRY(hipFree(plan->sums)); plan->sums = nullptr; plan->sums_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&plan->sums, (size_t)sums_bytes));
-        plan->sums_bytes = sums_bytes;
-    }
+    // partial | panel | sums[rows][Q] in one block: the caller's workspace when given, else the plan's own
     char* base;
-    int rc = ensure_ws(plan, plan->ws_partial + plan->ws_panel, workspace_dev, &base);
+    int rc = ensure_ws(plan, afhip_plan_run_workspace_bytes(plan, csr), workspace_dev, workspace_bytes, "plan_run", &base);
     if (rc) return rc;
     double* partial = (double*)base;
     double* panel = (double*)(base + plan->ws_partial);
+    plan->sums = (double*)(base + plan->ws_partial + plan->ws_panel);
     if (kernel_ms) {
         for (auto& e : plan->ev) if (!e) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventRecord(plan->ev[0], st));
@@ -1447,7 +1544,6 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if (plan->rf_plan_ok && !exact && !cells_dev && !plan->packed) {
         rf = rf_table(const_cast<afhip_csr*>(csr), plan->variant->vec);
         if (rf && plan->n_slots * (rf->n_runs + rf->n_xcells) * (K + 1) * 8 > plan->ws_partial) rf = nullptr;
-        if (rf && 64 * (size_t)plan->variant->vec * (size_t)(K + 3) * 8 * (size_t)(plan->wg / 64) + plan_lds_bytes(plan) > 64 * 1024) rf = nullptr;
     }
     const bool prof = !plan->prof_ev.empty() && (size_t)(2 * plan->prof_count + 1) < plan->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count)], st));
@@ -1473,7 +1569,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         const int64_t nv = exact ? csr->R : csr->nseg, nq = nv * P;
         if (nq) {
             // rows that are never cut (exact order, or a table without long rows): the gather finishes the panel itself, no divide kernel
-            divided = (exact || csr->n_split == 0) && nv == csr->R && !getenv("AFHIP_NO_COUNTS_DIVIDE");
+            divided = (exact || csr->n_split == 0) && nv == csr->R && !plan->no_counts_divide;
             hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st,
                                exact ? csr->indptr.p : csr->seg_ptr.p, exact ? (const int32_t*)nullptr : csr->seg_dst.p, csr->cols.p,
                                csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk,
@@ -1486,7 +1582,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
                 HIP_TRY(hipGetLastError());
             }
         }
-    } else if (!exact && !cells_dev && !plan->packed && K > 0 && !slot_spmm_off()) {
+    } else if (!exact && !cells_dev && !plan->packed && K > 0 && !plan->no_slot_spmm) {
         // no per-cell output wanted, no table-order promise: the weighted sums gather the slots directly (no panel)
         if ((rc = launch_spmm_slots(plan, csr, partial, st, num_dev, den_dev, res_dev, &divided))) return rc;
     } else {
@@ -1543,42 +1639,44 @@ static int run_group(const void* cube_dev, int dtype, int64_t T, int64_t n_cells
     if (!cube_dev || !bounds || !out_dev) return fail(AFHIP_E_INVALID, "group kernel: NULL argument");
     if (G < 0 || D <= 0) return fail(AFHIP_E_INVALID, "group kernel: bad G/D");
     if (G == 0) return AFHIP_OK;
-    GUARD_DEVICE(pointer_device(cube_dev));          // the temporary plan is created, run and freed on the cube's device
+    GUARD_DEVICE(pointer_device(cube_dev));          // the temporary plans are created, run and freed on the cube's device
     hipStream_t st = (hipStream_t)stream;
-    // D can exceed one pass's slot/column budget: run passes of <= MAX_COLS columns
-    const int64_t per_pass = std::min<int64_t>(MAX_COLS, MAX_THR);
     std::vector<int64_t> ob((size_t)G + 1);
     for (int64_t g = 0; g <= G; ++g) ob[(size_t)g] = g;
-    if (D > per_pass && D > 1)
-        return fail(AFHIP_E_UNSUPPORTED, "group kernel: D=%lld thresholds exceed %lld per call; split the ddargs", (long long)D, (long long)per_pass);
-    std::vector<afhip_column> cols((size_t)D);
-    for (int64_t d = 0; d < D; ++d) {
-        afhip_column c{};
-        c.inner = code; c.transform = AFHIP_TF_NONE; c.outer = AFHIP_IDENTITY;
-        if (ddargs) { c.inner_args[0] = ddargs[d * 3]; c.inner_args[1] = ddargs[d * 3 + 1]; c.inner_args[2] = ddargs[d * 3 + 2]; }
-        cols[(size_t)d] = c;
+    // D can exceed one pass's slot / column budget (the reference loops over any number of ddargs rows, nb_kernels.py:166,190,215):
+    // passes of <= per_pass columns, each writing its own columns [d0, d0 + n) of out[G][cell][D]
+    const int64_t per_pass = std::min<int64_t>(MAX_COLS, MAX_THR);
+    for (int64_t d0 = 0; d0 < D; d0 += per_pass) {
+        const int64_t n = std::min(per_pass, D - d0);
+        std::vector<afhip_column> cols((size_t)n);
+        for (int64_t d = 0; d < n; ++d) {
+            afhip_column c{};
+            c.inner = code; c.transform = AFHIP_TF_NONE; c.outer = AFHIP_IDENTITY;
+            if (ddargs) { c.inner_args[0] = ddargs[(d0 + d) * 3]; c.inner_args[1] = ddargs[(d0 + d) * 3 + 1]; c.inner_args[2] = ddargs[(d0 + d) * 3 + 2]; }
+            cols[(size_t)d] = c;
+        }
+        afhip_plan_desc desc{};
+        desc.T = T; desc.n_cells = n_cells; desc.dtype = dtype; desc.K = (int32_t)n; desc.G1 = G;
+        desc.inner_bounds = bounds; desc.P = G; desc.outer_bounds = ob.data(); desc.columns = cols.data();
+        afhip_plan* pl = nullptr;
+        int rc = afhip_plan_create(&desc, &pl);
+        if (rc) return rc;
+        char* base;
+        if ((rc = ensure_ws(pl, pl->ws_partial, nullptr, 0, "group kernel", &base))) { delete pl; return rc; }
+        double* partial = (double*)base;
+        if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
+        dim3 grid((unsigned)((n_cells + WG - 1) / WG), (unsigned)std::min<int64_t>(G, 65535));
+        if (dtype == AFHIP_F32)
+            hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)n, (int)D, (int)d0, pl->packed ? pl->pk : PackFmt{});
+        else
+            hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)n, (int)D, (int)d0, pl->packed ? pl->pk : PackFmt{});
+        hipError_t e = hipGetLastError();
+        // the plan owns the scratch the kernels are still reading: drain before freeing it
+        hipError_t e2 = hipStreamSynchronize(st);
+        delete pl;
+        if (e != hipSuccess) return fail(AFHIP_E_HIP, "k_slots_to_block launch failed: %s", hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(AFHIP_E_HIP, "stream synchronize failed: %s", hipGetErrorString(e2));
     }
-    afhip_plan_desc desc{};
-    desc.T = T; desc.n_cells = n_cells; desc.dtype = dtype; desc.K = (int32_t)D; desc.G1 = G;
-    desc.inner_bounds = bounds; desc.P = G; desc.outer_bounds = ob.data(); desc.columns = cols.data();
-    afhip_plan* pl = nullptr;
-    int rc = afhip_plan_create(&desc, &pl);
-    if (rc) return rc;
-    char* base;
-    if ((rc = ensure_ws(pl, pl->ws_partial, nullptr, &base))) { delete pl; return rc; }
-    double* partial = (double*)base;
-    if ((rc = launch_temporal(pl, cube_dev, partial, st))) { delete pl; return rc; }
-    dim3 grid((unsigned)((n_cells + WG - 1) / WG), (unsigned)std::min<int64_t>(G, 65535));
-    if (dtype == AFHIP_F32)
-        hipLaunchKernelGGL(k_slots_to_block<float>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (float*)out_dev, n_cells, G, (int)D, pl->packed ? pl->pk : PackFmt{});
-    else
-        hipLaunchKernelGGL(k_slots_to_block<double>, grid, dim3(WG), 0, st, partial, pl->d_slot_ptr.p, (double*)out_dev, n_cells, G, (int)D, pl->packed ? pl->pk : PackFmt{});
-    hipError_t e = hipGetLastError();
-    // the plan owns the scratch the kernels are still reading: drain before freeing it
-    hipError_t e2 = hipStreamSynchronize(st);
-    delete pl;
-    if (e != hipSuccess) return fail(AFHIP_E_HIP, "k_slots_to_block launch failed: %s", hipGetErrorString(e));
-    if (e2 != hipSuccess) return fail(AFHIP_E_HIP, "stream synchronize failed: %s", hipGetErrorString(e2));
     return AFHIP_OK;
 }
 

@@ -132,14 +132,13 @@ struct FusedArgs {
     uint32_t ccode[MAX_COLS];
     // Region-fused period ends (rf_w != null; afhip_api.hip: rf_table): instead of one value per (slot, column, cell) the kernel
     // writes one weighted sum per (slot, RUN, column) — a run = consecutive cells of a wave's tile whose e-th table entry names the
-    // same region (e = 0, 1; a cell's third, fourth ... entries are "extras", below).  Per period end a wave
-    // stages w_e * where(valid, x_k, 0) and w_e * valid of its cells in a wave-private LDS block and one lane per run adds the
-    // run's cells in cell order; k_rf_reduce then adds a region's runs in run order.  The per-cell period values — 0.4 GB per
+    // same region (e = 0, 1; a cell's third, fourth ... entries are "extras", below).  Per period end a wave multiplies
+    // where(valid, x_k, 0) and the valid flag of its cells by the cells' weights and adds each run's products with a segmented scan
+    // over its lanes (rf_emit); k_rf_reduce then adds a region's runs in run order.  The per-cell period values — 0.4 GB per
     // launch on the reference's own benchmark shape, stores that cost its streaming kernel 6 % — are never written, and the
     // gather kernel over them does not run.
     const double* rf_w;            // device [C][2]: weight of the cell's first / second table entry (0: none)
     const int32_t* rf_tile;        // device [wave tiles][2][2]: {first run, runs} of entry e in wave tile t (64 * VEC cells)
-    const uint16_t* rf_run;        // device [runs]: (first cell of the run in its wave tile) | (cells - 1) << 8
     double* rf_out;                // device [n_slots][runs][K + 1]
     int64_t rf_nruns;
     // cells that sit in MORE than two regions (junctions of polygons): their third, fourth ... entries are "extras" — such a cell
@@ -147,7 +146,9 @@ struct FusedArgs {
     const int32_t* rf_x;           // device [C]: index of the cell among the cells with extras, -1 = none; null: the table has none
     double* rf_ex;                 // device [n_slots][rf_nx][K + 1]
     int64_t rf_nx;
-    int32_t rf_lds_off, rf_pad;    // byte offset of the staging blocks in the dynamic LDS (one block of 64 * VEC * (K + 1) doubles per wave)
+    // region of the cell's first / second table entry (-1: none).  A wave reads its cells' keys and weights ONCE and derives where
+    // runs start and end inside its tile (the host numbered a tile's runs in cell order: rf_tile)
+    const int32_t* rf_key;         // device [C][2]
 };
 
 // ---------------------------------------------------------------------------------------
@@ -610,8 +611,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     //              lean form only.  The sum runs in time order ((u0 + u1) + u2) + u3, the mean is s / 4 = s * 0.25 exactly, min / max
     //              are taken in the input precision; sine_dd columns use the general closed forms (tavg is not the mid-range of four
     //              steps), so these variants read the acos table.
-    constexpr int GL = (FEAT & 1024) ? 4 : 2;
-    static_assert(!(FEAT & 1024) || (PAIR && LEAN && !LEAN_SINE), "four-row groups: a lean short-group form");
+    // FEAT bit 12: ... and of exactly THREE rows (8-hourly data): the sum runs (u0 + u1) + u2, the mean is the correctly rounded s / 3
+    //              (div_by with the correctly rounded reciprocal: bit-identical to the reference's division), otherwise like four rows.
+    constexpr int GL = (FEAT & 1024) ? 4 : ((FEAT & 4096) ? 3 : 2);
+    static_assert(!(FEAT & (1024 | 4096)) || (PAIR && LEAN && !LEAN_SINE), "three- / four-row groups: a lean short-group form");
+    static_assert((FEAT & (1024 | 4096)) != (1024 | 4096), "one group length per variant");
     static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % GL == 0),
                   "short-group mode: direct loads, sum (+ min + max), no threshold slots");
     static_assert(!LEAN || PAIR, "the lean group end is a short-group form");
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         unsigned char* base = dynlds + (PIPE == 1 ? (size_t)(bd >> 6) * DEPTH * 1024 : (size_t)0);
         if (a.sine_tab != nullptr) {            // uniform: the host sets it iff a column is sine_dd (and then sizes the LDS for it)
             typedef double d2 __attribute__((ext_vector_type(2)));
-            constexpr int bytes = ((FEAT & 128) != 0 && (FEAT & 1024) == 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
+            constexpr int bytes = ((FEAT & 128) != 0 && (FEAT & (1024 | 4096)) == 0) ? SINE_P2_BYTES : SINE_TAB_BYTES;
             // (the sine-only lean form works in DOUBLED units — clamp, arcs and the column's sum — and halves once per period end:
             // its copy of the table is 2 H, every step an exact scaling of the undoubled one)
             for (int e = tid; e < bytes / 16; e += bd) {
@@ -751,6 +755,80 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         }
     };
     reset_outer();
+
+    // ---- region-fused period ends, scan form (FusedArgs::rf_key): what a wave needs at every period end, read once ----
+    // A wave's tile is its 64 * VEC consecutive cells.  For entry e (the cell's first / second region) a RUN is a maximal stretch of
+    // cells of the tile with the same region; the host numbered the runs of a tile in cell order (afhip_api.hip: rf_table).
+    //   rfw[i][e]   weight of cell i's entry e (0: none)
+    //   rfbits      per lane, 16 bits per entry e:  bits 0-5   step s of the segmented scan adds the value of lane - 2^s
+    //                                                bits 6+i   cell i starts a stretch (region changes, or the tile starts)
+    //                                                bits 8+i   cell i ends a run of a region: its sum is stored
+    //   rfrid       byte 2 e + i: index of cell i's run among the runs of (tile, e)
+    //   rf_first[e] first run of (tile, e) in rf_out
+    static_assert(!RF || VEC <= 2, "region-fused period ends: one or two cells per lane");
+    //   rf_need[e]  (uniform) bit s: some lane of the wave adds in step s — steps no run of this tile is long enough for are skipped;
+    //               bit 6: some run ends at a lane's first cell (two cells per lane); bit 7: the tile has runs of entry e at all
+    double rfw[VEC][2];
+    uint32_t rfbits = 0, rfrid = 0;
+    int rf_first[2] = {0, 0}, rf_need[2] = {0, 0};
+    if constexpr (RF) {
+        if (a.rf_w != nullptr) {
+            const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)((c0 - (int64_t)lane * VEC) / (64 * VEC)));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                rf_first[e] = ld_uniform(a.rf_tile + (wt * 2 + e) * 2);
+                int key[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    key[i] = active ? a.rf_key[(c0 + i) * 2 + e] : -1;
+                    rfw[i][e] = active ? a.rf_w[(c0 + i) * 2 + e] : 0.0;
+                }
+                const int prev = __shfl_up(key[VEC - 1], 1, 64), next = __shfl_down(key[0], 1, 64);
+                bool bnd[VEC], endc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    bnd[i] = i == 0 ? (lane == 0 || key[0] != prev) : (key[i] != key[i - 1]);
+                    endc[i] = i == VEC - 1 ? (lane == 63 || key[VEC - 1] != next) : (key[i + 1] != key[i]);
+                }
+                // run numbers: the heads of regions' runs at or before a cell, in cell order (lane-major, then i)
+                int before = 0;
+                bool hd[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    hd[i] = bnd[i] && key[i] >= 0;
+                    const unsigned long long m = __ballot(hd[i]);
+                    before += __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                }
+                uint32_t bits = 0, rid = 0;
+                int n_at = before;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    n_at += hd[i] ? 1 : 0;
+                    rid |= (uint32_t)((n_at - 1) & 0xff) << (8 * i);
+                    bits |= (bnd[i] ? 1u : 0u) << (6 + i);
+                    bits |= ((endc[i] && key[i] >= 0) ? 1u : 0u) << (8 + i);
+                }
+                // the scan's flags do not depend on the data: which steps add is decided here, once
+                int F = 0;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) F |= bnd[i] ? 1 : 0;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    const int d = 1 << st;
+                    if (lane >= d && !F) bits |= 1u << st;
+                    const int Fp = __shfl_up(F, d, 64);
+                    if (lane >= d) F |= Fp;
+                }
+                rfbits |= bits << (16 * e);
+                rfrid |= rid << (16 * e);
+                int need = ld_uniform(a.rf_tile + (wt * 2 + e) * 2 + 1) > 0 ? 128 : 0;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) need |= __ballot((bits >> st) & 1u) != 0ull ? (1 << st) : 0;
+                if (VEC == 2) need |= __ballot((bits >> 8) & 1u) != 0ull ? 64 : 0;
+                rf_need[e] = __builtin_amdgcn_readfirstlane(need);
+            }
+        }
+    }
 
     // ---- the hot per-element update ----
     // LDS-histogram update of one value, in two halves so that a batch of rows can issue all its
@@ -849,73 +927,103 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     };
 
     // ---- region-fused period end (FusedArgs::rf_w): the period's K values of this lane's cells -> per-run weighted sums ----
-    // val[j][i]: column j of cell i (NaN = missing).  Everything below is in a fixed order: products rounded before the adds
-    // (like spatial.py:183-185), a run's cells added in cell order by ONE lane, so the sums do not depend on the launch shape.
-    auto rf_emit = [&](const double (&val)[KMAX][VEC], int at_slot, int zoff) {
-        // zoff is 0, but only known at run time (it comes from the group table word): every address below is formed from it, so
-        // that none of them is loop-invariant — hoisted out of the time loop they would sit in vector registers for the whole kernel
-        const int ln = lane + zoff;
-        const int64_t cl = c_ld + zoff;
-        // staged per cell: where(valid, x_k, 0) for the K columns, the valid flag and the cell's two weights (read here, by the lane
-        // that owns the cell, in one coalesced load: fetched inside the per-run loop — a serial walk — they cost more than the stores
-        // this route saves: the reference's benchmark shape 5.98 instead of 5.35 ms)
-        const int K1 = K + 1, S = K + 3;
-        const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        typedef __attribute__((address_space(3))) double* lds_f64_t;      // (32-bit LDS addresses: ds_read / ds_write, one register each)
-        lds_f64_t stage = (lds_f64_t)(lds_ptr_t)(dynlds + a.rf_lds_off) + wave * (64 * VEC) * S;
-        const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)((c0 + zoff - (int64_t)ln * VEC) / (64 * VEC)));
+    // val[j][i]: column j of cell i (NaN = missing).  The lanes multiply their cells' values (where(valid, x, 0), and the valid flag as
+    // column K) by the cells' weights; a segmented inclusive scan over the lanes — six shuffle steps whose add / skip pattern was
+    // fixed at kernel start, of which the wave runs only those some run of its tile needs — carries a run's sum to its last cell,
+    // and that lane stores it.  The order of the adds is a fixed tree over the cells of the tile: it depends on where the table's
+    // runs lie, never on the data or the launch shape.  Products are rounded before the adds (spatial.py:183-185).
+    // (Round 3 staged the values in a wave-private LDS block and let one lane per (run, column) walk its run: a serial chain of LDS
+    // round trips per period end, and the weights re-read from memory at every one — 3.7 against 3.3 ms on the daily configs[1]
+    // panel, 27.5 against 17.7 on a daily sine_dd panel of (tmin, tmax) pairs; profiles/r04_region_fused_scan.txt.)
+    auto rf_emit = [&](const double (&val)[KMAX][VEC], int at_slot) {
+        const int K1 = K + 1;
+        bool valid[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            bool valid = active;                                     // (lanes beyond the grid re-read valid cells: nothing of theirs counts)
+            valid[i] = active;                                       // (lanes beyond the grid carry no weight and no run)
 #pragma unroll
             for (int j = 0; j < KMAX; ++j)
-                if (j < K) valid = valid && (val[j][i] == val[j][i]);
-            lds_f64_t row = stage + (ln * VEC + i) * S;
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-                if (j < K) row[j] = valid ? val[j][i] : 0.0;
-            row[K] = valid ? 1.0 : 0.0;
+                if (j < K) valid[i] = valid[i] && (val[j][i] == val[j][i]);
             if (a.rf_x != nullptr) {                                 // (uniform) the table has cells in three or more regions
-                const int xi = active ? a.rf_x[cl + i] : -1;
+                const int xi = active ? a.rf_x[c0 + i] : -1;
                 if (xi >= 0) {                                       // rare lanes: the cell's values for its extra entries
                     double* ex = a.rf_ex + ((int64_t)at_slot * a.rf_nx + xi) * K1;
 #pragma unroll
                     for (int j = 0; j < KMAX; ++j)
-                        if (j < K) ex[j] = valid ? val[j][i] : 0.0;
-                    ex[K] = valid ? 1.0 : 0.0;
+                        if (j < K) ex[j] = valid[i] ? val[j][i] : 0.0;
+                    ex[K] = valid[i] ? 1.0 : 0.0;
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            const d2 w = *(const d2*)(a.rf_w + (cl + i) * 2);
-            lds_f64_t row = stage + (ln * VEC + i) * S;
-            row[K + 1] = w.x;
-            row[K + 2] = w.y;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int e = 0; e < 2; ++e) {
-            const int32_t* td = a.rf_tile + (wt * 2 + e) * 2;
-            const int first = ld_uniform(td), nr = ld_uniform(td + 1);
-            // one lane per (run, column): each sum walks its run's cells in cell order (the order never depends on which lane adds it),
-            // and the lanes of a wave share the walk of a run between the K + 1 columns instead of one lane doing them in turn
-            double* out0 = a.rf_out + ((int64_t)at_slot * a.rf_nruns + first) * K1;
-            for (int t = ln; t < nr * K1; t += 64) {
-                const int r = t / K1, k = t - r * K1;
-                const uint32_t u = a.rf_run[first + r];
-                const int len = (int)(u >> 8) + 1;
-                const lds_f64_t row0 = stage + (int)(u & 0xffu) * S;
-                double acc = 0.0;
-                for (int c = 0; c < len; ++c) acc = __dadd_rn(acc, __dmul_rn(row0[c * S + K + 1 + e], row0[c * S + k]));
-                out0[t] = acc;
+            const int need = rf_need[e];
+            if (!(need & 128)) continue;                             // (uniform) no cell of this tile has an entry e
+            const uint32_t bits = rfbits >> (16 * e), rid = rfrid >> (16 * e);
+            double* out0 = a.rf_out + ((int64_t)at_slot * a.rf_nruns + rf_first[e]) * K1;
+            double* dst0 = out0 + (int)(rid & 0xffu) * K1;           // where this lane's cells store, if they end a run
+            double* dst1 = out0 + (int)((rid >> 8) & 0xffu) * K1;
+            // columns in blocks of CB: inside a block the shuffles of the columns are independent and overlap; a step is skipped
+            // by the whole wave when no run of the tile needs it (county-sized runs span a few lanes: two or three steps of six)
+            constexpr int CB = 8;
+#pragma unroll
+            for (int j0 = 0; j0 < KMAX + 1; j0 += CB) {
+                if (j0 > K) continue;                                // (uniform)
+                double v[CB], p0[CB];
+#pragma unroll
+                for (int jj = 0; jj < CB; ++jj) {
+                    const int j = j0 + jj;
+                    v[jj] = 0.0; p0[jj] = 0.0;
+                    if (j < KMAX + 1 && j <= K) {
+                        double p[VEC];
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            double x = valid[i] ? 1.0 : 0.0;         // column K: the validity weight
+                            if (j < K) x = valid[i] ? val[j < KMAX ? j : 0][i] : 0.0;
+                            p[i] = __dmul_rn(rfw[i][e], x);
+                        }
+                        p0[jj] = p[0];
+                        v[jj] = p[VEC - 1];                          // the stretch that is still open at the lane's last cell
+                        if constexpr (VEC == 2) v[jj] = ((bits >> 7) & 1u) ? p[1] : __dadd_rn(p[0], p[1]);
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    if (!((need >> st) & 1)) continue;               // (uniform)
+                    const bool take = ((bits >> st) & 1u) != 0u;
+#pragma unroll
+                    for (int jj = 0; jj < CB; ++jj) {
+                        if (j0 + jj < KMAX + 1 && j0 + jj <= K) {
+                            const double pv = __shfl_up(v[jj], 1 << st, 64);
+                            v[jj] = __dadd_rn(v[jj], take ? pv : 0.0);
+                        }
+                    }
+                }
+                if constexpr (VEC == 2) {
+                    if (need & 64) {                                 // (uniform) a run ends at some lane's FIRST cell: what the previous lanes
+                        const bool fresh = ((bits >> 6) & 1u) != 0u, end0 = ((bits >> 8) & 1u) != 0u;      // carried (unless the cell starts a stretch) + the cell
+#pragma unroll
+                        for (int jj = 0; jj < CB; ++jj) {
+                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) {
+                                const double carried = __shfl_up(v[jj], 1, 64);
+                                if (end0) dst0[j0 + jj] = __dadd_rn(fresh ? 0.0 : carried, p0[jj]);
+                            }
+                        }
+                    }
+                    if ((bits >> 9) & 1u) {
+#pragma unroll
+                        for (int jj = 0; jj < CB; ++jj)
+                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) dst1[j0 + jj] = v[jj];
+                    }
+                } else {
+                    if ((bits >> 8) & 1u) {
+#pragma unroll
+                        for (int jj = 0; jj < CB; ++jj)
+                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) dst0[j0 + jj] = v[jj];
+                    }
+                }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the block is re-staged at the next period end)
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----
@@ -928,7 +1036,8 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         for (int i = 0; i < VEC; ++i) {
             if constexpr (PAIR) hasnan[i] = pnan[i];
             else hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
-            if constexpr (PAIR) mean[i] = s[i] * (1.0 / GL);           // == s / 2 (s / 4) bit for bit
+            if constexpr (PAIR && GL == 3) mean[i] = div_by(s[i], 3.0, 1.0 / 3.0);      // == s / 3 bit for bit (1.0 / 3.0: the correctly rounded reciprocal)
+            else if constexpr (PAIR) mean[i] = s[i] * (1.0 / GL);      // == s / 2 (s / 4) bit for bit
             else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
         }
         // single-sine degree days of one column (nb_kernels.py:218-251).  The reciprocal of the window's range and the arcs are
@@ -1052,10 +1161,11 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                             // (the full record of a sine_dd column is read where it is used: zoff is 0, but only known at run time)
                             if constexpr ((FEAT & 1) != 0) { const ColOp co = a.cols[KMAX > 2 ? j + zoff : j]; sine_column(co, x); }
                         } else if constexpr (STAT == 1) {
-                            // mean | sum: s / n with n = 2 or 4 is s * (1 / n) exactly; one multiply by a scalar either way
+                            // mean | sum: s / n with n = 2 or 4 is s * (1 / n) exactly; one multiply by a scalar either way (n = 3: the
+                            // correctly rounded quotient, already in mean[])
                             const double sc = src == SRC_SUM ? 1.0 : 1.0 / GL;
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) x[i] = s[i] * sc;
+                            for (int i = 0; i < VEC; ++i) x[i] = (GL == 3 && src != SRC_SUM) ? mean[i] : s[i] * sc;
                         } else {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) {
@@ -1122,7 +1232,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     for (int j = 0; j < KMAX; ++j)
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) val[j][i] = ((nanacc[i] >> lane) & 1ull) ? nan64() : (LEAN_SINE ? os[j][i] * 0.5 : os[j][i]);
-                    if constexpr (RF) rf_emit(val, slot, zoff);
+                    if constexpr (RF) rf_emit(val, slot);
                 } else {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
@@ -1308,7 +1418,7 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
         } else if (emit_slot) {
             if (RF && a.rf_w != nullptr) {
                 KEEP_BRANCH();
-                if constexpr (RF) rf_emit(os, slot, zoff);
+                if constexpr (RF) rf_emit(os, slot);
             } else if (active) {
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j) {
@@ -1359,6 +1469,21 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
                     mn[i] = (double)lo; mx[i] = (double)hi;
                     s[i] = mn[i] + mx[i];
                     if constexpr (STAT == 1) s[i] = (double)u + (double)v;     // (the same two addends; no min / max needed)
+                } else if constexpr (GL == 3) {
+                    const TIn u2 = r[2].v[i];
+                    pnan[i] = pnan[i] || u2 != u2;
+                    s[i] = ((double)u + (double)v) + (double)u2;                            // nb_kernels.py:130-137: k ascending
+                    if constexpr (STAT >= 2) {
+                        if constexpr (sizeof(TIn) == 4) {
+                            asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(u2));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(u2));
+                        } else {
+                            asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(u2));
+                            asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(u2));
+                        }
+                        plo[i] = lo; phi[i] = hi;
+                        mn[i] = (double)lo; mx[i] = (double)hi;
+                    }
                 } else {
                     const TIn u2 = r[2].v[i], u3 = r[3].v[i];
                     pnan[i] = pnan[i] || u2 != u2 || u3 != u3;

@@ -184,18 +184,18 @@ __global__ __launch_bounds__(WG) void k_combine_slots_tiled(const CombineArgs a)
     }
 }
 
-// Standalone reducers: slots -> the reference's out[G, cell, D] layout and dtype
-// (nb_kernels.py:257-268: float64 accumulate, store in the input dtype).
+// Standalone reducers: slots -> the reference's out[G, cell, D_out] layout and dtype
+// (nb_kernels.py:257-268: float64 accumulate, store in the input dtype); a pass holds the D columns [d_off, d_off + D) of it.
 template <typename TOut>
 __global__ __launch_bounds__(WG) void k_slots_to_block(const double* partial, const int32_t* slot_ptr,
-                                                       TOut* out, int64_t C, int64_t G, int D, const PackFmt pk) {
+                                                       TOut* out, int64_t C, int64_t G, int D, int D_out, int d_off, const PackFmt pk) {
     const int64_t c = (int64_t)blockIdx.x * WG + threadIdx.x;   // grid = (cell tiles, group lanes)
     if (c >= C) return;
     for (int64_t g = blockIdx.y; g < G; g += gridDim.y) {
         const int s0 = slot_ptr[g], s1 = slot_ptr[g + 1];
         for (int d = 0; d < D; ++d) {
             const double v = (s1 == s0) ? nan64() : ld_partial(partial, pk, s0, d, D, C, c);
-            out[(g * C + c) * D + d] = (TOut)v;
+            out[(g * C + c) * D_out + d_off + d] = (TOut)v;
         }
     }
 }
@@ -383,7 +383,10 @@ struct SlotSpmmArgs {
     const int64_t* outer_bounds;     // device [P + 1]
     double* out;                     // device [rows][P][K + 1]
     int64_t nseg, P, C;
-    int32_t K, pad;
+    int32_t K;
+    int32_t p_major;                 // order of the (segment, period) pairs over the grid: 0 = a segment's periods side by side (its table entries
+                                     // stay in cache across them), 1 = a period's segments side by side (neighbouring regions share the
+                                     // cache lines of ONE slot's planes: with many periods the planes of 365 slots do not fit any cache)
     int32_t outer[MAX_COLS];
     int32_t round_final[MAX_COLS];
     // res != null (no row of the table is cut into segments: segment v IS region dst[v]): the lane that holds the K + 1 sums writes
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_slots(const SlotSpmmArgs a) {
     const int64_t gid = ((int64_t)blockIdx.x * WG + threadIdx.x) / SUB;
     const bool live = gid < n;                                     // (a last wave's spare groups redo the last pair, unstored)
     const int64_t g = live ? gid : n - 1;
-    const int64_t v = g / a.P, p = g - v * a.P;
+    const int64_t v = a.p_major ? g % a.nseg : g / a.P, p = a.p_major ? g / a.nseg : g - v * a.P;
     const int sl = threadIdx.x & (SUB - 1);
     const int K = a.K;
     const int64_t C = a.C;
@@ -682,6 +685,33 @@ __global__ __launch_bounds__(WG) void k_place_box(const TE* __restrict__ src, TE
     if (i >= nt * ny * nx) return;
     const int64_t x = i % nx, r = i / nx, y = r % ny, t = r / ny;
     dst[((t0 + t) * NY + (y0 + y)) * NX + (x0 + x)] = src[((st + t) * by + (sy + y)) * bx + (sx + x)];
+}
+
+// ---------------------------------------------------------------------------------------
+// k_read_probe: the temporal kernel's access pattern with no arithmetic — the box's read ceiling for this shape, measured beside
+// the kernel it bounds (afhip_read_probe; bench.py: roofline.measured_read_ceiling_GBps).  Every lane owns 8 bytes of a row, a
+// single-wave workgroup one column tile, four row loads in flight (non-temporal), integer adds, one dword stored per lane at the
+// end: the fastest arm of scripts/probe/read_bw.hip's sweep over load width x depth x workgroup size x chunks x cache policy
+// (profiles/r03_read_ceiling.txt: 7.02 TB/s where 256-thread workgroups reach 6.69 and cached loads 6.23).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_read_probe(const uint32_t* __restrict__ base, int64_t row_dw, int64_t T, uint32_t* __restrict__ out) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const int64_t lane = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t col = lane * 2;
+    if (col >= row_dw) return;                                   // (whole lanes only: row_dw is even)
+    const uint32_t* p = base + col;
+    uint32_t acc = 0;
+    int64_t t = 0;
+    for (; t + 4 <= T; t += 4) {
+        u2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load((const u2*)(p + (int64_t)j * row_dw));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += v[j].x + v[j].y;
+        p += 4 * row_dw;
+    }
+    for (; t < T; ++t, p += row_dw) { const u2 v = __builtin_nontemporal_load((const u2*)p); acc += v.x + v.y; }
+    out[lane] = acc;
 }
 
 }  // namespace afhip

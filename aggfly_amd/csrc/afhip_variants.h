@@ -26,20 +26,21 @@ struct Variant {
     int pair;         // 1: plans whose inner groups all hold exactly two rows ((tmin, tmax) pairs)
     int ss;           // ... with the lean group end: 1 = columns mean | sum | min | max | sine_dd -> (integer power) -> sum | mean;
                       //     2 = every column a plain sine_dd -> sum | mean (the tightest form)
-    int quad;         // 1: ... for inner groups of exactly FOUR rows (6-hourly data) instead of two; lean form only
+    int quad;         // 1: ... for inner groups of exactly FOUR rows (6-hourly data) instead of two, 2: of exactly THREE rows (8-hourly); lean form only
     int rf;           // 1: region-fused period ends compiled in (the twin of the variant with the same other fields)
     const void* fn;
     const char* name;
 };
 
 const Variant* variants_table(int* n);   // generated (variants_table.hip)
+const char* variants_menu();             // "full" (the production menu), "arms" (+ the tuning arms) or "dev"
 
 // tuning: 0 = the default choice below; otherwise an explicit arm
 //         pipe*1000 + vec*100 + depth  (+10000: default cache policy instead of nt)
 //         e.g. 1404 LDS ring, 4 cells per lane, depth 4;  108 direct loads, 1 cell per lane, 8 rows in flight
 inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int K, int tuning, int vec = 0,
                                    bool all_bins = false, bool single_level = false, bool partition = false, bool arith = false,
-                                   bool pairs = false, int lean = 0, int depth_hint = 0, bool quads = false, bool rf = false) {
+                                   bool pairs = false, int lean = 0, int depth_hint = 0, int quads = 0, bool rf = false) {
     const Variant* best = nullptr;
     long best_cost = 0;
     int n = 0;
@@ -55,7 +56,7 @@ inline const Variant* find_variant(int dtype, int pipe, int stat, int nthr, int 
         if (v.dtype != dtype || v.stat < stat || v.nthr < nthr || v.kmax < K || (v.rf != 0) != rf) continue;
         if ((v.tki && !(all_bins && nthr > 0)) || (v.sl && !single_level) || (v.hb && !partition) || (v.ha && !arith)) continue;
         if (v.pair && !((pairs || quads) && nthr == 0)) continue;
-        if ((v.pair && (v.quad != 0) != quads) || (quads && !v.pair)) continue;    // a four-row plan takes four-row variants only, and vice versa
+        if ((v.pair && v.quad != quads) || (quads && !v.pair)) continue;    // a three- / four-row plan takes the variants of its group length only, and vice versa
         if (v.ss > lean) continue;                      // a lean variant needs a plan that qualifies for its form (2 implies 1)
         if (v.pipe != want_pipe || v.nt != want_nt) continue;
         if (tuning > 0) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes the translation units that instantiate k_fused_temporal (afhip_kernels.h).
 
-Usage: gen_variants.py OUTDIR [--menu full|dev] [--per-file N]
+Usage: gen_variants.py OUTDIR [--menu full|arms|dev] [--per-file N]      (full: the production menu; arms: + the tuning arms)
 
 Each generated ``variants_NN.hip`` holds a handful of explicit instantiations so that
 ``make -j`` compiles them in parallel; ``variants_table.hip`` collects the table that
@@ -18,11 +18,11 @@ def menu(kind):
     out = []
     vec16 = {0: 4, 1: 2}
 
-    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0, ss=0, quad=0, rf=0):
+    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0, ss=0, quad=0, rf=0, tri=0):
         # sine degree days ride on the min/max accumulators; generic pow() only in the
         # all-purpose (STAT 3) variants; bit 2 = nt cache policy on the streaming loads;
         # bit 3 = integer bin counters; bit 4 = single-level plan (no outer accumulators)
-        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0) | (512 if ss == 2 else 0) | (1024 if quad else 0) | (2048 if rf else 0)
+        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0) | (512 if ss == 2 else 0) | (1024 if quad else 0) | (2048 if rf else 0) | (4096 if tri else 0)
         key = (dtype, pipe, vec, stat, nthr, kmax, depth, feat)
         for i, v in enumerate(out):
             if v[:8] == key:
@@ -110,25 +110,34 @@ def menu(kind):
             for stat in (1, 2):
                 for kmax in (2, 6):
                     add(dtype, 0, vec, stat, 0, kmax, depth, pair=1, ss=1, quad=1, prod=prod)
-    # region-fused period ends (FEAT bit 11): twins of the production two-level variants on the direct-load path with up to six
-    # columns.  Of the short-group forms (their group end is inlined once per group copy): every lean four-row form (6-hourly data:
-    # monthly polynomial step 0.97 against 1.13 - 1.33 ms) and the six-column lean pair form (polynomial of the daily mean of
-    # (tmin, tmax): step 4.75 against 5.12 ms); the sine-only pair form measured 4 % behind and has no twin
+        # inner groups of exactly three rows (8-hourly data): the same lean form (FEAT bit 12), two groups per block of six rows
+        for vec in ((1,) if dtype == 1 else (2, 1)):
+            for stat in (1, 2):
+                for kmax in (2, 6):
+                    add(dtype, 0, vec, stat, 0, kmax, 6, pair=1, ss=1, tri=1)
+    # region-fused period ends (FEAT bit 11): twins of the production two-level variants on the direct-load path.  Round 3 built the
+    # twins that gain from two periods on (up to six columns and four threshold slots, with a statistic; of the short-group forms
+    # every lean four-row form and the six-column lean pair form); round 4 adds threshold-only plans (a daily panel of degree days) and
+    # every short-group form incl. the sine-only pair form (afhip_api.hip: rf_plan_ok says when the planner takes them).  Plans of
+    # more than six columns or four threshold slots are bound by their arithmetic and measured level with or behind the per-cell route
+    # (13 degree-day columns, daily panel: 20.7 against 21.1 ms; monthly: 15.5 against 14.5): no twins.  Single-level (`sl`),
+    # integer-bin and histogram variants have none either.
     # — appended, so that the translation units above keep their contents
     for v in list(out):
         dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
-        short = bool(feat & 128)                       # pair / four-row forms: only lean ones; of the two-row forms only the six-column variant
-        if short and not ((feat & 1024) or ((feat & 256) and not (feat & 512) and kmax == 6)):
-            continue
-        if prod and pipe == 0 and kmax <= 6 and nthr <= 4 and stat >= 1 and not (feat & (8 | 16 | 32)):
+        if prod and pipe == 0 and kmax <= 6 and nthr <= 4 and not (feat & (8 | 16 | 32)):
             out.append((dtype, pipe, vec, stat, nthr, kmax, depth, feat | 2048, prod))
+    # `full` = what the planner can pick; the tuning arms of the headline shapes (kbench.py / r03_arms.py `tuning=`; not production:
+    # 74 kernels) are compiled by `make MENU=arms` only
+    if kind != "arms":
+        out = [v for v in out if v[8]]
     return out
 
 
 def name_of(v):
     dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
     return (f"{'f32' if dtype == 0 else 'f64'}_p{pipe}_v{vec}_s{stat}_t{nthr}_k{kmax}_d{depth}" + ("_nt" if feat & 4 else "")
-            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 512 else ("_lean" if feat & 256 else "")) + ("_quad" if feat & 1024 else "") + ("_rf" if feat & 2048 else ""))
+            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 512 else ("_lean" if feat & 256 else "")) + ("_quad" if feat & 1024 else "") + ("_tri" if feat & 4096 else "") + ("_rf" if feat & 2048 else ""))
 
 
 def inst(v):
@@ -191,7 +200,7 @@ def main():
             f.write(f"int register_variants_{idx:02d}(Variant* out) {{\n    int n = 0;\n")
             for v in group:
                 dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
-                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {2 if feat & 512 else (1 if feat & 256 else 0)}, {1 if feat & 1024 else 0}, {1 if feat & 2048 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
+                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {2 if feat & 512 else (1 if feat & 256 else 0)}, {1 if feat & 1024 else (2 if feat & 4096 else 0)}, {1 if feat & 2048 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
             f.write("    return n;\n}\n}\n")
         files.append(fn)
     with _KeepIfSame(os.path.join(outdir, "variants_table.hip")) as f:
@@ -201,6 +210,7 @@ def main():
         for g in range(ngroups):
             f.write(f"int register_variants_{g:02d}(Variant* out);\n")
         f.write(f"static Variant g_table[{len(vs)}];\nstatic int g_count = -1;\n")
+        f.write(f'const char* variants_menu() {{ return "{kind}"; }}\n')
         f.write("const Variant* variants_table(int* n) {\n    if (g_count < 0) {\n        int c = 0;\n")
         for g in range(ngroups):
             f.write(f"        c += register_variants_{g:02d}(g_table + c);\n")

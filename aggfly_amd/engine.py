@@ -209,13 +209,21 @@ def get_plan(T, n_cells, dtype_code, ib, ob, columns, exact_order=None, tuning=N
     dev = hip._device_index(device)
     # the second cube of an 'inter' column is bound per run (hip.FusedPlan.bind_inter), so it is not part of the key
     ckey = (dev, T, n_cells, dtype_code, _hash(ib, ob), repr([{k: v for k, v in c.items() if k != "inter"} for c in columns]), exact, tune)
-    p = _PLAN_CACHE.get(ckey)
-    if p is None:
-        p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune, device=dev)
-        held = sum(q.workspace_bytes() for q in _PLAN_CACHE.values())
-        while _PLAN_CACHE and (len(_PLAN_CACHE) >= _PLAN_CACHE_MAX or held + p.workspace_bytes() > _PLAN_CACHE_BYTES):
+    with _CACHE_LOCK:
+        p = _PLAN_CACHE.get(ckey)
+    if p is not None:
+        return p
+    # built OUTSIDE the cache lock (table uploads, occupancy queries, the chunk search): the first calls of the threads / devices of
+    # a dask-style pool do not queue up behind one another
+    p = hip.FusedPlan(T, n_cells, dtype_code, ib, ob, columns, exact_order=exact, tuning=tune, device=dev)
+    with _CACHE_LOCK:
+        hit = _PLAN_CACHE.get(ckey)
+        if hit is not None:                             # another thread built the same plan meanwhile: keep one
+            return hit
+        held = sum(q.scratch_bytes() for q in _PLAN_CACHE.values())
+        while _PLAN_CACHE and (len(_PLAN_CACHE) >= _PLAN_CACHE_MAX or held + p.scratch_bytes() > _PLAN_CACHE_BYTES):
             old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
-            held -= old.workspace_bytes()
+            held -= old.scratch_bytes()
         _PLAN_CACHE[ckey] = p
     return p
 
@@ -398,7 +406,7 @@ def plan_groups(time_index, cols):
 
 # Re-entrancy (the reference's kernels are called concurrently from dask's thread pool, `nb_kernels.py:271-305`).
 # Two locks, neither global over the runs:
-#   * ``_CACHE_LOCK`` guards the two caches (lookup / insert / evict) — held for microseconds;
+#   * ``_CACHE_LOCK`` guards the two caches (lookup / insert / evict) — held for microseconds: plans and tables are built outside it;
 #   * every cached plan has its own lock (``hip.FusedPlan.lock``), held while ONE call binds its second cubes and enqueues its
 #     kernel sequence: a plan handle owns scratch in HBM and must not be entered twice at once (include/aggfly_hip.h).
 # Calls on DIFFERENT plans (other shapes, other specs, other devices) enqueue concurrently; calls on the same plan enqueue one
@@ -419,8 +427,7 @@ def _run_fused_pass(cube, cols, ib, ob, csr=None, want_cells=True, exact_order=N
     f32_rules = config.match_reference_f32 and code == hip.F32
     cdicts = [_column_dict(c, f32_rules) for c in cols]
     try:
-        with _CACHE_LOCK:
-            plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order, device=cube.device)
+        plan = get_plan(T, n_cells, code, ib, ob, cdicts, exact_order, device=cube.device)
     except hip.HipUnsupported:
         if len(cols) == 1:
             raise

@@ -26,14 +26,15 @@ ROUND_INNER, ROUND_HINGE, ROUND_FINAL = 1, 2, 4
 CALC_CODE = {"mean": MEAN, "sum": SUM, "min": MIN, "max": MAX, "nanmean": NANMEAN,
              "dd": DD, "bins": BINS, "sine_dd": SINE_DD}
 E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4
+ABI_VERSION = 4                 # AFHIP_ABI_VERSION of include/aggfly_hip.h this binding was written against
 
 EXPORTS = (
-    "afhip_last_error", "afhip_abi_version", "afhip_device_count", "afhip_device_info",
+    "afhip_last_error", "afhip_abi_version", "afhip_build_info", "afhip_device_count", "afhip_device_info",
     "afhip_group_stat", "afhip_group_dd", "afhip_group_bins", "afhip_group_sine_dd",
     "afhip_csr_create", "afhip_csr_destroy", "afhip_scatter_block", "afhip_spatial_wavg", "afhip_place_box",
-    "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes",
+    "afhip_plan_create", "afhip_plan_destroy", "afhip_plan_workspace_bytes", "afhip_plan_run_workspace_bytes",
     "afhip_plan_describe", "afhip_plan_run_temporal", "afhip_plan_run",
-    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_csr_device", "afhip_plan_device", "afhip_transform", "afhip_panel_divide", "afhip_lz4_decode_streams", "afhip_unshuffle_blocks",
+    "afhip_plan_profile_begin", "afhip_plan_profile_end", "afhip_plan_bind_inter", "afhip_csr_device", "afhip_plan_device", "afhip_transform", "afhip_panel_divide", "afhip_lz4_decode_streams", "afhip_unshuffle_blocks", "afhip_read_probe",
 )
 
 
@@ -83,8 +84,14 @@ def load():
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
     lib.afhip_last_error.restype = C.c_char_p
     lib.afhip_plan_workspace_bytes.restype = i64
+    lib.afhip_plan_run_workspace_bytes.restype = i64
+    lib.afhip_plan_run_workspace_bytes.argtypes = [vp, vp]
+    if lib.afhip_abi_version() != ABI_VERSION:
+        raise HipEngineError(f"{LIB_PATH} speaks ABI {lib.afhip_abi_version()}, this binding ABI {ABI_VERSION}: rebuild it (make -C aggfly_amd/csrc)")
     lib.afhip_csr_destroy.restype = None
     lib.afhip_plan_destroy.restype = None
+    lib.afhip_build_info.argtypes = [C.c_char_p, i32]
+    lib.afhip_read_probe.argtypes = [vp, i64, i64, i32, C.POINTER(C.c_float), vp]
     lib.afhip_device_info.argtypes = [i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)]
     lib.afhip_group_stat.argtypes = [vp, i32, i64, i64, vp, i64, i32, vp, vp]
     for nm in ("afhip_group_dd", "afhip_group_bins", "afhip_group_sine_dd"):
@@ -98,8 +105,8 @@ def load():
     lib.afhip_plan_destroy.argtypes = [vp]
     lib.afhip_plan_workspace_bytes.argtypes = [vp]
     lib.afhip_plan_describe.argtypes = [vp, C.c_char_p, i32]
-    lib.afhip_plan_run_temporal.argtypes = [vp, vp, vp, vp, vp]
-    lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    lib.afhip_plan_run_temporal.argtypes = [vp, vp, vp, vp, i64, vp]
+    lib.afhip_plan_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, C.POINTER(C.c_float)]
     lib.afhip_plan_bind_inter.argtypes = [vp, i32, vp, i32]
     lib.afhip_transform.argtypes = [vp, i32, i64, i32, dbl, vp, i32, vp, i32, vp]
     lib.afhip_panel_divide.argtypes = [vp, vp, vp, i64, i64, i64, vp]
@@ -129,11 +136,29 @@ def device_count() -> int:
     return int(load().afhip_device_count())
 
 
+def build_info() -> dict:
+    """What the loaded build holds: {"menu": "full" | "arms" | "dev", "variants", "arms", "region_fused_twins", "abi"} (`afhip_build_info`)."""
+    buf = C.create_string_buffer(256)
+    load().afhip_build_info(buf, 256)
+    out = dict(kv.split("=") for kv in buf.value.decode().split())
+    return {k: (int(v) if v.isdigit() else v) for k, v in out.items()}
+
+
 def device_info(dev: int = 0) -> dict:
     name, arch = C.create_string_buffer(256), C.create_string_buffer(256)
     cus, mem = C.c_int(0), C.c_int64(0)
     _check(load().afhip_device_info(dev, name, 256, arch, 256, C.byref(cus), C.byref(mem)))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+
+def read_probe(cube, launches: int = 10):
+    """`afhip_read_probe`: per-launch ms of a bare streaming read of ``cube`` ([T, ...] HBM tensor, rows of a multiple of 8 bytes)
+    with the temporal kernels' access pattern — this box's read ceiling for the shape."""
+    require_gpu()
+    cube, T, n_cells = _dev_cube(cube)
+    ms = (C.c_float * int(launches))()
+    _check(load().afhip_read_probe(cube.data_ptr(), T, n_cells * cube.element_size(), int(launches), ms, _stream_ptr(cube)))
+    return [float(v) for v in ms]
 
 
 def place_box(chunk, cube, box_in_chunk, at):
@@ -253,18 +278,9 @@ def _group(fn_name, cube, bounds, code=None, ddargs=None):
     dda = np.ascontiguousarray(np.atleast_2d(np.asarray(ddargs, dtype=np.float64)))
     D = dda.shape[0]
     out = torch.empty((G,) + spatial + (D,), dtype=cube.dtype, device=cube.device)
-    MAXD = 16
-    if G:
-        if D <= MAXD:
-            _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
-                                         dda.ctypes.data, D, out.data_ptr(), _stream_ptr(cube)))
-        else:  # more thresholds than one pass holds: run passes of 16 and interleave
-            for d0 in range(0, D, MAXD):
-                sub = np.ascontiguousarray(dda[d0:d0 + MAXD])
-                tmp = torch.empty((G,) + spatial + (len(sub),), dtype=cube.dtype, device=cube.device)
-                _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
-                                             sub.ctypes.data, len(sub), tmp.data_ptr(), _stream_ptr(cube)))
-                out[..., d0:d0 + len(sub)] = tmp
+    if G:      # any D: the library runs passes of 16 thresholds inside the call (like the reference's loop over ddargs rows)
+        _check(getattr(lib, fn_name)(cube.data_ptr(), _dtype_code(cube), T, n_cells, bounds.ctypes.data, G,
+                                     dda.ctypes.data, D, out.data_ptr(), _stream_ptr(cube)))
     return out
 
 
@@ -445,6 +461,7 @@ class FusedPlan:
         self._h = h
         self.G1 = len(self.ib) - 1
         self._inter = {}               # column -> the bound second cube (kept alive while bound)
+        self._ws = None                # this plan's scratch: a block of torch's caching allocator, grown at need (`_workspace`)
         import threading
         #: held by a caller while it binds second cubes and enqueues a run: the handle owns scratch in HBM and must not be
         #: entered by two calls at once (include/aggfly_hip.h); `engine._run_fused_pass` takes it around bind + run
@@ -463,8 +480,30 @@ class FusedPlan:
         load().afhip_plan_describe(self._h, buf, 2048)
         return buf.value.decode()
 
-    def workspace_bytes(self) -> int:
-        return int(load().afhip_plan_workspace_bytes(self._h))
+    def workspace_bytes(self, csr: "CSR | None" = None) -> int:
+        """Bytes of HBM scratch a run needs: of `run_temporal` (no ``csr``), or of a whole `run` against ``csr``."""
+        if csr is None:
+            return int(load().afhip_plan_workspace_bytes(self._h))
+        return int(load().afhip_plan_run_workspace_bytes(self._h, csr.handle))
+
+    def scratch_bytes(self) -> int:
+        """HBM this plan pins while it is cached: its scratch block (once a run has allocated it; before, the temporal stage's
+        share plus the cell-major panel, which is what a run will ask for up to the small sums area)."""
+        if self._ws is not None:
+            return int(self._ws.numel())
+        return int(self.workspace_bytes()) + 8 * self.n_cells * (self.K + 1) * max(self.P, 1)
+
+    def _workspace(self, nbytes: int, device):
+        """The plan's own scratch as a CALLER-owned workspace of the library: a uint8 block from torch's caching allocator, kept
+        on the plan and grown at need (the outgrown block goes back to the allocator; the stream-ordered allocator keeps it
+        alive for kernels already enqueued on the current stream).  Where the library's own first hipMalloc lands decides
+        7-9 % of the bin-count kernel on some boxes (profiles/r03_plan_order_probe.txt: the same plan is fast on a torch
+        block), and a plan-owned block would be a second allocator beside torch's."""
+        torch = _torch()
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+        return self._ws
 
     def _check_cube(self, cube):
         cube, T, n_cells = _dev_cube(cube)
@@ -477,12 +516,14 @@ class FusedPlan:
         torch = _torch()
         cube = self._check_cube(cube)
         cells = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=cube.device)
-        _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), None, _stream_ptr(cube)))
+        ws = self._workspace(self.workspace_bytes(), cube.device)
+        _check(load().afhip_plan_run_temporal(self._h, cube.data_ptr(), cells.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(cube)))
         return cells
 
     def run(self, cube, csr: CSR, want_cells=False, timed=False, out=None, workspace=None):
         """-> dict(num[K,R,P], den[R,P], res[K,R,P], cells?, kernel_ms?).  ``workspace``: an optional
-        caller-owned uint8 HBM tensor of at least ``workspace_bytes()`` (else the plan owns one).
+        caller-owned uint8 HBM tensor of at least ``workspace_bytes(csr)``; None: the plan's own block of torch's caching
+        allocator (`_workspace`); the string "library": the library's own hipMalloc'ed scratch, as a bare C caller gets it.
 
         ``want_cells=False`` (what `aggregate_dataset` asks for) lets the library skip the per-cell values: one gather over the
         period partials finishes the panel, and plans with several output periods reduce their cells by region inside the
@@ -499,13 +540,19 @@ class FusedPlan:
                 out["cells"] = torch.empty((self.K, self.P, self.n_cells), dtype=torch.float64, device=dev)
         ms = (C.c_float * 2)() if timed else None
         cells_ptr = out["cells"].data_ptr() if "cells" in out else None
-        ws_ptr = None
-        if workspace is not None:
-            if workspace.numel() * workspace.element_size() < self.workspace_bytes() or not workspace.is_cuda:
-                raise ValueError(f"workspace must be an HBM tensor of >= {self.workspace_bytes()} bytes")
-            ws_ptr = workspace.data_ptr()
+        need = self.workspace_bytes(csr)
+        if isinstance(workspace, str):
+            if workspace != "library":
+                raise ValueError("workspace must be None, an HBM tensor or 'library'")
+            ws_ptr, ws_bytes = None, 0
+        else:
+            if workspace is None:
+                workspace = self._workspace(need, dev)
+            elif workspace.numel() * workspace.element_size() < need or not workspace.is_cuda:
+                raise ValueError(f"workspace must be an HBM tensor of >= {need} bytes")
+            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         _check(load().afhip_plan_run(self._h, cube.data_ptr(), csr.handle, out["num"].data_ptr(),
-                                     out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, ws_ptr,
+                                     out["den"].data_ptr(), out["res"].data_ptr(), cells_ptr, ws_ptr, ws_bytes,
                                      _stream_ptr(cube), ms))
         if timed:
             out["kernel_ms"] = (float(ms[0]), float(ms[1]))
@@ -529,6 +576,7 @@ class FusedPlan:
         if getattr(self, "_h", None):
             load().afhip_plan_destroy(self._h)
             self._h = None
+        self._ws = None
 
     def __del__(self):
         try:

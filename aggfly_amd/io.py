@@ -351,17 +351,19 @@ def _torch_dtype(np_dtype):
 
 
 _PINNED_STAGE = {}      # (nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
+_STAGED_DEVICES = set() # indices of the devices this process uploaded to through the staging buffers (`_pinned_stage`)
 
 
 def _release_staging_at_exit():
-    """Interpreter teardown: wait for every stream of every device this process touched, then give the page-locked staging
+    """Interpreter teardown: wait for every stream of the devices this process uploaded to (only those: with one rank per GPU a
+    rank must not open a context on the other ranks' cards on its way out), then give the page-locked staging
     buffers back while the HIP runtime is still alive.  The ingest routes drain their own copy / work streams before they
     return, but the cached buffers outlived the runtime's teardown order: under `rocprofv3 --memory-copy-trace` the process
     ended with "completion callbacks were not delivered" for the last asynchronous uploads (round 2's timeline run)."""
     try:
         import torch
         if _PINNED_STAGE and torch.cuda.is_available() and torch.cuda.is_initialized():
-            for d in range(torch.cuda.device_count()):
+            for d in sorted(_STAGED_DEVICES):
                 torch.cuda.synchronize(d)
     except Exception:      # teardown must never raise
         pass
@@ -374,12 +376,15 @@ if os.environ.get("AGGFLY_HIP_NO_EXIT_HOOK") != "1":
     atexit.register(_release_staging_at_exit)
 
 
-def _pinned_stage(nbytes: int, count: int):
+def _pinned_stage(nbytes: int, count: int, device=None):
     """``count`` page-locked host buffers of >= nbytes, cached for the life of the process (the CLI's
     year loop and every later dataset reuse them).  Pinning costs ~0.1 s per GB, which is why a
     per-call pinned buffer measured slower than a pageable one; a cached one makes the H2D copy
     truly asynchronous, so slab i uploads at PCIe rate while slab i+1 decodes."""
     import torch
+    if torch.cuda.is_available():
+        idx = None if device is None else torch.device(device).index
+        _STAGED_DEVICES.add(int(torch.cuda.current_device() if idx is None else idx))
     size = 1 << max(20, (int(nbytes) - 1).bit_length())
     bufs = _PINNED_STAGE.setdefault(size, [])
     while len(bufs) < count:
@@ -404,7 +409,7 @@ def stream_to_device(T: int, spatial: tuple, np_dtype, read_slab, slab_steps: in
     slab_steps = max(1, min(slab_steps, T))
     row = int(np.prod(spatial)) * np_dtype.itemsize
     nstage = 2 if T > slab_steps else 1
-    stage_t = [b[:slab_steps * row].view(tdt).reshape((slab_steps,) + tuple(spatial)) for b in _pinned_stage(slab_steps * row, nstage)]
+    stage_t = [b[:slab_steps * row].view(tdt).reshape((slab_steps,) + tuple(spatial)) for b in _pinned_stage(slab_steps * row, nstage, device)]
     stage = [t.numpy() for t in stage_t]
     copy_stream = torch.cuda.Stream(device=device)
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
@@ -705,7 +710,7 @@ def _scatter_host_decode(job: _ScatterJob, threads: int, slab_bytes: int, post):
     if cb >= (64 << 20):
         per = 1          # big chunks decode block-parallel on the whole team: one per batch pipelines best with the upload
     nstage = 2 if len(idxs) > per else 1
-    host = _pinned_stage(per * cb, nstage)
+    host = _pinned_stage(per * cb, nstage, device)
     dev = [torch.empty(per * cb, dtype=torch.uint8, device=device) for _ in range(nstage)]
     copy_stream = torch.cuda.Stream(device=device)
     # the cube (and the staging tensors) come from the caching allocator on the CURRENT stream: a block freed there may
@@ -773,7 +778,7 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     cap_streams = per * (nblk * tsz + cb // 65536 + 2)          # one stream per byte plane of a block; stored chunks in 64 KiB pieces
     cap_blocks = per * nblk
     rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
-    host = _pinned_stage(per * cmax + rec_bytes, nstage)
+    host = _pinned_stage(per * cmax + rec_bytes, nstage, device)
     comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
     tmp_dev = [torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device) for _ in range(nstage)]
     staged = [None] * nstage                             # decoded chunks of batches that cannot go straight into the cube

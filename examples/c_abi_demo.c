@@ -6,7 +6,11 @@
  *   (the HIP runtime is only used here for hipMalloc / hipMemcpy of the demo's own buffers)
  *
  * A 48-step, 2x3-cell cube; daily mean -> square -> sum over the two days, and degree days
- * [10, 30); two regions.  The expected numbers are computed on the host in the same order. */
+ * [10, 30); two regions.  The expected numbers are computed on the host in the same order.
+ * The plan runs twice — on scratch the library allocates itself, and on a caller-owned workspace
+ * sized by afhip_plan_run_workspace_bytes (nothing on the run path allocates then) — and the
+ * drop-in for _block_dd (nb_kernels.py:158-179) is called with D = 20 threshold rows, more than
+ * one pass over the cube holds: the library loops the passes, as the reference loops ddargs. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -44,7 +48,19 @@ int main(void) {
     if (hipMalloc((void**)&d_cube, sizeof cube) || hipMalloc((void**)&d_num, sizeof num) ||
         hipMalloc((void**)&d_den, sizeof den) || hipMalloc((void**)&d_res, sizeof res)) return 3;
     hipMemcpy(d_cube, cube, sizeof cube, hipMemcpyHostToDevice);
-    CHECK(afhip_plan_run(plan, d_cube, csr, d_num, d_den, d_res, NULL, NULL, NULL, NULL));
+    CHECK(afhip_plan_run(plan, d_cube, csr, d_num, d_den, d_res, NULL, NULL, 0, NULL, NULL));      /* plan-owned scratch */
+    hipDeviceSynchronize();
+    double first[K * R * P];
+    hipMemcpy(first, d_res, sizeof first, hipMemcpyDeviceToHost);
+    /* the same run on a workspace this program owns (hipMalloc returns 256-byte aligned blocks) */
+    const int64_t ws_bytes = afhip_plan_run_workspace_bytes(plan, csr);
+    void* d_ws = NULL;
+    if (ws_bytes <= 0 || hipMalloc(&d_ws, (size_t)ws_bytes)) return 3;
+    hipMemset(d_res, 0, sizeof res);
+    CHECK(afhip_plan_run(plan, d_cube, csr, d_num, d_den, d_res, NULL, d_ws, ws_bytes, NULL, NULL));
+    if (afhip_plan_run(plan, d_cube, csr, d_num, d_den, d_res, NULL, d_ws, ws_bytes - 256, NULL, NULL) != AFHIP_E_INVALID) {
+        fprintf(stderr, "a workspace that is too small was not refused\n"); return 1;
+    }
     hipDeviceSynchronize();
     hipMemcpy(num, d_num, sizeof num, hipMemcpyDeviceToHost);
     hipMemcpy(den, d_den, sizeof den, hipMemcpyDeviceToHost);
@@ -82,6 +98,30 @@ int main(void) {
             if (fabs(got - want) > 1e-12 * fabs(want)) ++fails;
         }
     }
+    for (int i = 0; i < K * R * P; ++i)
+        if (!(first[i] == res[i])) { printf("plan-owned and caller-owned scratch disagree at %d\n", i); ++fails; }
+
+    /* _block_dd with D = 20 rows (t0, t1, flag): out[G][cell][D] in the cube's dtype, two daily groups */
+    enum { D = 20, G = 2 };
+    double ddargs[D * 3], *d_out, out[G * C * D];
+    for (int q = 0; q < D; ++q) { ddargs[3 * q] = -2.0 + 1.5 * q; ddargs[3 * q + 1] = 9.0 + 1.5 * q; ddargs[3 * q + 2] = q % 2; }
+    if (hipMalloc((void**)&d_out, sizeof out)) return 3;
+    CHECK(afhip_group_dd(d_cube, AFHIP_F64, T, C, inner, G, ddargs, D, d_out, NULL));
+    hipMemcpy(out, d_out, sizeof out, hipMemcpyDeviceToHost);
+    for (int g = 0; g < G; ++g)
+        for (int c = 0; c < C; ++c)
+            for (int q = 0; q < D; ++q) {
+                const double t0 = ddargs[3 * q], t1 = ddargs[3 * q + 1], base = ddargs[3 * q + 2] == 0.0 ? t0 : t1;
+                double a = 0; int nan_ = 0;
+                for (int k = inner[g]; k < inner[g + 1]; ++k) {
+                    double v = cube[k * C + c];
+                    if (isnan(v)) { nan_ = 1; break; }
+                    if (v > t0 && v < t1) a += fabs(v - base);
+                }
+                const double got = out[(g * C + c) * D + q];
+                if (nan_ ? !isnan(got) : !(got == a)) { printf("group_dd g=%d c=%d d=%d: gpu %.17g host %.17g\n", g, c, q, got, nan_ ? NAN : a); ++fails; }
+            }
+    printf("afhip_group_dd with D = %d rows: %s\n", D, fails ? "MISMATCH" : "bit-exact");
     afhip_plan_destroy(plan);
     afhip_csr_destroy(csr);
     printf(fails ? "MISMATCH\n" : "C ABI OK\n");

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AFHIP_ABI_VERSION 3
+#define AFHIP_ABI_VERSION 4
 
 /* status codes */
 #define AFHIP_OK            0
@@ -67,6 +67,9 @@ extern "C" {
 
 const char* afhip_last_error(void);
 int afhip_abi_version(void);
+/* What this build of the library holds, as text into buf ("menu=full variants=426 arms=0 region_fused_twins=150 abi=4"); returns the
+ * bytes needed.  menu: full = every kernel the planner can pick; arms = + the tuning arms a `tuning` hint can name (make MENU=arms). */
+int afhip_build_info(char* buf, int buf_len);
 /* Number of visible GPUs (hipGetDeviceCount); 0 when there is none. */
 int afhip_device_count(void);
 /* Name/arch/CU count of device `dev` into caller buffers (arch e.g. "gfx950"). */
@@ -87,6 +90,9 @@ int afhip_device_info(int dev, char* name, int name_len, char* arch, int arch_le
  * out_dev    [G, n_cells] (stat) or [G, n_cells, D] of `dtype` — the reference's output
  *            layout and dtype (accumulation is float64, the store rounds to `dtype`,
  *            nb_kernels.py:257-268).
+ * D is unbounded, like the reference's loop over ddargs rows (nb_kernels.py:166,190,215): more rows than one pass over the
+ * cube holds (16) run as consecutive passes inside the call, each writing its own columns of out_dev.
+ * These calls build a temporary plan, own their scratch and synchronise `stream` before they return.
  * ---------------------------------------------------------------------------------- */
 int afhip_group_stat(const void* cube_dev, int dtype, int64_t T, int64_t n_cells,
                      const int64_t* bounds, int64_t G, int code, void* out_dev, void* stream);
@@ -119,8 +125,16 @@ void afhip_csr_destroy(afhip_csr* csr);
  * reference calls its kernels from dask's thread pool, nb_kernels.py:271-305) drives a handle of device r correctly.  What
  * must match is the data: afhip_plan_run / _run_temporal refuse (AFHIP_E_INVALID) a cube or a CSR that lives on another
  * device than the plan.  Entry points without a handle (afhip_group_*, afhip_transform, afhip_place_box, ...) run on the
- * device that owns their array argument.  `stream` must be a stream of that device (or NULL).
- * afhip_csr_device / afhip_plan_device: the device a handle was created on (-1 for NULL). */
+ * device that owns their array argument.  `stream` must be a stream of that device (or NULL).  The same holds for every other
+ * device pointer handed to a plan: the second cube of afhip_plan_bind_inter, the outputs (num / den / res / cells) and a
+ * caller-owned workspace are refused with AFHIP_E_INVALID when the runtime knows them to live on another device.
+ * afhip_csr_device / afhip_plan_device: the device a handle was created on (-1 for NULL).
+ *
+ * Threads.  Entry points without a handle are re-entrant.  An afhip_csr is immutable after creation (the run tables it
+ * caches on first use are built under its own lock): share ONE CSR between any number of threads and plans.  An afhip_plan is
+ * NOT re-entrant: it owns scratch in HBM, per-launch event pairs and the second-cube bindings, so two calls must never be
+ * inside the same plan at once — give every worker thread its own plan (plans are cheap: tables of a few KB) or serialise the
+ * calls; `aggfly_amd/engine.py` holds a per-plan lock around bind + run.  Two plans on two streams run concurrently. */
 int afhip_csr_device(const afhip_csr* csr);
 
 /* Replaces _scatter_block(block, region_idx, cell_idx, w_vals, n_regions)
@@ -139,6 +153,12 @@ int afhip_scatter_block(const afhip_csr* csr, const double* block_dev, int64_t n
  * like numpy's.  In-place (out_dev == x_dev with equal dtypes) is allowed. */
 int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, double arg,
                     const void* other_dev, int other_dtype, void* out_dev, int out_dtype, void* stream);
+
+/* Measuring aid (no counterpart in the reference): the streaming-read ceiling of THIS box for a time-major cube — a kernel with the
+ * temporal kernels' access pattern and no arithmetic (8 bytes per lane, single-wave workgroups, four non-temporal row loads in
+ * flight) launched `launches` times back to back over cube_dev [T rows of row_bytes bytes, row_bytes % 8 == 0]; ms_out[i] = the
+ * i-th launch's duration by HIP events.  Synchronises `stream`.  bench.py reports T * row_bytes / min(ms) beside the 8 TB/s spec peak. */
+int afhip_read_probe(const void* cube_dev, int64_t T, int64_t row_bytes, int launches, float* ms_out, void* stream);
 
 /* Ingestion helper (no counterpart in the reference, whose chunks are assembled by dask on the host,
  * aggfly/dataset/dataset.py:697-728): copies the part [st, st+nt) x [sy, sy+ny) x [sx, sx+nx) of a
@@ -228,17 +248,22 @@ int afhip_plan_device(const afhip_plan* plan);
  * output, whose time axis is the inner groups).  The pointer is read by every later run until it is bound again; the
  * caller keeps the memory alive.  A run with an unbound AFHIP_TF_INTER column fails with AFHIP_E_INVALID. */
 int afhip_plan_bind_inter(afhip_plan* plan, int column, const void* inter_dev, int dtype);
-/* Bytes of device scratch the plan needs (per-chunk partials + the cell-major panel). */
+/* Bytes of device scratch a run needs.  afhip_plan_workspace_bytes: the temporal stage alone (per-chunk partials; what
+ * afhip_plan_run_temporal takes).  afhip_plan_run_workspace_bytes: a whole afhip_plan_run against `csr` (partials + the
+ * cell-major panel + the [rows][P][K+1] sums of that table).  A caller-owned workspace must be 256-byte aligned. */
 int64_t afhip_plan_workspace_bytes(const afhip_plan* plan);
+int64_t afhip_plan_run_workspace_bytes(const afhip_plan* plan, const afhip_csr* csr);
 /* Human-readable lowering (kernel variant, chunks, slots) into buf; returns bytes needed. */
 int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_len);
 
 /* Temporal stage only: cells_dev[K, P, n_cells] float64 = the per-cell, per-period value
  * of every column (NaN where the reference's temporal stage yields NaN).  This is what
  * aggregate_time returns before the spatial step (aggregate.py:160-162).
- * workspace_dev may be NULL (the plan then allocates and caches its own). */
+ * workspace_dev / workspace_bytes: caller-owned scratch of at least afhip_plan_workspace_bytes(plan) (AFHIP_E_INVALID when
+ * smaller), or NULL / 0: the plan allocates and caches its own (hipMalloc; a plan that outgrows it keeps the old block
+ * until afhip_plan_destroy, so that no run ever waits for the device in a hipFree). */
 int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cells_dev,
-                            void* workspace_dev, void* stream);
+                            void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Whole path: temporal stage, shared validity, CSR weighted sums, divide.
  * num_dev [K, R, P], den_dev [R, P], res_dev [K, R, P] float64 (num/den may be NULL);
@@ -248,12 +273,16 @@ int afhip_plan_run_temporal(afhip_plan* plan, const void* cube_dev, double* cell
  * several output periods whose table allows it, weighted sums per region formed inside the temporal kernel at every period end (the
  * per-cell period values are then never written); bin-count plans gather their packed records.  The CSR handle caches the tables of
  * the last route on first use (it is entered through a const pointer but guarded by its own lock).
+ * workspace_dev / workspace_bytes: caller-owned scratch of at least afhip_plan_run_workspace_bytes(plan, csr), or NULL / 0 for
+ * plan-owned scratch as above.  Nothing on the run path allocates, frees or synchronises when the workspace is the caller's
+ * (the Python host hands every plan a block of torch's caching allocator: where a process's first hipMalloc'ed scratch lands
+ * decides 7-9 % of the bin-count kernel on some boxes, profiles/r03_plan_order_probe.txt; afhip_plan_describe names which it was).
  * If kernel_ms is not NULL the call records HIP events on `stream` around the temporal
  * kernel and around the whole sequence, synchronises the stream, and writes
  * kernel_ms[0] = temporal kernel ms, kernel_ms[1] = whole sequence ms. */
 int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhip_csr* csr,
                    double* num_dev, double* den_dev, double* res_dev, double* cells_dev,
-                   void* workspace_dev, void* stream, float* kernel_ms);
+                   void* workspace_dev, int64_t workspace_bytes, void* stream, float* kernel_ms);
 
 /* Per-launch device timing of the dominant (temporal) kernel without host syncs in the
  * timed region: _begin arms up to max_launches HIP event pairs; every afhip_plan_run then

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--short", action="store_true", help="forward and reversed series only (for counter passes)")
     ap.add_argument("--dummy-mb", type=int, default=0, help="a sacrificial HBM allocation of this size made after the cube, before any plan")
+    ap.add_argument("--ws", default="torch", choices=["torch", "library", "mix"], help="where the plans' scratch comes from (see wsmode below)")
     a = ap.parse_args()
     dt = torch.float64 if a.dtype == "f64" else torch.float32
     C = a.ny * a.nx
@@ -66,7 +67,13 @@ def main():
     dummy = torch.empty(a.dummy_mb << 20, dtype=torch.uint8, device="cuda") if a.dummy_mb else None
     plans = [hip.FusedPlan(a.T, C, code, ib, ob, cols) for _ in range(a.n)]
     print(plans[0].describe(), flush=True)
-    outs = [p.run(cube, csr) for p in plans]          # warm: workspaces allocated, results buffers kept
+    # --ws torch (round 4's default of the Python host): every plan's scratch is a block of torch's caching allocator, handed to the
+    # library as a caller-owned workspace; library: the library's own hipMalloc (round 3, and what a bare C caller gets); mix: even
+    # plans library, odd plans torch, in one process
+    def wsmode(i):
+        return {"torch": None, "library": "library"}.get(a.ws, "library" if i % 2 == 0 else None)
+    print("scratch: " + ", ".join(f"plan{i}={'library' if wsmode(i) else 'torch'}" for i in range(a.n)), flush=True)
+    outs = [p.run(cube, csr, workspace=wsmode(i)) for i, p in enumerate(plans)]          # warm: workspaces allocated, results buffers kept
     torch.cuda.synchronize()
 
     def series(order, rounds, sleep=0.0):
@@ -75,7 +82,7 @@ def main():
             for i in order:
                 if sleep:
                     time.sleep(sleep)
-                ms[i].append(plans[i].run(cube, csr, timed=True, out=outs[i])["kernel_ms"][0])
+                ms[i].append(plans[i].run(cube, csr, timed=True, out=outs[i], workspace=wsmode(i))["kernel_ms"][0])
         return ms
 
     def show(name, ms, order):
@@ -95,7 +102,7 @@ def main():
     for i in fwd[:2]:
         plans[i].profile_begin(20)
         for _ in range(20):
-            plans[i].run(cube, csr, out=outs[i])
+            plans[i].run(cube, csr, out=outs[i], workspace=wsmode(i))
         torch.cuda.synchronize()
         ms = plans[i].profile_end()
         print(f"plan{i} 20 launches, no sync:  " + " ".join(f"{v:.3f}" for v in ms), flush=True)
@@ -108,18 +115,18 @@ def placement(a_plans, cube, csr, outs):
     for i in (0, 1):
         p = a_plans[i]
         for trial in range(3):
-            ws = torch.empty(p.workspace_bytes(), dtype=torch.uint8, device="cuda")
+            ws = torch.empty(p.workspace_bytes(csr), dtype=torch.uint8, device="cuda")
             ms = [p.run(cube, csr, timed=True, out=outs[i], workspace=ws)["kernel_ms"][0] for _ in range(8)]
             print(f"plan{i} caller workspace #{trial} @0x{ws.data_ptr():x}: median {np.median(ms):.3f}", flush=True)
             del ws
-        ms = [p.run(cube, csr, timed=True, out=outs[i])["kernel_ms"][0] for _ in range(8)]
-        print(f"plan{i} own workspace again:            median {np.median(ms):.3f}", flush=True)
+        ms = [p.run(cube, csr, timed=True, out=outs[i], workspace="library")["kernel_ms"][0] for _ in range(8)]
+        print(f"plan{i} library-owned scratch again:    median {np.median(ms):.3f}", flush=True)
 
 
 def offsets(a_plans, cube, csr, outs):
     """a caller workspace at different offsets inside ONE larger buffer: does the address itself matter?"""
     p = a_plans[1]
-    need = p.workspace_bytes()
+    need = p.workspace_bytes(csr)
     big = torch.empty(need + (1 << 30), dtype=torch.uint8, device="cuda")
     print(f"cube @0x{cube.data_ptr():x} ({cube.numel() * cube.element_size()} bytes), big buffer @0x{big.data_ptr():x}", flush=True)
     for off in (0, 256, 4096, 65536, 1 << 20, 2 << 20, 3 << 20, 16 << 20, 64 << 20, 256 << 20, 512 << 20, (1 << 30) - 4096):

@@ -30,6 +30,10 @@ def columns(plan):
             [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)], False
     if plan == "c1":
         return [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2)], False
+    if plan == "dd":        # degree days alone: a threshold slot and no statistic
+        return [dict(inner="dd", inner_args=(10, 30, 0), outer="sum")], False
+    if plan == "dd13":      # thirteen degree-day columns (multi_dd with thirteen threshold pairs)
+        return [dict(inner="dd", inner_args=(float(t), float(t) + 7, 0), outer="sum") for t in range(-10, 29, 3)], False
     if plan == "mean":      # daily mean of short groups -> annual sum (tmin/tmax pairs, 6-hourly data)
         return [dict(inner="mean", outer="sum")], False
     if plan == "ref":       # the reference's published benchmark shape: mean@date -> power[1..4] -> sum@month (use --periods 12)

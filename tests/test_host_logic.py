@@ -29,7 +29,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.afhip_abi_version() == 3
+    assert lib.afhip_abi_version() == hip.ABI_VERSION == 4
+    assert int(re.search(r"#define AFHIP_ABI_VERSION (\d+)", hdr).group(1)) == hip.ABI_VERSION
     assert isinstance(hip.device_count(), int)
 
 
@@ -438,7 +439,7 @@ def test_plan_and_csr_caches_are_keyed_by_device(monkeypatch):
             self.device_index = device
             made.append(("plan", device))
 
-        def workspace_bytes(self):
+        def scratch_bytes(self):
             return 0
 
     class FakeCSR:

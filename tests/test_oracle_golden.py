@@ -193,3 +193,40 @@ def test_T4_sine_parts_are_the_single_sine_integrals():
             assert abs(cool - want_c) <= 1e-9 * max(1.0, abs(want_c)), (tmin, tmax, thr, cool, want_c)
             assert abs(heat - want_h) <= 1e-9 * max(1.0, abs(want_h)), (tmin, tmax, thr, heat, want_h)
             assert abs((cool - heat) - (tavg - thr)) <= 1e-9 * max(1.0, abs(tavg - thr))        # max(x,0) - max(-x,0) = x, averaged
+
+
+def _sine_fixture_errors(get_value):
+    """Errors of an implementation over tests/golden/sine_dd_fixtures.json (exact values at 50 digits, mpmath:
+    tests/golden/make_sine_fixtures.py).  ``get_value(case, ddargs_row) -> float``.  -> {class: (max abs, max rel where |v| > 1e-6,
+    max abs / scale)}, scale = max(window range, |v|); NaN cases (|r| > 1 in the heating form) must be NaN."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sine_dd_fixtures.json")))
+    dd = np.array(fx["ddargs"])
+    worst = {"interior": [0.0, 0.0, 0.0], "near_edge": [0.0, 0.0, 0.0]}
+    for c in fx["cases"]:
+        got = get_value(c, dd[c["row"]])
+        if c["value"] is None:
+            assert np.isnan(got), c
+            continue
+        v, w = c["value_f64"], np.array(c["window"])
+        ae = abs(got - v)
+        t = worst["near_edge" if " * rng inside " in c["tag"] else "interior"]
+        t[0] = max(t[0], ae)
+        t[1] = max(t[1], ae / abs(v) if abs(v) > 1e-6 else 0.0)
+        t[2] = max(t[2], ae / max(w.max() - w.min(), abs(v)))
+    return worst, len(fx["cases"])
+
+
+def test_T4_oracle_against_the_50_digit_sine_fixtures():
+    """Both restatements of `_block_sine_dd` (`nb_kernels.py:202-251`: the plain-C port and the numpy one) against the exact
+    single-sine integrals.  What the reference's own arithmetic achieves, so that the GPU test's bound can be read against it:
+    away from the window's edges 2e-14 relative; with a threshold within 1e-3 ... 1e-9 of the range from an edge the closed
+    forms lose digits in acos / sqrt(1 - r^2): up to ~4e-9 RELATIVE (on values of 1e-5 ... 1e-3), 3e-13 absolute, 3e-14 of
+    the window's scale — i.e. the reference's libm path is itself only good to rtol 1e-8 there, in absolute terms excellent."""
+    for name, fn in (("cport", lambda w, d: cport.block_sine_dd(w, np.array([0, len(w)]), d[None, :])[0, 0, 0, 0]),
+                     ("numpy", lambda w, d: rt.numba_sine_dd(w, np.array([0, len(w)]), d[None, :])[0, 0, 0, 0])):
+        worst, n = _sine_fixture_errors(lambda c, d: float(fn(np.array(c["window"])[:, None, None], d)))
+        assert n > 2000
+        assert worst["interior"][1] <= 2e-14 and worst["interior"][2] <= 5e-15, (name, worst)
+        assert worst["near_edge"][0] <= 5e-13 and worst["near_edge"][2] <= 5e-14 and worst["near_edge"][1] <= 1e-8, (name, worst)
+        assert worst["near_edge"][1] > 1e-10, (name, worst)       # the libm closed form is NOT good to 1e-10 relative near the edges
