@@ -604,13 +604,24 @@ static int64_t stat_range(const char* path, const int64_t* offsets, const int64_
     return sz;
 }
 
-/* One piece of a file: open, read, close.  -> bytes read (short = failure). */
-static int64_t read_piece_of(const char* path, uint8_t* dst, int64_t len, int64_t off, int nt_copy) {
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return -1;
-    const int64_t done = read_piece(fd, dst, len, off, nt_copy);
-    close(fd);
-    return done;
+/* One piece of a file through the calling thread's one-entry descriptor cache: consecutive pieces of a file (the dynamic schedule
+ * hands a thread runs of them) share ONE open — at most one descriptor per thread is ever held, so a batch of any size stays
+ * under the descriptor limit (every file held open at once ran into EMFILE on large batches and reported existing chunks as
+ * absent), without an open / close per MiB.  After the open the file is fstat'ed again: one that shrank since the sizes were
+ * taken (replaced while the batch was being read) is reported as such (-2), not as a short read.
+ * -> bytes read; -1: could not be opened / read, -2: the file changed. */
+typedef struct { int64_t file; int fd; } fd_cache;
+static int64_t read_piece_of(fd_cache* fc, int64_t file, const char* path, uint8_t* dst, int64_t len, int64_t off, int nt_copy) {
+    if (fc->file != file) {
+        if (fc->fd >= 0) close(fc->fd);
+        fc->file = file;
+        fc->fd = open(path, O_RDONLY);
+    }
+    if (fc->fd < 0) return -1;
+    struct stat stt;
+    if (fstat(fc->fd, &stt) != 0) return -1;
+    if (off + len > (int64_t)stt.st_size) return -2;
+    return read_piece(fc->fd, dst, len, off, nt_copy);
 }
 
 /* Reads and decodes byte ranges of chunk files -> dsts[i] on an OpenMP team (no Python between chunks):
@@ -639,26 +650,37 @@ int afcodec_decode_ranges(int kind, int64_t n, const char* const* paths, const i
         first[0] = 0;
         for (int64_t i = 0; i < n; ++i) first[i + 1] = first[i] + (results[i] > 0 ? (results[i] + PIECE - 1) / PIECE : 0);
         const int64_t npieces = first[n];
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-        for (int64_t q = 0; q < npieces; ++q) {
-            int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
-            while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
-            while (first[lo + 1] <= q) ++lo;                      /* (files without pieces share a boundary) */
-            const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            const int64_t done = read_piece_of(paths[lo], (uint8_t*)dsts[lo] + at, len, offs[lo] + at, nt_copy_default());
-            if (done != len) {
+        int changed = 0;
+#pragma omp parallel num_threads(nthreads)
+        {
+            fd_cache fc = {-1, -1};
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t q = 0; q < npieces; ++q) {
+                int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
+                while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
+                while (first[lo + 1] <= q) ++lo;                      /* (files without pieces share a boundary) */
+                const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
+                int64_t o;
+#pragma omp atomic read
+                o = offs[lo];
+                if (o < 0) continue;                                  /* an earlier piece of this file failed */
+                const int64_t done = read_piece_of(&fc, lo, paths[lo], (uint8_t*)dsts[lo] + at, len, o + at, nt_copy_default());
+                if (done != len) {
 #pragma omp atomic write
-                offs[lo] = -1;                                    /* marks the file as failed */
+                    offs[lo] = done == -2 ? -2 : -1;                  /* marks the file as failed (-2: it changed under the read) */
+                }
             }
+            if (fc.fd >= 0) close(fc.fd);
         }
         for (int64_t i = 0; i < n; ++i) {
-            if (results[i] >= 0 && offs[i] < 0) results[i] = AFCODEC_E_FORMAT;
+            if (results[i] >= 0 && offs[i] < 0) { changed += offs[i] == -2; results[i] = AFCODEC_E_FORMAT; }
             if (results[i] < 0 && results[i] != -100) bad += 1;
         }
         free(first); free(offs);
         if (bad) {
             for (int64_t i = 0; i < n; ++i)
                 if (results[i] == AFCODEC_E_SIZE) return fail(AFCODEC_E_CODEC, "raw chunk larger than its destination (see results[])");
+            if (changed) return fail(AFCODEC_E_CODEC, "a chunk file shrank between stat and read: the store is being rewritten (see results[])");
             return fail(AFCODEC_E_CODEC, "one or more chunk files could not be read (see results[])");
         }
         return AFCODEC_OK;
@@ -759,23 +781,34 @@ int afcodec_read_packed(int64_t n, const char* const* paths, const int64_t* offs
     int too_big = !bad && out_off[n] > cap;
     if (!bad && !too_big) {
         const int64_t npieces = first[n];
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-        for (int64_t q = 0; q < npieces; ++q) {
-            int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
-            while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
-            while (first[lo + 1] <= q) ++lo;
-            const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
-            const int64_t done = read_piece_of(paths[lo], (uint8_t*)dst + out_off[lo] + at, len, foff[lo] + at, nt_copy);
-            if (done != len) {
+#pragma omp parallel num_threads(nthreads)
+        {
+            fd_cache fc = {-1, -1};
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t q = 0; q < npieces; ++q) {
+                int64_t lo = 0, hi = n;                               /* the file of piece q: first[lo] <= q < first[lo + 1] */
+                while (hi - lo > 1) { const int64_t mid = (lo + hi) / 2; if (first[mid] <= q) lo = mid; else hi = mid; }
+                while (first[lo + 1] <= q) ++lo;
+                const int64_t at = (q - first[lo]) * PIECE, len = results[lo] - at < PIECE ? results[lo] - at : PIECE;
+                int64_t o;
+#pragma omp atomic read
+                o = foff[lo];
+                if (o < 0) continue;
+                const int64_t done = read_piece_of(&fc, lo, paths[lo], (uint8_t*)dst + out_off[lo] + at, len, o + at, nt_copy);
+                if (done != len) {
 #pragma omp atomic write
-                foff[lo] = -1;                                    /* marks the file as failed */
+                    foff[lo] = done == -2 ? -2 : -1;                  /* marks the file as failed (-2: it changed under the read) */
+                }
             }
+            if (fc.fd >= 0) close(fc.fd);
         }
     }
+    int changed = 0;
     for (int64_t i = 0; i < n; ++i)
-        if (results[i] >= 0 && foff[i] < 0) { results[i] = AFCODEC_E_FORMAT; bad += 1; }
+        if (results[i] >= 0 && foff[i] < 0) { changed += foff[i] == -2; results[i] = AFCODEC_E_FORMAT; bad += 1; }
     free(first); free(foff);
     if (too_big) return fail(AFCODEC_E_SIZE, "read_packed: the files do not fit the buffer");
+    if (changed) return fail(AFCODEC_E_CODEC, "a chunk file shrank between stat and read: the store is being rewritten (see results[])");
     return bad ? fail(AFCODEC_E_CODEC, "one or more chunk files could not be read (see results[])") : AFCODEC_OK;
 }
 

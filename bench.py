@@ -463,6 +463,13 @@ def run_other_configs(torch, steps=10, warmup=10):      # the first ~10 launches
                    "kernel": desc.split()[0].replace("variant=", "") + ("_rf" if "last-run=region-fused" in desc else ""), "spatial_route": route,
                    "kernel_ms_mean": k_ms, "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
                    "algorithmic_bytes_per_launch": T * C * elem, "regions": R, "nnz": int(csr.nnz)}
+            try:      # PMC-measured HBM bytes per launch of this shape's kernel, where a counter pass over bench.py itself has been committed
+                te = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{c['name'].lower()}_{c['dtype']}_T{T}_C{C}")
+                if te:
+                    row.update({"traffic": te.get("hbm_bytes_per_launch"), "traffic_build": te.get("build"), "traffic_source": te.get("source"),
+                                "traffic_measured_on_this_build": te.get("build") == lib_build_id()})
+            except (OSError, ValueError):
+                pass
             vc = valu.get(c["name"])
             if vc:      # a VALU-bound kernel: its own roofline beside the HBM figure
                 inst = vc["valu_inst_per_cell_step"] * T * C / (k_ms * 1e-3)

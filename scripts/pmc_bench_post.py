@@ -61,20 +61,47 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     json.dump({f"c2_f64_T{T}_C{C}": ent}, open(f"{o}/traffic_{tag}.json", "w"), indent=1)
     print("traffic:", json.dumps(ent, indent=1))
 
-# ---- VALU counts of the C5 kernel
-v = {}
-for f in glob.glob(f"{o}/pmc_bench_{tag}_c5_*"):
-    if os.path.isdir(f):
-        v.update(counters(f"{f}/**/*counter_collection.csv", "2, 0, 2, 8, "))       # the pair-mode sine_dd variant (float, 0, 2, 2, 0, 2, 8, FEAT)
-if "SQ_INSTS_VALU" in v:
+# ---- traffic of the configs[3] kernel (13 bins per year, LDS histogram with arithmetic edges, f32): passes with AGGFLY_BENCH_ONLY=C4
+c4 = {}
+for nm in ("FETCH_SIZE", "WRITE_SIZE"):
+    c4.update(counters(f"{o}/pmc_bench_{tag}_c4_{nm}/**/*counter_collection.csv", "k_fused_temporal<float, 0, 1, 0, 16, 16, 8, "))
+if "FETCH_SIZE" in c4 and "WRITE_SIZE" in c4:
+    T4, C4 = 91615, 180 * 288
+    rd, wr = c4["FETCH_SIZE"][0] * 2 * 1024, c4["WRITE_SIZE"][0] * 1024
+    ent = {"kernel": c4["FETCH_SIZE"][2].replace("void afhip::", ""), "FETCH_SIZE_KiB": c4["FETCH_SIZE"][0], "WRITE_SIZE_KiB": c4["WRITE_SIZE"][0],
+           "launches_averaged": c4["FETCH_SIZE"][1], "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+           "algorithmic_bytes_per_launch": T4 * C4 * 4, "ratio_to_algorithmic": (rd + wr) / (T4 * C4 * 4), "build": build_id(),
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py's own C4 run (AGGFLY_BENCH_ONLY=C4); "
+                     "FETCH_SIZE doubled per MI355X_MICROARCH.md", "source": f"profiles/{rnd}_pmc_traffic_bench_{tag}.json (scripts/{rnd}_bench_profiles.sh)"}
+    try:
+        cur = json.load(open(f"{o}/traffic_{tag}.json"))
+    except (OSError, ValueError):
+        cur = {}
+    cur[f"c4_f32_T{T4}_C{C4}"] = ent
+    json.dump(cur, open(f"{o}/traffic_{tag}.json", "w"), indent=1)
+    print("traffic C4:", json.dumps(ent, indent=1))
+
+# ---- VALU counts of the C5 kernel (the SURVEY 8d field) and of the same kernel on the iid cube (C5_iid: its hostile case)
+out_v = {}
+for cfg, sub in (("C5", "c5"), ("C5_iid", "c5iid")):
+    v = {}
+    for f in glob.glob(f"{o}/pmc_bench_{tag}_{sub}_*"):
+        if os.path.isdir(f):
+            v.update(counters(f"{f}/**/*counter_collection.csv", "2, 0, 2, 8, "))       # the pair-mode sine_dd variant (float, 0, 2, 2, 0, 2, 8, FEAT)
+    if "SQ_INSTS_VALU" not in v:
+        continue
     T5, C5 = 730, 1801 * 3600
     per = v["SQ_INSTS_VALU"][0] * 64 / (T5 * C5)
     ent = {"valu_inst_per_cell_step": per, "kernel": v["SQ_INSTS_VALU"][2].replace("void afhip::", ""), "build": build_id(),
            "counters_per_launch": {k: x[0] for k, x in v.items()},
-           "source": f"profiles/{rnd}_pmc_valu_bench_{tag}.json: SQ_INSTS_VALU x 64 lanes / (T x cells), rocprofv3 --pmc over bench.py's own C5 run "
-                     "(AGGFLY_BENCH_ONLY=C5, ERA5-like (tmin, tmax) field)"}
+           "source": f"profiles/{rnd}_pmc_valu_bench_{tag}.json: SQ_INSTS_VALU x 64 lanes / (T x cells), rocprofv3 --pmc over bench.py's own {cfg} run "
+                     f"(AGGFLY_BENCH_ONLY={cfg}, " + ("ERA5-like (tmin, tmax) field)" if cfg == "C5" else "iid cube)")}
     if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         ent["valu_issue_utilisation"] = v["SQ_ACTIVE_INST_VALU"][0] * 4 / (v["GRBM_GUI_ACTIVE"][0] / 8 * 256 * 4)
-    json.dump({"C5": ent}, open(f"{o}/valu_counts_{tag}.json", "w"), indent=1)
-    print("valu:", json.dumps(ent, indent=1))
+    if "SQ_WAIT_INST_ANY" in v and "SQ_WAVE_CYCLES" in v:
+        ent["share_of_wave_cycles_waiting"] = v["SQ_WAIT_INST_ANY"][0] / v["SQ_WAVE_CYCLES"][0]
+    out_v[cfg] = ent
+if out_v:
+    json.dump(out_v, open(f"{o}/valu_counts_{tag}.json", "w"), indent=1)
+    print("valu:", json.dumps(out_v, indent=1))

@@ -82,8 +82,8 @@ def test_device_sine_forms_against_the_50_digit_fixtures(torch_cuda, monkeypatch
                     t[1] = max(t[1], ae / abs(v) if abs(v) > 1e-6 else 0.0)
                     t[2] = max(t[2], ae / scale)
                 n_cases += len(sel)
-            variant = desc.split()[0].replace("variant=", "")
-            report[f"L={L} {form} ({variant})"] = {"cases": n_cases, **{k: {"max_abs": v[0], "max_rel_above_1e-6": v[1], "max_abs_over_scale": v[2]} for k, v in worst.items()}}
+            variants = " | ".join(sorted(v for (l2, f2, v) in seen if l2 == L and f2 == form))
+            report[f"L={L} {form} ({variants})"] = {"cases": n_cases, **{k: {"max_abs": v[0], "max_rel_above_1e-6": v[1], "max_abs_over_scale": v[2]} for k, v in worst.items()}}
     # the forms really were the ones named (a threshold pair given in reverse order, t0 > t1, takes the general pair form)
     by = {}
     for L, f, v in seen:
