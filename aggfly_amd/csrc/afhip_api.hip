@@ -324,6 +324,7 @@ struct afhip_plan {
     int last_ws = 0;                        // 1: the last run used a caller-owned workspace, 2: plan-owned (afhip_plan_describe tells)
     // experiment knobs, read once when the plan is created (never on the run path)
     bool no_slot_spmm = false, no_slots_divide = false, no_counts_divide = false;
+    int rf_layout = -1;                               // AFHIP_RF_LAYOUT=slot|run: layout of the run sums forced (rf_run_major)
     int slot_spmm_sub = 0, slot_spmm_order = -1;      // AFHIP_SLOT_SPMM_ORDER=v|p: SlotSpmmArgs::p_major forced off / on
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
@@ -837,7 +838,9 @@ static int build_chunks(afhip_plan* pl, int vec) {
     // Plans that already get eight chunks or more keep them (configs[2]'s shape, 14 chunks for 40 years: 40 measured 0.5 % behind).
     bool period_chunks = false;
     if (P > 1 && !hist && want_chunks < 8 && !getenv("AFHIP_WGS_PER_CU") && !getenv("AFHIP_NO_PERIOD_CHUNKS")) {
-        const int64_t by_period = std::min<int64_t>(P, std::max<int64_t>(1, (int64_t)262144 / std::max<int64_t>(pl->tiles, 1)));
+        int64_t wg_cap = 262144;                                    // workgroups a period-chunked launch may have
+        if (const char* e = getenv("AFHIP_PERIOD_CHUNK_WGS")) wg_cap = std::max<int64_t>(1024, atoll(e));      // experiment knob
+        const int64_t by_period = std::min<int64_t>(P, std::max<int64_t>(1, wg_cap / std::max<int64_t>(pl->tiles, 1)));
         // (a handful of period chunks makes a handful of occupancy rounds with a costly last one: P = 4 measured 2-4 % behind one chunk)
         if (by_period >= 8) { want_chunks = by_period; period_chunks = true; }
     }
@@ -1046,7 +1049,9 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // 1801 x 3600 f32); with more columns the lean group end wins (profiles/r03_pairs_mean_poly.txt)
     // (four-row groups: the lean form measured ahead of the ring at every column count, profiles/r03_quad_groups.txt)
     if (pairs && pl->stat == 1) {
-        int min_k = quad_len ? 1 : 3;
+        // (three-row groups on float32: one- and two-column plans stream faster through the ring, 4.59 / 4.94 against 4.93 / 5.04 ms on
+        // 1801 x 3600; from three columns on, and on float64 at every count, the lean form is ahead: profiles/r04_three_row_groups.txt)
+        int min_k = quad_len ? ((glen == 3 && desc->dtype == AFHIP_F32) ? 3 : 1) : 3;
         if (const char* e = getenv("AFHIP_LEAN_STAT1_MIN_K")) min_k = atoi(e);      // experiment knob
         if (!lean || pl->K < min_k) pairs = lean = lean_sine = false;
     }
@@ -1243,6 +1248,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->no_slot_spmm = env_flag("AFHIP_NO_SLOT_SPMM");            // keep k_combine_slots + k_csr_spmm on every route
     pl->no_slots_divide = getenv("AFHIP_NO_SLOTS_DIVIDE") != nullptr;
     pl->no_counts_divide = getenv("AFHIP_NO_COUNTS_DIVIDE") != nullptr;
+    if (const char* e = getenv("AFHIP_RF_LAYOUT")) pl->rf_layout = (e[0] == 'r') ? 1 : 0;
     if (const char* e = getenv("AFHIP_SLOT_SPMM_ORDER")) pl->slot_spmm_order = (e[0] == 'p') ? 1 : 0;
     if (const char* e = getenv("AFHIP_SLOT_SPMM_SUB")) { const int sb = atoi(e); if (sb == 8 || sb == 16 || sb == 32 || sb == 64) pl->slot_spmm_sub = sb; }
     pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
@@ -1337,6 +1343,17 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     return n + 1;
 }
 
+// Layout of the run sums: slot-major [slots][runs][K + 1] (a period end's stores of one wave side by side: one or two cache lines per
+// store instruction) or run-major [runs][slots][K + 1] (a run's periods side by side: k_rf_reduce reads whole lines instead of K + 1
+// doubles a slot apart — its time falls to a half ... a fifth — but every run a wave closes is then a cache line of its own at every
+// period end, which costs the float32 streaming kernels 7 % at 24 - 73 periods).  Measured (profiles/r04_rf_layout.txt): run-major pays
+// where the reduce side is large — from ~1e8 (run, period, column) gathers: daily sine_dd on 0.1 deg 16.4 -> 12.7 ms, weekly 5.41 ->
+// 5.0, the float64 daily configs[1] panel 4.66 -> 4.25, 6-hourly daily 4.77 -> 4.40 — and loses below (float32 daily degree days 2.33 -> 2.47).
+static bool rf_run_major(const afhip_plan* pl, const afhip_csr::RfTab* rf) {
+    if (pl->rf_layout >= 0) return pl->rf_layout == 1;
+    return (double)rf->n_runs * (double)pl->desc.P * (double)(pl->K + 1) >= 1e8;
+}
+
 static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st, const afhip_csr::RfTab* rf = nullptr) {
     if (pl->chunks.empty()) return AFHIP_OK;
     for (int j = 0; j < pl->K; ++j)
@@ -1373,7 +1390,9 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     const void* fn = pl->variant->fn;
     if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area (no LDS of its own)
         fn = pl->variant_rf->fn;
-        fa.rf_w = rf->w2.p; fa.rf_key = rf->key.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial; fa.rf_nruns = rf->n_runs;
+        fa.rf_w = rf->w2.p; fa.rf_key = rf->key.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial;
+        fa.rf_slot_stride = rf_run_major(pl, rf) ? (int64_t)(pl->K + 1) : rf->n_runs * (pl->K + 1);
+        fa.rf_run_stride = rf_run_major(pl, rf) ? pl->n_slots * (pl->K + 1) : (int64_t)(pl->K + 1);
         fa.rf_x = rf->n_xcells ? rf->xidx.p : nullptr; fa.rf_nx = rf->n_xcells;
         fa.rf_ex = partial + pl->n_slots * rf->n_runs * (pl->K + 1);           // behind the run sums
     }
@@ -1560,7 +1579,8 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
             for (int j = 0; j < plan->K; ++j) if (plan->cols[(size_t)j].outer == OUT_MEAN) mean_mask |= 1u << j;
             hipLaunchKernelGGL(k_rf_reduce, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, (const double*)partial, rf->reg_ptr.p, rf->reg_runs.p,
                                plan->d_slot_ptr.p, plan->d_ob.p, mean_mask, (const double*)(partial + plan->n_slots * rf->n_runs * (K + 1)), rf->n_xcells,
-                               rf->xreg_ptr.p, rf->xcell.p, rf->xw.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs);
+                               rf->xreg_ptr.p, rf->xcell.p, rf->xw.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs,
+                               rf_run_major(plan, rf) ? (int64_t)(K + 1) : rf->n_runs * (K + 1), rf_run_major(plan, rf) ? plan->n_slots * (K + 1) : (int64_t)(K + 1));
             HIP_TRY(hipGetLastError());
         }
     } else if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {

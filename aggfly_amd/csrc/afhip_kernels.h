@@ -139,8 +139,8 @@ struct FusedArgs {
     // gather kernel over them does not run.
     const double* rf_w;            // device [C][2]: weight of the cell's first / second table entry (0: none)
     const int32_t* rf_tile;        // device [wave tiles][2][2]: {first run, runs} of entry e in wave tile t (64 * VEC cells)
-    double* rf_out;                // device [n_slots][runs][K + 1]
-    int64_t rf_nruns;
+    double* rf_out;                // device: the sum of (slot, run, column k) at  slot * rf_slot_stride + run * rf_run_stride + k  —
+    int64_t rf_slot_stride, rf_run_stride;      // run-major ([runs][n_slots][K + 1]) for plans of many periods: a region's periods side by side for k_rf_reduce
     // cells that sit in MORE than two regions (junctions of polygons): their third, fourth ... entries are "extras" — such a cell
     // also writes its validated period values to rf_ex[slot][rf_x[cell]][K + 1], and k_rf_reduce adds the extras of a region from there
     const int32_t* rf_x;           // device [C]: index of the cell among the cells with extras, -1 = none; null: the table has none
@@ -960,9 +960,9 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
             const int need = rf_need[e];
             if (!(need & 128)) continue;                             // (uniform) no cell of this tile has an entry e
             const uint32_t bits = rfbits >> (16 * e), rid = rfrid >> (16 * e);
-            double* out0 = a.rf_out + ((int64_t)at_slot * a.rf_nruns + rf_first[e]) * K1;
-            double* dst0 = out0 + (int)(rid & 0xffu) * K1;           // where this lane's cells store, if they end a run
-            double* dst1 = out0 + (int)((rid >> 8) & 0xffu) * K1;
+            double* out0 = a.rf_out + (int64_t)at_slot * a.rf_slot_stride + (int64_t)rf_first[e] * a.rf_run_stride;
+            double* dst0 = out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride;           // where this lane's cells store, if they end a run
+            double* dst1 = out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride;
             // columns in blocks of CB: inside a block the shuffles of the columns are independent and overlap; a step is skipped
             // by the whole wave when no run of the tile needs it (county-sized runs span a few lanes: two or three steps of six)
             constexpr int CB = 8;

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
                                                   const int64_t* __restrict__ outer_bounds, uint32_t mean_mask,
                                                   const double* __restrict__ ex, int64_t nx, const int64_t* __restrict__ xreg_ptr,
                                                   const int32_t* __restrict__ xcell, const double* __restrict__ xw,
-                                                  double* __restrict__ sums, int64_t R, int64_t P, int K1, int64_t n_runs) {
+                                                  double* __restrict__ sums, int64_t R, int64_t P, int K1, int64_t n_runs,
+                                                  int64_t slot_stride, int64_t run_stride) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
     if (tid >= R * P * K1) return;
     const int k = (int)(tid % K1);
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
     const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
     double acc = 0.0;
     if (s1 != s0) {
-        const double* base = rf_out + (int64_t)s0 * n_runs * K1 + k;
+        const double* base = rf_out + (int64_t)s0 * slot_stride + k;
         // eight independent gathers in flight, then the adds in run order (one at a time the walk is a chain of memory round trips:
         // 70 us for the 30 runs per region of the reference's benchmark shape)
         int64_t q = reg_ptr[r];
@@ -536,11 +537,11 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
         for (; q + 8 <= q1; q += 8) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)reg_runs[q + u] * K1];
+            for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)reg_runs[q + u] * run_stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, v[u]);
         }
-        for (; q < q1; ++q) acc = __dadd_rn(acc, base[(int64_t)reg_runs[q] * K1]);
+        for (; q < q1; ++q) acc = __dadd_rn(acc, base[(int64_t)reg_runs[q] * run_stride]);
         if (nx) {       // the region's entries on cells that sit in three or more regions (their third, fourth ... entries), in table order
             const double* xb = ex + (int64_t)s0 * nx * K1 + k;
             for (int64_t x = xreg_ptr[r]; x < xreg_ptr[r + 1]; ++x) acc = __dadd_rn(acc, __dmul_rn(xw[x], xb[(int64_t)xcell[x] * K1]));

@@ -1019,7 +1019,7 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
 def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeypatch):
     """The region-fused period ends add a run's cells in cell order and a region's runs in run order; runs are cut per wave TILE (64
     cells per lane-cell), not per workgroup or chunk — so single-wave (the default) or four-wave workgroups, one time chunk per period or two
-    periods per chunk, a caller-owned workspace or the plan's own: the same bits."""
+    periods per chunk, a caller-owned workspace or the plan's own, run sums laid slot-major or run-major: the same bits."""
     from aggfly_amd import hip
     torch = torch_cuda
     T, ny, nx = 24 * 24, 160, 512                                    # 1280 single-wave tiles
@@ -1047,7 +1047,9 @@ def test_region_fused_sums_do_not_depend_on_the_launch_shape(torch_cuda, monkeyp
 
     base_desc, base = run({})
     assert "wg=64" in base_desc and "chunks=8 " in base_desc, base_desc
-    for env, ws, must in (({"AFHIP_FORCE_WG": "256"}, False, "wg=256"), ({"AFHIP_NO_PERIOD_CHUNKS": "1", "AFHIP_NO_ROUND_FILL": "1"}, False, "chunks=4 "), ({}, True, "wg=64")):
+    # ... nor on where the run sums are laid (slot-major / run-major: k_rf_reduce adds the same values in the same order)
+    for env, ws, must in (({"AFHIP_FORCE_WG": "256"}, False, "wg=256"), ({"AFHIP_NO_PERIOD_CHUNKS": "1", "AFHIP_NO_ROUND_FILL": "1"}, False, "chunks=4 "), ({}, True, "wg=64"),
+                          ({"AFHIP_RF_LAYOUT": "run"}, False, "wg=64"), ({"AFHIP_RF_LAYOUT": "slot"}, True, "wg=64")):
         desc, got = run(env, ws)
         assert must in desc, desc
         for k in base:
@@ -1168,7 +1170,9 @@ def test_four_and_three_row_groups_take_the_lean_group_end(torch_cuda, dtype, sh
     generic = [dict(inner="mean", transform="hinge", transform_arg=20.0, outer="sum"), dict(inner="max", outer="max")]
     many = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4, 5, 6, 7)]
     light = [dict(inner="mean", outer="sum")]
-    for cols, quad in ((poly, True), (mixed, True), (two, True), (generic, False), (many, False), (light, True)):
+    # (one- and two-column mean / sum plans on three-row float32 groups stream faster through the ring: the planner keeps them there)
+    light_lean = not (glen == 3 and dtype == np.float32)
+    for cols, quad in ((poly, True), (mixed, True), (two, True), (generic, False), (many, False), (light, light_lean)):
         plan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True)
         name = plan.describe().split()[0]
         assert name.endswith(suffix) == quad, name
