@@ -474,3 +474,25 @@ def test_plan_and_csr_caches_are_keyed_by_device(monkeypatch):
     assert c5.device_index == 5 and c2.device_index == 2 and eng.get_csr(w, ds, device=2)[0] is c2
     assert eng.dataset_device(ds) == 5                                # a host array goes to the current device
     assert made.count(("csr", 2)) == 1 and made.count(("plan", 3)) == 1
+
+
+def test_kernel_menu_shape():
+    """The production menu (`make`) holds no tuning arm, every region-fused twin has its plain variant beside it (same fields, FEAT bit
+    11 apart), twins exist only for direct-load two-level forms of at most six columns and four slots, the three-row (8-hourly) forms are
+    lean short-group forms with depth 6; `MENU=arms` adds the arms and nothing else; the loaded library reports the menu it was built from."""
+    sys.path.insert(0, os.path.join(ROOT, "aggfly_amd", "csrc"))
+    import gen_variants as gv
+    full, arms = gv.menu("full"), gv.menu("arms")
+    assert all(v[8] for v in full) and sum(1 for v in arms if not v[8]) == len(arms) - len(full) > 0
+    assert set(full) <= set(arms)
+    keys = {v[:8] for v in full}
+    twins = [v for v in full if v[7] & 2048]
+    assert twins and all(v[:7] + (v[7] & ~2048,) in keys for v in twins)
+    assert all(v[1] == 0 and v[5] <= 6 and v[4] <= 4 and not (v[7] & (8 | 16 | 32)) for v in twins)          # pipe, kmax, nthr, no tki / sl / hb
+    tri = [v for v in full if v[7] & 4096]
+    assert tri and all((v[7] & 128) and (v[7] & 256) and not (v[7] & 1024) and v[6] % 3 == 0 for v in tri)
+    assert len({gv.name_of(v) for v in arms}) == len(arms)                                                   # names are unique
+    info = hip.build_info()
+    assert info["abi"] == hip.ABI_VERSION and info["menu"] in ("full", "arms", "dev")
+    if info["menu"] == "full":
+        assert info["variants"] == len(full) and info["arms"] == 0 and info["region_fused_twins"] == len(twins)
