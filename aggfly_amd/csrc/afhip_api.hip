@@ -206,8 +206,8 @@ struct afhip_csr {
         bool built = false, ok = false;
         int64_t n_runs = 0;
         DevBuf<double> w2;            // [n_cells][2]
-        DevBuf<int32_t> key;          // [n_cells][2] region of the cell's first / second entry, -1 = none (the scan form of the period end)
-        DevBuf<int32_t> tile;         // [wave tiles][2][2]
+        DevBuf<uint32_t> lane;        // [wave tiles * 64][2] per lane slot: {scan / start / end bits, run indices} (k_fused_temporal: rfbits, rfrid)
+        DevBuf<int32_t> tile;         // [wave tiles][2][2]: {first run, need mask} of entry e
         DevBuf<int64_t> reg_ptr;      // [R + 1]
         DevBuf<int32_t> reg_runs;     // [n_runs] run ids by region, ascending inside a region
         // cells in three or more regions: their entries beyond the second ("extras"), by region in table order
@@ -223,7 +223,7 @@ struct afhip_csr {
 
 // Builds (once) the run tables for wave tiles of 64 * vec cells.  Returns the table, or nullptr when the route does not apply.
 static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
-    const int slot = vec == 1 ? 0 : (vec == 2 ? 1 : (vec == 4 ? 2 : -1));
+    const int slot = vec == 1 ? 0 : (vec == 2 ? 1 : -1);      // (the twins hold one or two cells per lane)
     if (slot < 0) return nullptr;
     std::lock_guard<std::mutex> lk(csr->rf_mu);
     afhip_csr::RfTab& t = csr->rf[slot];
@@ -250,19 +250,52 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
         xreg_ptr[(size_t)r + 1] = (int64_t)xcell.size();
     }
     // (+ 4 empty tiles: the waves of the last workgroup that start beyond the grid look their tile up too)
-    // runs of a tile, numbered in cell order (the kernel derives the same numbering from the keys: a run starts where the key changes
-    // to a region, or at the tile's first cell)
+    // Runs of a tile, numbered in cell order (a run starts where the region changes to one, or at the tile's first cell), and — per lane
+    // slot — how the segmented scan of the period end proceeds (k_fused_temporal: rfbits / rfrid / rf_need).  A lane holds `vec`
+    // consecutive cells; a cell without an entry e is a stretch of its own, so the scan never adds across the gaps between runs and
+    // the steps a wave needs follow its longest RUN.
     std::vector<int32_t> tile((size_t)(nt + 4) * 4, 0), run_region;
+    std::vector<uint32_t> lanew((size_t)(nt + 4) * 64 * 2, 0u);
     for (int64_t ti = 0; ti < nt; ++ti)
         for (int e = 0; e < 2; ++e) {
-            const int64_t c_lo = ti * tc, c_hi = std::min(C, c_lo + tc);
-            tile[(size_t)(ti * 2 + e) * 2] = (int32_t)run_region.size();
-            int32_t key = -1;
-            for (int64_t c = c_lo; c < c_hi; ++c) {
-                const int32_t k = reg[(size_t)(2 * c + e)];
-                if (k != key || c == c_lo) { if (k >= 0) run_region.push_back(k); key = k; }
+            const int64_t c_lo = ti * tc;
+            const int first = (int)run_region.size();
+            auto key_of = [&](int64_t c) -> int32_t { return c < C ? reg[(size_t)(2 * c + e)] : -1; };
+            bool F[64];
+            uint32_t bits[64], rid[64];
+            int n_at = 0;
+            for (int l = 0; l < 64; ++l) {
+                bits[l] = 0; rid[l] = 0; F[l] = false;
+                for (int i = 0; i < vec; ++i) {
+                    const int64_t c = c_lo + (int64_t)l * vec + i;
+                    const int32_t k = key_of(c);
+                    const bool first_cell = l == 0 && i == 0, last_cell = l == 63 && i == vec - 1;
+                    const bool bnd = first_cell || k != key_of(c - 1) || k < 0;
+                    const bool endc = last_cell || key_of(c + 1) != k;
+                    if (bnd && k >= 0) { run_region.push_back(k); ++n_at; }
+                    rid[l] |= (uint32_t)((n_at - 1) & 0xff) << (8 * i);
+                    bits[l] |= (bnd ? 1u : 0u) << (6 + i);
+                    bits[l] |= ((endc && k >= 0) ? 1u : 0u) << (8 + i);
+                    F[l] = F[l] || bnd;
+                }
             }
-            tile[(size_t)(ti * 2 + e) * 2 + 1] = (int32_t)run_region.size() - tile[(size_t)(ti * 2 + e) * 2];
+            int need = n_at > 0 ? 128 : 0;
+            for (int st = 0; st < 6; ++st) {
+                const int d = 1 << st;
+                bool Fn[64];
+                for (int l = 0; l < 64; ++l) {
+                    if (l >= d && !F[l]) { bits[l] |= 1u << st; need |= 1 << st; }
+                    Fn[l] = F[l] || (l >= d && F[l - d]);
+                }
+                for (int l = 0; l < 64; ++l) F[l] = Fn[l];
+            }
+            for (int l = 0; l < 64; ++l) {
+                if (vec == 2 && ((bits[l] >> 8) & 1u)) need |= 64;
+                lanew[(size_t)(ti * 64 + l) * 2] |= bits[l] << (16 * e);
+                lanew[(size_t)(ti * 64 + l) * 2 + 1] |= rid[l] << (16 * e);
+            }
+            tile[(size_t)(ti * 2 + e) * 2] = first;
+            tile[(size_t)(ti * 2 + e) * 2 + 1] = need;
         }
     t.n_runs = (int64_t)run_region.size();
     if (t.n_runs == 0 || t.n_runs > INT32_MAX) return nullptr;
@@ -275,7 +308,7 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
     { std::vector<int64_t> at(reg_ptr.begin(), reg_ptr.end() - 1);
       for (int64_t q = 0; q < t.n_runs; ++q) reg_runs[(size_t)at[(size_t)run_region[(size_t)q]]++] = (int32_t)q; }
     DeviceGuard g(csr->device);
-    if (t.key.upload(reg) || t.w2.upload(w2) || t.tile.upload(tile) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
+    if (t.lane.upload(lanew) || t.w2.upload(w2) || t.tile.upload(tile) || t.reg_ptr.upload(reg_ptr) || t.reg_runs.upload(reg_runs)) return nullptr;
     if (t.n_xcells && (t.xidx.upload(xidx) || t.xreg_ptr.upload(xreg_ptr) || t.xcell.upload(xcell) || t.xw.upload(xw))) return nullptr;
     t.ok = true;
     return &t;
@@ -1390,7 +1423,7 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     const void* fn = pl->variant->fn;
     if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area (no LDS of its own)
         fn = pl->variant_rf->fn;
-        fa.rf_w = rf->w2.p; fa.rf_key = rf->key.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial;
+        fa.rf_w = rf->w2.p; fa.rf_lane = rf->lane.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial;
         fa.rf_slot_stride = rf_run_major(pl, rf) ? (int64_t)(pl->K + 1) : rf->n_runs * (pl->K + 1);
         fa.rf_run_stride = rf_run_major(pl, rf) ? pl->n_slots * (pl->K + 1) : (int64_t)(pl->K + 1);
         fa.rf_x = rf->n_xcells ? rf->xidx.p : nullptr; fa.rf_nx = rf->n_xcells;

@@ -138,7 +138,7 @@ struct FusedArgs {
     // launch on the reference's own benchmark shape, stores that cost its streaming kernel 6 % — are never written, and the
     // gather kernel over them does not run.
     const double* rf_w;            // device [C][2]: weight of the cell's first / second table entry (0: none)
-    const int32_t* rf_tile;        // device [wave tiles][2][2]: {first run, runs} of entry e in wave tile t (64 * VEC cells)
+    const int32_t* rf_tile;        // device [wave tiles][2][2]: {first run, need mask (rf_need)} of entry e in wave tile t (64 * VEC cells)
     double* rf_out;                // device: the sum of (slot, run, column k) at  slot * rf_slot_stride + run * rf_run_stride + k  —
     int64_t rf_slot_stride, rf_run_stride;      // run-major ([runs][n_slots][K + 1]) for plans of many periods: a region's periods side by side for k_rf_reduce
     // cells that sit in MORE than two regions (junctions of polygons): their third, fourth ... entries are "extras" — such a cell
@@ -146,9 +146,9 @@ struct FusedArgs {
     const int32_t* rf_x;           // device [C]: index of the cell among the cells with extras, -1 = none; null: the table has none
     double* rf_ex;                 // device [n_slots][rf_nx][K + 1]
     int64_t rf_nx;
-    // region of the cell's first / second table entry (-1: none).  A wave reads its cells' keys and weights ONCE and derives where
-    // runs start and end inside its tile (the host numbered a tile's runs in cell order: rf_tile)
-    const int32_t* rf_key;         // device [C][2]
+    // per lane slot (tile * 64 + lane, tiles padded): {scan / start / end bits, run indices} of its cells for both entries, worked out
+    // on the host from the regions of neighbouring cells (afhip_api.hip: rf_table; k_fused_temporal: rfbits / rfrid)
+    const uint32_t* rf_lane;       // device [wave tiles * 64][2]
 };
 
 // ---------------------------------------------------------------------------------------
@@ -570,8 +570,11 @@ __device__ __forceinline__ RawVec<TIn, VEC> ld_stream_row(const void* row, uint3
 //
 // The workgroup size is a launch parameter (64 or 256 threads): waves never talk to each
 // other, so small grids are launched as single-wave workgroups for a finer tail.
+#ifndef AFHIP_RF_WAVES
+#define AFHIP_RF_WAVES 1           // waves per SIMD the region-fused twins are compiled for (1 = no constraint)
+#endif
 template <typename TIn, int PIPE, int VEC, int STAT, int NTHR, int KMAX, int DEPTH, int FEAT>
-__global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048) ? AFHIP_RF_WAVES : 1))) void k_fused_temporal(const FusedArgs a) {
     constexpr int AUX = (FEAT & 4) ? 2 : 0;   // FEAT bit 2: non-temporal (nt) cache policy on the streaming loads
     // FEAT bit 3: every threshold slot is a bin count -> 32-bit integer counters (one
     //             v_addc per slot and element instead of fma + select + f64 add)
@@ -756,76 +759,39 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     };
     reset_outer();
 
-    // ---- region-fused period ends, scan form (FusedArgs::rf_key): what a wave needs at every period end, read once ----
+    // ---- region-fused period ends (FusedArgs::rf_w): what a wave needs at every period end, read once ----
     // A wave's tile is its 64 * VEC consecutive cells.  For entry e (the cell's first / second region) a RUN is a maximal stretch of
-    // cells of the tile with the same region; the host numbered the runs of a tile in cell order (afhip_api.hip: rf_table).
+    // cells of the tile with the same region; the host numbered the runs of a tile in cell order and worked out, per lane, how the
+    // segmented scan of the period end proceeds (afhip_api.hip: rf_table — the tables depend on the weights table and VEC only):
     //   rfw[i][e]   weight of cell i's entry e (0: none)
     //   rfbits      per lane, 16 bits per entry e:  bits 0-5   step s of the segmented scan adds the value of lane - 2^s
-    //                                                bits 6+i   cell i starts a stretch (region changes, or the tile starts)
+    //                                                bits 6+i   cell i starts a stretch (region changes, no region, or the tile starts)
     //                                                bits 8+i   cell i ends a run of a region: its sum is stored
     //   rfrid       byte 2 e + i: index of cell i's run among the runs of (tile, e)
     //   rf_first[e] first run of (tile, e) in rf_out
-    static_assert(!RF || VEC <= 2, "region-fused period ends: one or two cells per lane");
     //   rf_need[e]  (uniform) bit s: some lane of the wave adds in step s — steps no run of this tile is long enough for are skipped;
     //               bit 6: some run ends at a lane's first cell (two cells per lane); bit 7: the tile has runs of entry e at all
+    static_assert(!RF || VEC <= 2, "region-fused period ends: one or two cells per lane");
+#ifndef AFHIP_RF_CB
+#define AFHIP_RF_CB 2
+#endif
+    constexpr int RF_CB = AFHIP_RF_CB;                 // columns per block of the period end's scan (registers against overlap)
     double rfw[VEC][2];
     uint32_t rfbits = 0, rfrid = 0;
     int rf_first[2] = {0, 0}, rf_need[2] = {0, 0};
     if constexpr (RF) {
         if (a.rf_w != nullptr) {
-            const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)((c0 - (int64_t)lane * VEC) / (64 * VEC)));
+            const int64_t lane0 = (c0 - (int64_t)lane * VEC) / VEC;                      // the wave's first lane slot (uniform)
+            const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)(lane0 / 64));
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            const u2 lw = *(const u2*)(a.rf_lane + (wt * 64 + lane) * 2);                 // (the table is padded to whole tiles)
+            rfbits = lw.x; rfrid = lw.y;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 rf_first[e] = ld_uniform(a.rf_tile + (wt * 2 + e) * 2);
-                int key[VEC];
+                rf_need[e] = ld_uniform(a.rf_tile + (wt * 2 + e) * 2 + 1);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    key[i] = active ? a.rf_key[(c0 + i) * 2 + e] : -1;
-                    rfw[i][e] = active ? a.rf_w[(c0 + i) * 2 + e] : 0.0;
-                }
-                const int prev = __shfl_up(key[VEC - 1], 1, 64), next = __shfl_down(key[0], 1, 64);
-                bool bnd[VEC], endc[VEC];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    bnd[i] = i == 0 ? (lane == 0 || key[0] != prev) : (key[i] != key[i - 1]);
-                    endc[i] = i == VEC - 1 ? (lane == 63 || key[VEC - 1] != next) : (key[i + 1] != key[i]);
-                }
-                // run numbers: the heads of regions' runs at or before a cell, in cell order (lane-major, then i)
-                int before = 0;
-                bool hd[VEC];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    hd[i] = bnd[i] && key[i] >= 0;
-                    const unsigned long long m = __ballot(hd[i]);
-                    before += __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                }
-                uint32_t bits = 0, rid = 0;
-                int n_at = before;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    n_at += hd[i] ? 1 : 0;
-                    rid |= (uint32_t)((n_at - 1) & 0xff) << (8 * i);
-                    bits |= (bnd[i] ? 1u : 0u) << (6 + i);
-                    bits |= ((endc[i] && key[i] >= 0) ? 1u : 0u) << (8 + i);
-                }
-                // the scan's flags do not depend on the data: which steps add is decided here, once
-                int F = 0;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) F |= bnd[i] ? 1 : 0;
-#pragma unroll
-                for (int st = 0; st < 6; ++st) {
-                    const int d = 1 << st;
-                    if (lane >= d && !F) bits |= 1u << st;
-                    const int Fp = __shfl_up(F, d, 64);
-                    if (lane >= d) F |= Fp;
-                }
-                rfbits |= bits << (16 * e);
-                rfrid |= rid << (16 * e);
-                int need = ld_uniform(a.rf_tile + (wt * 2 + e) * 2 + 1) > 0 ? 128 : 0;
-#pragma unroll
-                for (int st = 0; st < 6; ++st) need |= __ballot((bits >> st) & 1u) != 0ull ? (1 << st) : 0;
-                if (VEC == 2) need |= __ballot((bits >> 8) & 1u) != 0ull ? 64 : 0;
-                rf_need[e] = __builtin_amdgcn_readfirstlane(need);
+                for (int i = 0; i < VEC; ++i) rfw[i][e] = active ? a.rf_w[(c0 + i) * 2 + e] : 0.0;
             }
         }
     }
@@ -935,95 +901,146 @@ __global__ __launch_bounds__(WG) void k_fused_temporal(const FusedArgs a) {
     // (Round 3 staged the values in a wave-private LDS block and let one lane per (run, column) walk its run: a serial chain of LDS
     // round trips per period end, and the weights re-read from memory at every one — 3.7 against 3.3 ms on the daily configs[1]
     // panel, 27.5 against 17.7 on a daily sine_dd panel of (tmin, tmax) pairs; profiles/r04_region_fused_scan.txt.)
-    auto rf_emit = [&](const double (&val)[KMAX][VEC], int at_slot) {
+    auto rf_emit = [&](double (&val)[KMAX][VEC], int at_slot) {
         const int K1 = K + 1;
-        bool valid[VEC];
+        // shared validity, applied in place (the caller resets / drops its period values right after): x = where(valid, x, 0)
+        double flag[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            valid[i] = active;                                       // (lanes beyond the grid carry no weight and no run)
+            bool valid = active;                                     // (lanes beyond the grid carry no weight and no run)
 #pragma unroll
             for (int j = 0; j < KMAX; ++j)
-                if (j < K) valid[i] = valid[i] && (val[j][i] == val[j][i]);
+                if (j < K) valid = valid && (val[j][i] == val[j][i]);
+            flag[i] = valid ? 1.0 : 0.0;
+            if (!valid) {
+                KEEP_BRANCH();
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) val[j][i] = 0.0;
+            }
             if (a.rf_x != nullptr) {                                 // (uniform) the table has cells in three or more regions
                 const int xi = active ? a.rf_x[c0 + i] : -1;
                 if (xi >= 0) {                                       // rare lanes: the cell's values for its extra entries
                     double* ex = a.rf_ex + ((int64_t)at_slot * a.rf_nx + xi) * K1;
 #pragma unroll
                     for (int j = 0; j < KMAX; ++j)
-                        if (j < K) ex[j] = valid[i] ? val[j][i] : 0.0;
-                    ex[K] = valid[i] ? 1.0 : 0.0;
+                        if (j < K) ex[j] = val[j][i];
+                    ex[K] = flag[i];
                 }
             }
         }
+        // (the lanes' bit fields are made opaque here: tested where they are used, the compiler would otherwise hoist all the lane
+        // masks they decode to out of the time loop — two dozen scalar register pairs that spilled into v_readlane traffic)
+        uint32_t rb = rfbits, rr = rfrid;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("; rf_emit: begin" : "+v"(rb), "+v"(rr));
+#endif
+        // Per entry: the lane conditions and store addresses once, then the columns in blocks of CB.  The column list is fixed at
+        // compile time — the validity weight first, then val[0 .. KMAX) — so nothing inside the scan branches on K: columns beyond K
+        // carry whatever their registers hold through the shuffles and only their stores are skipped (the weight is stored at index K
+        // of the record).  Per block: products, the lane's own stretch, the scan steps some run of the tile needs (a shuffle = two
+        // ds_bpermute on an address formed once per step; the adds run under the lanes' take / start / end bits as branches on lane
+        // conditions, i.e. EXEC masks, not selects), the sums of the runs that end in this lane.
+        constexpr int CB = RF_CB, NCOL = KMAX + 1;
+        auto shfl64 = [&](double x, int addr) -> double {
+            const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+            const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+            return __hiloint2double(hi, lo);
+        };
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int need = rf_need[e];
+            int need = rf_need[e];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+s"(need));                           // (the same for the wave's step mask: s_bitcmp here, not a spilled mask per step)
+#endif
             if (!(need & 128)) continue;                             // (uniform) no cell of this tile has an entry e
-            const uint32_t bits = rfbits >> (16 * e), rid = rfrid >> (16 * e);
+            const uint32_t bits = rb >> (16 * e), rid = rr >> (16 * e);
             double* out0 = a.rf_out + (int64_t)at_slot * a.rf_slot_stride + (int64_t)rf_first[e] * a.rf_run_stride;
             double* dst0 = out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride;           // where this lane's cells store, if they end a run
             double* dst1 = out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride;
-            // columns in blocks of CB: inside a block the shuffles of the columns are independent and overlap; a step is skipped
-            // by the whole wave when no run of the tile needs it (county-sized runs span a few lanes: two or three steps of six)
-            constexpr int CB = 8;
+            const bool joins = !((bits >> 7) & 1u), fresh = ((bits >> 6) & 1u) != 0u, end0 = ((bits >> 8) & 1u) != 0u, end1 = ((bits >> 9) & 1u) != 0u;
 #pragma unroll
-            for (int j0 = 0; j0 < KMAX + 1; j0 += CB) {
-                if (j0 > K) continue;                                // (uniform)
+            for (int q0 = 0; q0 < NCOL; q0 += CB) {                  // q: position in the column list (0 = the weight, q >= 1: val[q - 1])
+                if (q0 > K) continue;                                // (uniform: the block's first value column is val[q0 - 1])
                 double v[CB], p0[CB];
 #pragma unroll
-                for (int jj = 0; jj < CB; ++jj) {
-                    const int j = j0 + jj;
-                    v[jj] = 0.0; p0[jj] = 0.0;
-                    if (j < KMAX + 1 && j <= K) {
-                        double p[VEC];
+                for (int qq = 0; qq < CB; ++qq) {
+                    const int q = q0 + qq;
+                    v[qq] = 0.0; p0[qq] = 0.0;
+                    if (q < NCOL) {
+                        p0[qq] = __dmul_rn(rfw[0][e], q == 0 ? flag[0] : val[q == 0 ? 0 : q - 1][0]);
+                        v[qq] = VEC == 2 ? __dmul_rn(rfw[VEC - 1][e], q == 0 ? flag[VEC - 1] : val[q == 0 ? 0 : q - 1][VEC - 1]) : p0[qq];
+                    }
+                }
+                if constexpr (VEC == 2) {
+                    if (joins) {                                     // (lanes whose second cell continues the first cell's stretch)
+                        KEEP_BRANCH();
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            double x = valid[i] ? 1.0 : 0.0;         // column K: the validity weight
-                            if (j < K) x = valid[i] ? val[j < KMAX ? j : 0][i] : 0.0;
-                            p[i] = __dmul_rn(rfw[i][e], x);
-                        }
-                        p0[jj] = p[0];
-                        v[jj] = p[VEC - 1];                          // the stretch that is still open at the lane's last cell
-                        if constexpr (VEC == 2) v[jj] = ((bits >> 7) & 1u) ? p[1] : __dadd_rn(p[0], p[1]);
+                        for (int qq = 0; qq < CB; ++qq)
+                            if (q0 + qq < NCOL) v[qq] = __dadd_rn(p0[qq], v[qq]);
                     }
                 }
 #pragma unroll
                 for (int st = 0; st < 6; ++st) {
                     if (!((need >> st) & 1)) continue;               // (uniform)
-                    const bool take = ((bits >> st) & 1u) != 0u;
+                    const int addr = ((lane - (1 << st)) & 63) << 2;
+                    double pv[CB];
 #pragma unroll
-                    for (int jj = 0; jj < CB; ++jj) {
-                        if (j0 + jj < KMAX + 1 && j0 + jj <= K) {
-                            const double pv = __shfl_up(v[jj], 1 << st, 64);
-                            v[jj] = __dadd_rn(v[jj], take ? pv : 0.0);
-                        }
+                    for (int qq = 0; qq < CB; ++qq) pv[qq] = q0 + qq < NCOL ? shfl64(v[qq], addr) : 0.0;
+                    if ((bits >> st) & 1u) {
+                        KEEP_BRANCH();
+#pragma unroll
+                        for (int qq = 0; qq < CB; ++qq)
+                            if (q0 + qq < NCOL) v[qq] = __dadd_rn(v[qq], pv[qq]);
                     }
                 }
+                // record index of list position q: the weight at K, val[q - 1] at q - 1 (stored when q - 1 < K)
                 if constexpr (VEC == 2) {
                     if (need & 64) {                                 // (uniform) a run ends at some lane's FIRST cell: what the previous lanes
-                        const bool fresh = ((bits >> 6) & 1u) != 0u, end0 = ((bits >> 8) & 1u) != 0u;      // carried (unless the cell starts a stretch) + the cell
+                        const int addr = ((lane - 1) & 63) << 2;     // carried (unless the cell starts a stretch) + the cell
+                        double carried[CB];
 #pragma unroll
-                        for (int jj = 0; jj < CB; ++jj) {
-                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) {
-                                const double carried = __shfl_up(v[jj], 1, 64);
-                                if (end0) dst0[j0 + jj] = __dadd_rn(fresh ? 0.0 : carried, p0[jj]);
+                        for (int qq = 0; qq < CB; ++qq) carried[qq] = q0 + qq < NCOL ? shfl64(v[qq], addr) : 0.0;
+                        if (end0) {
+                            KEEP_BRANCH();
+                            if (!fresh) {
+                                KEEP_BRANCH();
+#pragma unroll
+                                for (int qq = 0; qq < CB; ++qq)
+                                    if (q0 + qq < NCOL) p0[qq] = __dadd_rn(carried[qq], p0[qq]);
+                            }
+#pragma unroll
+                            for (int qq = 0; qq < CB; ++qq) {
+                                const int q = q0 + qq;
+                                if (q == 0) dst0[K] = p0[qq];
+                                else if (q < NCOL && q - 1 < K) dst0[q - 1] = p0[qq];
                             }
                         }
                     }
-                    if ((bits >> 9) & 1u) {
+                    if (end1) {
+                        KEEP_BRANCH();
 #pragma unroll
-                        for (int jj = 0; jj < CB; ++jj)
-                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) dst1[j0 + jj] = v[jj];
+                        for (int qq = 0; qq < CB; ++qq) {
+                            const int q = q0 + qq;
+                            if (q == 0) dst1[K] = v[qq];
+                            else if (q < NCOL && q - 1 < K) dst1[q - 1] = v[qq];
+                        }
                     }
                 } else {
-                    if ((bits >> 8) & 1u) {
+                    if (end0) {
+                        KEEP_BRANCH();
 #pragma unroll
-                        for (int jj = 0; jj < CB; ++jj)
-                            if (j0 + jj < KMAX + 1 && j0 + jj <= K) dst0[j0 + jj] = v[jj];
+                        for (int qq = 0; qq < CB; ++qq) {
+                            const int q = q0 + qq;
+                            if (q == 0) dst0[K] = v[qq];
+                            else if (q < NCOL && q - 1 < K) dst0[q - 1] = v[qq];
+                        }
                     }
                 }
             }
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("; rf_emit: end");
+#endif
     };
 
     // ---- end of an inner group: column values, transforms, outer accumulation ----

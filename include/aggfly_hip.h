@@ -90,6 +90,11 @@ int afhip_device_info(int dev, char* name, int name_len, char* arch, int arch_le
  * out_dev    [G, n_cells] (stat) or [G, n_cells, D] of `dtype` — the reference's output
  *            layout and dtype (accumulation is float64, the store rounds to `dtype`,
  *            nb_kernels.py:257-268).
+ * Numerics: stat / dd / bins are bit-identical to the reference's loops (same operation order, float64 accumulators, no contraction).
+ * sine_dd evaluates the same closed forms by other means (table acos, rsq + Newton, cubic arc tables):
+ *     |out - exact| <= 1e-10 |exact| + 1e-12 max(tmax - tmin, |exact|),   exact = the closed forms of nb_kernels.py:202-251 in exact arithmetic
+ * (tests/golden/sine_dd_fixtures.json at 50 digits; the reference's own libm evaluation sits at 3.5e-9 relative / 3e-14 of the window's scale next to
+ * the window's edges, the (tmin, tmax)-pair forms here at 1.7e-11 / 5.5e-15: profiles/r04_sine_accuracy.json).
  * D is unbounded, like the reference's loop over ddargs rows (nb_kernels.py:166,190,215): more rows than one pass over the
  * cube holds (16) run as consecutive passes inside the call, each writing its own columns of out_dev.
  * These calls build a temporary plan, own their scratch and synchronise `stream` before they return.
