@@ -358,6 +358,7 @@ struct afhip_plan {
     // experiment knobs, read once when the plan is created (never on the run path)
     bool no_slot_spmm = false, no_slots_divide = false, no_counts_divide = false;
     int rf_layout = -1;                               // AFHIP_RF_LAYOUT=slot|run: layout of the run sums forced (rf_run_major)
+    int rf_reduce_order = -1;                         // AFHIP_RF_REDUCE_ORDER=r|p: k_rf_reduce's (region, period) pairs region-major / period-major
     int slot_spmm_sub = 0, slot_spmm_order = -1;      // AFHIP_SLOT_SPMM_ORDER=v|p: SlotSpmmArgs::p_major forced off / on
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
@@ -1282,6 +1283,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     pl->no_slots_divide = getenv("AFHIP_NO_SLOTS_DIVIDE") != nullptr;
     pl->no_counts_divide = getenv("AFHIP_NO_COUNTS_DIVIDE") != nullptr;
     if (const char* e = getenv("AFHIP_RF_LAYOUT")) pl->rf_layout = (e[0] == 'r') ? 1 : 0;
+    if (const char* e = getenv("AFHIP_RF_REDUCE_ORDER")) pl->rf_reduce_order = (e[0] == 'p') ? 1 : 0;
     if (const char* e = getenv("AFHIP_SLOT_SPMM_ORDER")) pl->slot_spmm_order = (e[0] == 'p') ? 1 : 0;
     if (const char* e = getenv("AFHIP_SLOT_SPMM_SUB")) { const int sb = atoi(e); if (sb == 8 || sb == 16 || sb == 32 || sb == 64) pl->slot_spmm_sub = sb; }
     pl->packed = v->tki && v->sl && K <= 16 && !getenv("AFHIP_NO_PACKED_COUNTS");
@@ -1377,14 +1379,15 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
 }
 
 // Layout of the run sums: slot-major [slots][runs][K + 1] (a period end's stores of one wave side by side: one or two cache lines per
-// store instruction) or run-major [runs][slots][K + 1] (a run's periods side by side: k_rf_reduce reads whole lines instead of K + 1
-// doubles a slot apart — its time falls to a half ... a fifth — but every run a wave closes is then a cache line of its own at every
-// period end, which costs the float32 streaming kernels 7 % at 24 - 73 periods).  Measured (profiles/r04_rf_layout.txt): run-major pays
-// where the reduce side is large — from ~1e8 (run, period, column) gathers: daily sine_dd on 0.1 deg 16.4 -> 12.7 ms, weekly 5.41 ->
-// 5.0, the float64 daily configs[1] panel 4.66 -> 4.25, 6-hourly daily 4.77 -> 4.40 — and loses below (float32 daily degree days 2.33 -> 2.47).
+// store instruction; k_rf_reduce then deals its (region, period) pairs period-major, so that neighbouring regions read neighbouring
+// runs of ONE slot) or run-major [runs][slots][K + 1] (a run's periods side by side: k_rf_reduce reads whole lines — its time falls to
+// a half ... a fifth — but every run a wave closes is then a cache line of its own at every period end: +0.25 ... 0.5 ms on the general
+// streaming forms, next to nothing on the short-group forms).  Measured (profiles/r04_rf_layout.txt, both tables): run-major pays on the
+// short-group forms from ~5e7 (run, period, column) gathers (daily sine_dd on 0.1 deg 12.3 -> 9.5 ms, weekly 5.12 -> 4.60, 6-hourly daily
+// 3.21 -> 2.96) and on the general forms nowhere below 5e8 (float64 daily configs[1] panel 4.49 -> 4.87, float32 2.76 -> 2.90).
 static bool rf_run_major(const afhip_plan* pl, const afhip_csr::RfTab* rf) {
     if (pl->rf_layout >= 0) return pl->rf_layout == 1;
-    return (double)rf->n_runs * (double)pl->desc.P * (double)(pl->K + 1) >= 1e8;
+    return (double)rf->n_runs * (double)pl->desc.P * (double)(pl->K + 1) >= (pl->variant->pair ? 5e7 : 5e8);
 }
 
 static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hipStream_t st, const afhip_csr::RfTab* rf = nullptr) {
@@ -1613,7 +1616,8 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
             hipLaunchKernelGGL(k_rf_reduce, dim3((unsigned)((n + WG - 1) / WG)), dim3(WG), 0, st, (const double*)partial, rf->reg_ptr.p, rf->reg_runs.p,
                                plan->d_slot_ptr.p, plan->d_ob.p, mean_mask, (const double*)(partial + plan->n_slots * rf->n_runs * (K + 1)), rf->n_xcells,
                                rf->xreg_ptr.p, rf->xcell.p, rf->xw.p, plan->sums, csr->R, P, (int)(K + 1), rf->n_runs,
-                               rf_run_major(plan, rf) ? (int64_t)(K + 1) : rf->n_runs * (K + 1), rf_run_major(plan, rf) ? plan->n_slots * (K + 1) : (int64_t)(K + 1));
+                               rf_run_major(plan, rf) ? (int64_t)(K + 1) : rf->n_runs * (K + 1), rf_run_major(plan, rf) ? plan->n_slots * (K + 1) : (int64_t)(K + 1),
+                               plan->rf_reduce_order >= 0 ? plan->rf_reduce_order : ((!rf_run_major(plan, rf) && P >= 8) ? 1 : 0));
             HIP_TRY(hipGetLastError());
         }
     } else if (plan->packed && !cells_dev && plan->n_slots <= P && plan->counts_spmm) {

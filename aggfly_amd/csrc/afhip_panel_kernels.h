@@ -521,11 +521,14 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
                                                   const double* __restrict__ ex, int64_t nx, const int64_t* __restrict__ xreg_ptr,
                                                   const int32_t* __restrict__ xcell, const double* __restrict__ xw,
                                                   double* __restrict__ sums, int64_t R, int64_t P, int K1, int64_t n_runs,
-                                                  int64_t slot_stride, int64_t run_stride) {
+                                                  int64_t slot_stride, int64_t run_stride, int p_major) {
     const int64_t tid = (int64_t)blockIdx.x * WG + threadIdx.x;
     if (tid >= R * P * K1) return;
     const int k = (int)(tid % K1);
-    const int64_t rp = tid / K1, r = rp / P, p = rp - r * P;
+    const int64_t rp = tid / K1;
+    // slot-major run sums: a period's regions side by side (neighbouring regions' runs are neighbours in ONE slot); run-major: a
+    // region's periods side by side (its runs hold their periods contiguously)
+    const int64_t r = p_major ? rp % R : rp / P, p = p_major ? rp / R : rp - r * P;
     const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
     double acc = 0.0;
     if (s1 != s0) {
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(WG) void k_rf_reduce(const double* __restrict__ rf_
         }
         if ((mean_mask >> k) & 1u) acc = acc / (double)(outer_bounds[p + 1] - outer_bounds[p]);
     }
-    sums[tid] = acc;
+    sums[(r * P + p) * K1 + k] = acc;
 }
 
 // The pieces of a cut region, added in row order: sums[split_row[i]][q] = sum over scratch rows R + [split_ptr[i], split_ptr[i+1]).

@@ -37,4 +37,4 @@ for src, dst in (("$o/traffic_$tag.json", "profiles/traffic.json"), ("$o/valu_co
 PY
 python bench.py > $o/bench_$tag.json 2> $o/bench_$tag.err; tail -c 400 $o/bench_$tag.err; head -c 600 $o/bench_$tag.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/rp_bench_$tag -o p -- python3 bench.py --steps 20 --no-cpu-baseline --no-other-configs > $o/rp_bench_$tag.log 2>&1
-python3 scripts/pmc_bench_post.py $tag | head -12
+python3 scripts/pmc_bench_post.py $tag > $o/pmc_post2_$tag.log 2>&1; head -12 $o/pmc_post2_$tag.log
