@@ -1229,3 +1229,20 @@ def test_short_group_plans_shorter_than_a_block_of_rows(torch_cuda, glen, ngroup
             w = cport.resample(x, ob, col["outer"]).reshape(len(ob) - 1, -1)
             assert np.array_equal(np.isnan(got[k]), np.isnan(w))
             np.testing.assert_allclose(got[k], w, rtol=1e-10 if col["inner"] == "sine_dd" else 4e-15, atol=1e-10 if col["inner"] == "sine_dd" else 0, equal_nan=True)
+
+
+def test_read_probe_and_build_info(torch_cuda):
+    """The measuring aids of the ABI: `afhip_read_probe` times a bare streaming read of a cube (bench.py's measured read ceiling) and
+    refuses what it cannot stream; `afhip_build_info` names the menu the library was built from."""
+    from aggfly_amd import hip
+    torch = torch_cuda
+    cube = torch.zeros((512, 64, 256), dtype=torch.float32, device="cuda")       # 512 rows of 64 KiB
+    ms = hip.read_probe(cube, 5)
+    assert len(ms) == 5 and all(0.0 < m < 50.0 for m in ms), ms
+    gbps = cube.numel() * 4 / (min(ms) * 1e-3) / 1e9
+    assert gbps > 50.0, gbps                                                      # (a 33 MB cube: cache-resident, far below the HBM figure's scale)
+    odd = torch.zeros((8, 3), dtype=torch.float32, device="cuda")                # rows of 12 bytes: not a multiple of 8
+    with pytest.raises(ValueError, match="multiples of 8"):
+        hip.read_probe(odd, 2)
+    info = hip.build_info()
+    assert info["abi"] == hip.ABI_VERSION and info["variants"] > 300 and info["region_fused_twins"] > 50
