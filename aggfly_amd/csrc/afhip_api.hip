@@ -1424,8 +1424,11 @@ static int launch_temporal(afhip_plan* pl, const void* cube, double* partial, hi
     void* args[] = {&fa};
     size_t lds = plan_lds_bytes(pl);
     const void* fn = pl->variant->fn;
-    if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area (no LDS of its own)
+    if (rf) {       // region-fused period ends: the twin variant, per-run sums into the partial area, a parking block per lane in LDS
         fn = pl->variant_rf->fn;
+        lds = (lds + 15) / 16 * 16;
+        fa.rf_lds_off = (int32_t)lds;
+        lds += (size_t)pl->wg * (size_t)(pl->variant->vec * 16 + 16);      // RF_LANE_BYTES of afhip_kernels.h
         fa.rf_w = rf->w2.p; fa.rf_lane = rf->lane.p; fa.rf_tile = rf->tile.p; fa.rf_out = partial;
         fa.rf_slot_stride = rf_run_major(pl, rf) ? (int64_t)(pl->K + 1) : rf->n_runs * (pl->K + 1);
         fa.rf_run_stride = rf_run_major(pl, rf) ? pl->n_slots * (pl->K + 1) : (int64_t)(pl->K + 1);

@@ -149,6 +149,7 @@ struct FusedArgs {
     // per lane slot (tile * 64 + lane, tiles padded): {scan / start / end bits, run indices} of its cells for both entries, worked out
     // on the host from the regions of neighbouring cells (afhip_api.hip: rf_table; k_fused_temporal: rfbits / rfrid)
     const uint32_t* rf_lane;       // device [wave tiles * 64][2]
+    int32_t rf_lds_off, rf_pad;    // byte offset, in the dynamic LDS, of the waves' parking blocks: RF_LANE_BYTES per lane (weights + lane words)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -763,11 +764,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
     // A wave's tile is its 64 * VEC consecutive cells.  For entry e (the cell's first / second region) a RUN is a maximal stretch of
     // cells of the tile with the same region; the host numbered the runs of a tile in cell order and worked out, per lane, how the
     // segmented scan of the period end proceeds (afhip_api.hip: rf_table — the tables depend on the weights table and VEC only):
-    //   rfw[i][e]   weight of cell i's entry e (0: none)
-    //   rfbits      per lane, 16 bits per entry e:  bits 0-5   step s of the segmented scan adds the value of lane - 2^s
+    //   weights     of cell i's entries e = 0, 1 (0: none)
+    //   bits        per lane, 16 bits per entry e:  bits 0-5   step s of the segmented scan adds the value of lane - 2^s
     //                                                bits 6+i   cell i starts a stretch (region changes, no region, or the tile starts)
     //                                                bits 8+i   cell i ends a run of a region: its sum is stored
-    //   rfrid       byte 2 e + i: index of cell i's run among the runs of (tile, e)
+    //   rid         byte 2 e + i: index of cell i's run among the runs of (tile, e)
     //   rf_first[e] first run of (tile, e) in rf_out
     //   rf_need[e]  (uniform) bit s: some lane of the wave adds in step s — steps no run of this tile is long enough for are skipped;
     //               bit 6: some run ends at a lane's first cell (two cells per lane); bit 7: the tile has runs of entry e at all
@@ -776,22 +777,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #define AFHIP_RF_CB 2
 #endif
     constexpr int RF_CB = AFHIP_RF_CB;                 // columns per block of the period end's scan (registers against overlap)
-    double rfw[VEC][2];
-    uint32_t rfbits = 0, rfrid = 0;
+    // The lane's weights and words are PARKED in LDS (a wave-private block behind the variant's other LDS: RF_LANE_BYTES per lane) and
+    // read back at every period end: held in registers they cost the twins ten VGPRs for the whole kernel — 103 against the plain
+    // variant's 74 on the float32 configs[1] plan, four waves per SIMD instead of six, for a kernel that is bound by bytes in flight.
+    constexpr int RF_LANE_BYTES = VEC * 16 + 16;      // (a multiple of 16: the block is read and written in 16-byte pieces)
+    typedef __attribute__((address_space(3))) unsigned char* rf_lds_t;
+    rf_lds_t rf_park = nullptr;
     int rf_first[2] = {0, 0}, rf_need[2] = {0, 0};
     if constexpr (RF) {
         if (a.rf_w != nullptr) {
             const int64_t lane0 = (c0 - (int64_t)lane * VEC) / VEC;                      // the wave's first lane slot (uniform)
             const int64_t wt = (int64_t)__builtin_amdgcn_readfirstlane((int)(lane0 / 64));
             typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            typedef double d2 __attribute__((ext_vector_type(2)));
             const u2 lw = *(const u2*)(a.rf_lane + (wt * 64 + lane) * 2);                 // (the table is padded to whole tiles)
-            rfbits = lw.x; rfrid = lw.y;
+            rf_park = (rf_lds_t)(lds_ptr_t)(dynlds + a.rf_lds_off) + (threadIdx.x * RF_LANE_BYTES);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                d2 w = d2{0.0, 0.0};
+                if (active) w = *(const d2*)(a.rf_w + (c0 + i) * 2);
+                *(__attribute__((address_space(3))) d2*)(rf_park + i * 16) = w;
+            }
+            *(__attribute__((address_space(3))) u2*)(rf_park + VEC * 16) = lw;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 rf_first[e] = ld_uniform(a.rf_tile + (wt * 2 + e) * 2);
                 rf_need[e] = ld_uniform(a.rf_tile + (wt * 2 + e) * 2 + 1);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) rfw[i][e] = active ? a.rf_w[(c0 + i) * 2 + e] : 0.0;
             }
         }
     }
@@ -904,14 +915,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
     auto rf_emit = [&](double (&val)[KMAX][VEC], int at_slot) {
         const int K1 = K + 1;
         // shared validity, applied in place (the caller resets / drops its period values right after): x = where(valid, x, 0)
-        double flag[VEC];
+        bool ok[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             bool valid = active;                                     // (lanes beyond the grid carry no weight and no run)
 #pragma unroll
             for (int j = 0; j < KMAX; ++j)
                 if (j < K) valid = valid && (val[j][i] == val[j][i]);
-            flag[i] = valid ? 1.0 : 0.0;
+            ok[i] = valid;
             if (!valid) {
                 KEEP_BRANCH();
 #pragma unroll
@@ -924,13 +935,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #pragma unroll
                     for (int j = 0; j < KMAX; ++j)
                         if (j < K) ex[j] = val[j][i];
-                    ex[K] = flag[i];
+                    ex[K] = ok[i] ? 1.0 : 0.0;
                 }
             }
         }
         // (the lanes' bit fields are made opaque here: tested where they are used, the compiler would otherwise hoist all the lane
         // masks they decode to out of the time loop — two dozen scalar register pairs that spilled into v_readlane traffic)
-        uint32_t rb = rfbits, rr = rfrid;
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 lw = *(const __attribute__((address_space(3))) u2*)(rf_park + VEC * 16);
+        uint32_t rb = lw.x, rr = lw.y;
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; rf_emit: begin" : "+v"(rb), "+v"(rr));
 #endif
@@ -954,6 +967,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #endif
             if (!(need & 128)) continue;                             // (uniform) no cell of this tile has an entry e
             const uint32_t bits = rb >> (16 * e), rid = rr >> (16 * e);
+            double rfw[VEC];                                         // the cells' weights for this entry, from the lane's parking block
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) rfw[i] = *(const __attribute__((address_space(3))) double*)(rf_park + i * 16 + e * 8);
             double* out0 = a.rf_out + (int64_t)at_slot * a.rf_slot_stride + (int64_t)rf_first[e] * a.rf_run_stride;
             double* dst0 = out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride;           // where this lane's cells store, if they end a run
             double* dst1 = out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride;
@@ -967,8 +983,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
                     const int q = q0 + qq;
                     v[qq] = 0.0; p0[qq] = 0.0;
                     if (q < NCOL) {
-                        p0[qq] = __dmul_rn(rfw[0][e], q == 0 ? flag[0] : val[q == 0 ? 0 : q - 1][0]);
-                        v[qq] = VEC == 2 ? __dmul_rn(rfw[VEC - 1][e], q == 0 ? flag[VEC - 1] : val[q == 0 ? 0 : q - 1][VEC - 1]) : p0[qq];
+                        // (the validity weight's product w * 1 / w * 0 is a select)
+                        p0[qq] = q == 0 ? (ok[0] ? rfw[0] : 0.0) : __dmul_rn(rfw[0], val[q == 0 ? 0 : q - 1][0]);
+                        v[qq] = VEC == 2 ? (q == 0 ? (ok[VEC - 1] ? rfw[VEC - 1] : 0.0) : __dmul_rn(rfw[VEC - 1], val[q == 0 ? 0 : q - 1][VEC - 1])) : p0[qq];
                     }
                 }
                 if constexpr (VEC == 2) {
