@@ -1057,13 +1057,23 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
             for (int64_t g = 0; all && g < desc->G1; ++g) all = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g] == L;
             if (all) glen = L;
         }
+        // mixed lengths of one to four rows (a sub-daily series with missing steps): the four-row form with a length per group
+        // (FEAT bit 13); a series of single rows throughout is not a short-group plan
+        if (glen == 0 && desc->T > desc->G1 && !getenv("AFHIP_NO_RAGGED_MODE")) {
+            bool all = true;
+            for (int64_t g = 0; all && g < desc->G1; ++g) {
+                const int64_t L = pl->ib[(size_t)g + 1] - pl->ib[(size_t)g];
+                all = L >= 1 && L <= 4;
+            }
+            if (all) glen = 5;
+        }
     }
-    if ((glen == 4 || glen == 3) && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
+    if (glen >= 3 && getenv("AFHIP_NO_QUAD_MODE")) glen = 0;
     // (its loads address a row by a 32-bit byte offset per lane: rows of 4 GiB and more take the general path)
     if ((uint64_t)desc->n_cells * (desc->dtype == AFHIP_F64 ? 8u : 4u) >= (1ull << 32)) glen = 0;
     bool pairs = glen >= 2;                              // short-group mode (two-, three- or four-row groups)
-    const bool quad_len = glen >= 3;                     // three / four rows: the lean form only, general sine closed forms
-    const int glcode = glen == 4 ? 1 : (glen == 3 ? 2 : 0);      // Variant::quad
+    const bool quad_len = glen >= 3;                     // three / four / mixed rows: the lean form only, general sine closed forms
+    const int glcode = glen == 5 ? 3 : (glen == 4 ? 1 : (glen == 3 ? 2 : 0));      // Variant::quad
     // pair plans whose columns are all  mean | sum | min | max | sine_dd -> (integer power) -> sum | mean  without float32 rounding
     // take the lean group end (FEAT bit 8); when every column is a plain sine_dd, its tightest form (FEAT bit 9).  A sine_dd
     // column there needs s0 < s1: its two max() terms are one clamp of width s1 - s0.
@@ -1085,7 +1095,8 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     if (pairs && pl->stat == 1) {
         // (three-row groups on float32: one- and two-column plans stream faster through the ring, 4.59 / 4.94 against 4.93 / 5.04 ms on
         // 1801 x 3600; from three columns on, and on float64 at every count, the lean form is ahead: profiles/r04_three_row_groups.txt)
-        int min_k = quad_len ? ((glen == 3 && desc->dtype == AFHIP_F32) ? 3 : 1) : 3;
+        // (mixed lengths likewise: 6.25 / 6.39 against 6.89 / 6.83 ms, float64 level; profiles/r04_mixed_short_groups.txt)
+        int min_k = quad_len ? (((glen == 3 || glen == 5) && desc->dtype == AFHIP_F32) ? 3 : 1) : 3;
         if (const char* e = getenv("AFHIP_LEAN_STAT1_MIN_K")) min_k = atoi(e);      // experiment knob
         if (!lean || pl->K < min_k) pairs = lean = lean_sine = false;
     }

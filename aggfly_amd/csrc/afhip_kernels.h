@@ -617,9 +617,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
     //              steps), so these variants read the acos table.
     // FEAT bit 12: ... and of exactly THREE rows (8-hourly data): the sum runs (u0 + u1) + u2, the mean is the correctly rounded s / 3
     //              (div_by with the correctly rounded reciprocal: bit-identical to the reference's division), otherwise like four rows.
-    constexpr int GL = (FEAT & 1024) ? 4 : ((FEAT & 4096) ? 3 : 2);
-    static_assert(!(FEAT & (1024 | 4096)) || (PAIR && LEAN && !LEAN_SINE), "three- / four-row groups: a lean short-group form");
-    static_assert((FEAT & (1024 | 4096)) != (1024 | 4096), "one group length per variant");
+    // FEAT bit 13: ... and of MIXED lengths one to four rows (a 6-hourly series with missing steps, a 12-hourly one joined to a
+    //              6-hourly one): every group owns four row registers and fills as many as it is long; its length is a scalar read from
+    //              the group table, the loads and the statistics' tail rows sit under scalar branches on it, the mean is div_by's
+    //              correctly rounded s / n (n = 2, 4: exact anyway).  Otherwise the four-row form.
+    constexpr bool RAG = (FEAT & 8192) != 0;
+    constexpr int GL = ((FEAT & 1024) || RAG) ? 4 : ((FEAT & 4096) ? 3 : 2);
+    static_assert(!(FEAT & (1024 | 4096 | 8192)) || (PAIR && LEAN && !LEAN_SINE), "three- / four-row / mixed groups: a lean short-group form");
+    static_assert(((FEAT & 1024) != 0) + ((FEAT & 4096) != 0) + ((FEAT & 8192) != 0) <= 1, "one group length rule per variant");
     static_assert(!PAIR || (PIPE == 0 && (STAT == 2 || (STAT == 1 && LEAN)) && NTHR == 0 && DEPTH % GL == 0),
                   "short-group mode: direct loads, sum (+ min + max), no threshold slots");
     static_assert(!LEAN || PAIR, "the lean group end is a short-group form");
@@ -1071,6 +1076,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
             if constexpr (PAIR) hasnan[i] = pnan[i];
             else hasnan[i] = ((nanmask[i] >> lane) & 1ull) != 0ull;
             if constexpr (PAIR && GL == 3) mean[i] = div_by(s[i], 3.0, 1.0 / 3.0);      // == s / 3 bit for bit (1.0 / 3.0: the correctly rounded reciprocal)
+            else if constexpr (PAIR && RAG) mean[i] = div_by(s[i], dn, inv_n);          // the group's own length (1 .. 4)
             else if constexpr (PAIR) mean[i] = s[i] * (1.0 / GL);      // == s / 2 (s / 4) bit for bit
             else mean[i] = (STAT >= 1) ? div_by(s[i], dn, inv_n) : 0.0;      // == s / dn bit for bit (inv_n = RN(1/n))
         }
@@ -1199,7 +1205,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
                             // correctly rounded quotient, already in mean[])
                             const double sc = src == SRC_SUM ? 1.0 : 1.0 / GL;
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) x[i] = (GL == 3 && src != SRC_SUM) ? mean[i] : s[i] * sc;
+                            for (int i = 0; i < VEC; ++i) x[i] = ((GL == 3 || RAG) && src != SRC_SUM) ? mean[i] : s[i] * sc;
                         } else {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) {
@@ -1555,6 +1561,86 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
         const char* nx = (const char*)a.cube + (size_t)(k_lo * C) * sizeof(TIn);       // the next row to load (uniform)
         const uint32_t voff = (uint32_t)((uint64_t)c_ld * sizeof(TIn));
         const size_t rowb = (size_t)C * sizeof(TIn);
+        if constexpr (RAG) {
+            // groups of one to four rows: slot q of the block holds group g + q in its four row registers, as many of them filled
+            // as the group is long.  Rows are requested in time order through the one scalar row pointer, a group's successor in
+            // its slot (group g + GB + q) as soon as its own rows have been reduced — the uniform forms' schedule with a scalar
+            // trip count on the loads.
+            auto rag_stats = [&](const RawVec<TIn, VEC>* rr, int len) {
+                TIn lo[VEC], hi[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const TIn u = rr[0].v[i];
+                    pnan[i] = u != u; s[i] = (double)u; lo[i] = u; hi[i] = u;
+                }
+#pragma unroll
+                for (int d = 1; d < GL; ++d) {
+                    if (d < len) {
+                        KEEP_BRANCH();
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const TIn v = rr[d].v[i];
+                            pnan[i] = pnan[i] || v != v;
+                            s[i] += (double)v;                                      // nb_kernels.py:130-137: k ascending
+                            if constexpr (STAT >= 2) {
+                                if constexpr (sizeof(TIn) == 4) {
+                                    asm("v_min_f32 %0, %1, %2" : "=v"(lo[i]) : "v"(lo[i]), "v"(v));
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(hi[i]) : "v"(hi[i]), "v"(v));
+                                } else {
+                                    asm("v_min_f64 %0, %1, %2" : "=v"(lo[i]) : "v"(lo[i]), "v"(v));
+                                    asm("v_max_f64 %0, %1, %2" : "=v"(hi[i]) : "v"(hi[i]), "v"(v));
+                                }
+                            }
+                        }
+                    }
+                }
+                if constexpr (STAT >= 2) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) { plo[i] = lo[i]; phi[i] = hi[i]; mn[i] = (double)lo[i]; mx[i] = (double)hi[i]; }
+                }
+            };
+            RawVec<TIn, VEC> r[DEPTH];
+            int lens[GB];
+            int k_next = (int)k_lo;                     // the next row to request (the cube's row index)
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                lens[q] = 0;
+                if (g + q < g_hi) {
+                    const int e = (int)(ld_uniform(&a.gtab[2 * (g + q)]) >> 1) & 0x7fffffff;
+                    lens[q] = e - k_next;
+                    k_next = e;
+                }
+#pragma unroll
+                for (int d = 0; d < GL; ++d) {
+                    if (d < lens[q]) { r[GL * q + d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+                    else r[GL * q + d] = r[0];         // (never read: the statistics stop at the group's length)
+                }
+            }
+            while (g < g_hi) {
+                const int ng = (g_hi - g) < GB ? (g_hi - g) : GB;
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    if (q < ng) {
+                        const int64_t w = ld_uniform(&a.gtab[2 * (g + q)]);
+                        const int len = lens[q];
+                        rag_stats(&r[GL * q], len);
+                        if (g + GB + q < g_hi) {
+                            const int e = (int)(ld_uniform(&a.gtab[2 * (g + GB + q)]) >> 1) & 0x7fffffff;
+                            const int ln = e - k_next;
+                            k_next = e;
+                            lens[q] = ln;
+#pragma unroll
+                            for (int d = 0; d < GL; ++d) {
+                                if (d < ln) { r[GL * q + d] = ld_stream_row<TIn, VEC, AUX>(nx, voff); nx += rowb; }
+                            }
+                        }
+                        const double inv = len == 3 ? 1.0 / 3.0 : (len == 2 ? 0.5 : (len == 4 ? 0.25 : 1.0));
+                        group_end((w & 1) != 0, len, inv, (int)((uint64_t)w >> 63), g + q);
+                    }
+                }
+                g += ng;
+            }
+        } else {
         RawVec<TIn, VEC> r[DEPTH];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -1579,6 +1665,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
             }
             g += ng;
             kk += GL * ng;
+        }
         }
     } else if constexpr (PIPE == 0) {
         const TIn* p = cube;

@@ -26,7 +26,7 @@ struct Variant {
     int pair;         // 1: plans whose inner groups all hold exactly two rows ((tmin, tmax) pairs)
     int ss;           // ... with the lean group end: 1 = columns mean | sum | min | max | sine_dd -> (integer power) -> sum | mean;
                       //     2 = every column a plain sine_dd -> sum | mean (the tightest form)
-    int quad;         // 1: ... for inner groups of exactly FOUR rows (6-hourly data) instead of two, 2: of exactly THREE rows (8-hourly); lean form only
+    int quad;         // 1: ... for inner groups of exactly FOUR rows (6-hourly data) instead of two, 2: of exactly THREE rows (8-hourly), 3: of one to four rows, mixed; lean form only
     int rf;           // 1: region-fused period ends compiled in (the twin of the variant with the same other fields)
     const void* fn;
     const char* name;

@@ -18,11 +18,11 @@ def menu(kind):
     out = []
     vec16 = {0: 4, 1: 2}
 
-    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0, ss=0, quad=0, rf=0, tri=0):
+    def add(dtype, pipe, vec, stat, nthr, kmax, depth, nt=1, prod=1, tki=0, sl=0, hb=0, ha=0, pair=0, ss=0, quad=0, rf=0, tri=0, rag=0):
         # sine degree days ride on the min/max accumulators; generic pow() only in the
         # all-purpose (STAT 3) variants; bit 2 = nt cache policy on the streaming loads;
         # bit 3 = integer bin counters; bit 4 = single-level plan (no outer accumulators)
-        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0) | (512 if ss == 2 else 0) | (1024 if quad else 0) | (2048 if rf else 0) | (4096 if tri else 0)
+        feat = {0: 0, 1: 0, 2: 1, 3: 3}[stat] | (4 if nt else 0) | (8 if tki else 0) | (16 if sl else 0) | (32 if hb else 0) | (64 if ha else 0) | (128 if pair else 0) | (256 if ss else 0) | (512 if ss == 2 else 0) | (1024 if quad else 0) | (2048 if rf else 0) | (4096 if tri else 0) | (8192 if rag else 0)
         key = (dtype, pipe, vec, stat, nthr, kmax, depth, feat)
         for i, v in enumerate(out):
             if v[:8] == key:
@@ -127,6 +127,15 @@ def menu(kind):
         dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
         if prod and pipe == 0 and kmax <= 6 and nthr <= 4 and not (feat & (8 | 16 | 32)):
             out.append((dtype, pipe, vec, stat, nthr, kmax, depth, feat | 2048, prod))
+    # inner groups of MIXED lengths one to four rows (FEAT bit 13; a sub-daily series with missing steps): the four-row form with a
+    # scalar trip count per group, and its region-fused twins — appended likewise
+    if kind != "dev":
+        for dtype in (0, 1):
+            for vec in ((1,) if dtype == 1 else (2, 1)):
+                for stat in (1, 2):
+                    for kmax in (2, 6):
+                        add(dtype, 0, vec, stat, 0, kmax, 8, pair=1, ss=1, rag=1)
+                        add(dtype, 0, vec, stat, 0, kmax, 8, pair=1, ss=1, rag=1, rf=1)
     # `full` = what the planner can pick; the tuning arms of the headline shapes (kbench.py / r03_arms.py `tuning=`; not production:
     # 74 kernels) are compiled by `make MENU=arms` only
     if kind != "arms":
@@ -137,7 +146,7 @@ def menu(kind):
 def name_of(v):
     dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
     return (f"{'f32' if dtype == 0 else 'f64'}_p{pipe}_v{vec}_s{stat}_t{nthr}_k{kmax}_d{depth}" + ("_nt" if feat & 4 else "")
-            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 512 else ("_lean" if feat & 256 else "")) + ("_quad" if feat & 1024 else "") + ("_tri" if feat & 4096 else "") + ("_rf" if feat & 2048 else ""))
+            + ("_ibins" if feat & 8 else "") + ("_sl" if feat & 16 else "") + ("_hist" if feat & 32 else "") + ("_arith" if feat & 64 else "") + ("_pair" if feat & 128 else "") + ("_ss" if feat & 512 else ("_lean" if feat & 256 else "")) + ("_quad" if feat & 1024 else "") + ("_tri" if feat & 4096 else "") + ("_rag" if feat & 8192 else "") + ("_rf" if feat & 2048 else ""))
 
 
 def inst(v):
@@ -200,7 +209,7 @@ def main():
             f.write(f"int register_variants_{idx:02d}(Variant* out) {{\n    int n = 0;\n")
             for v in group:
                 dtype, pipe, vec, stat, nthr, kmax, depth, feat, prod = v
-                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {2 if feat & 512 else (1 if feat & 256 else 0)}, {1 if feat & 1024 else (2 if feat & 4096 else 0)}, {1 if feat & 2048 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
+                f.write(f"    out[n++] = Variant{{{dtype}, {pipe}, {vec}, {stat}, {nthr}, {kmax}, {depth}, {1 if feat & 4 else 0}, {prod}, {1 if feat & 8 else 0}, {1 if feat & 16 else 0}, {1 if feat & 32 else 0}, {1 if feat & 64 else 0}, {1 if feat & 128 else 0}, {2 if feat & 512 else (1 if feat & 256 else 0)}, {1 if feat & 1024 else (2 if feat & 4096 else (3 if feat & 8192 else 0))}, {1 if feat & 2048 else 0}, (const void*)&{inst(v)}, \"{name_of(v)}\"}};\n")
             f.write("    return n;\n}\n}\n")
         files.append(fn)
     with _KeepIfSame(os.path.join(outdir, "variants_table.hip")) as f:

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--plan", default="c2")
     ap.add_argument("--spd", type=int, default=24)
     ap.add_argument("--periods", type=int, default=1)
+    ap.add_argument("--gaps", type=float, default=0.0, help="share of the inner groups that miss one step (a series with gaps: mixed group lengths)")
     ap.add_argument("--regions", type=int, default=3100)
     ap.add_argument("--data", default="era5", choices=["iid", "era5"])
     ap.add_argument("--arms", nargs="+", default=["base"])
@@ -75,6 +76,13 @@ def main():
             base = 15.0 + 12.0 * torch.sin(2 * np.pi * torch.floor(k / a.spd) / 365.0) + 6.0 * torch.sin(2 * np.pi * (k % a.spd) / a.spd - np.pi / 2)
             cube[k0:k1] = (base[:, None, None] * lat + 3.0 * noise).to(dt)
     ib = synth.hourly_bounds(a.T, a.spd)
+    if a.gaps > 0:
+        lens = np.diff(ib)
+        hit = np.random.default_rng(3).random(len(lens)) < a.gaps
+        lens = np.where(hit & (lens > 1), lens - 1, lens)
+        ib = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        a.T = int(ib[-1])
+        cube = cube[:a.T]
     G1 = len(ib) - 1
     ob = np.round(np.linspace(0, G1, a.periods + 1)).astype(np.int64)
     cols, single = columns(a.plan)

@@ -65,14 +65,19 @@ def _random_steps(rng):
     return steps
 
 
-def _time_axes(rng, T, spd, seed):
+def _time_axes(rng, T, spd, seed, whole_days=True):
     """(product index, oracle index, kept positions): standard or CF calendar, with a gap of whole
     days and a few single missing steps so that empty and ragged groups occur."""
     from oracle.ref_calendar import OracleCFIndex, cf_daily_index
     keep = np.ones(T, bool)
-    g0 = int(rng.integers(spd * 5, T - spd * 12))
-    keep[g0:g0 + spd * int(rng.integers(1, 5))] = False
-    keep[rng.integers(0, T, 4)] = False
+    if whole_days:
+        g0 = int(rng.integers(spd * 5, T - spd * 12))
+        keep[g0:g0 + spd * int(rng.integers(1, 5))] = False
+        keep[rng.integers(0, T, 4)] = False
+    else:       # single steps only, never a whole day: date groups of mixed lengths 1 .. spd, none empty
+        miss = rng.integers(0, T, 9)
+        miss = miss[np.unique(miss // spd, return_index=True)[1]]          # at most one missing step per day
+        keep[miss] = False
     keep = np.nonzero(keep)[0]
     cal = [None, "noleap", "360_day"][seed % 3] if seed >= 16 else None
     step_h = 24 // spd
@@ -86,17 +91,20 @@ def _time_axes(rng, T, spd, seed):
     return prod[keep], orc[keep], keep
 
 
-@pytest.mark.parametrize("seed", range(44))
+@pytest.mark.parametrize("seed", list(range(44)) + [47, 53, 59, 65])      # (the last four: series with single steps missing)
 def test_random_specs_match_oracle(torch_cuda, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = np.float64 if seed % 2 == 0 else np.float32
     spd = 24 if seed < 16 else int(rng.choice([1, 2, 24]))            # hourly; later seeds also daily / 12-hourly
     pair_seed = 28 <= seed < 36 or (seed >= 44 and seed % 3 == 0)      # (seeds beyond the parametrised ones: scripts/fuzz_more.py)
     quad_seed = 36 <= seed < 44 or (seed >= 44 and seed % 3 == 1)
+    gaps_seed = seed >= 44 and seed % 6 == 5      # 12- / 8- / 6-hourly steps with single steps missing: date groups of mixed lengths -> the `_rag` form
     if pair_seed:
         spd = 2             # unbroken (tmin, tmax)-like pairs: the date groups are all two rows -> pair mode and its lean group ends
     if quad_seed:
         spd = 4             # unbroken 6-hourly steps: the date groups are all four rows -> the four-row form of the lean group end
+    if gaps_seed:
+        spd = int(rng.choice([2, 3, 4]))
     ndays = int(rng.integers(70, 130)) if spd == 24 else int(rng.integers(400, 800))
     T, ny, nx = spd * ndays + (int(rng.integers(0, 24)) if spd == 24 else 0), int(rng.integers(3, 9)), int(rng.integers(3, 12))
     cube = synth.temperature_cube(T, ny, nx, dtype=dtype, seed=seed, steps_per_day=spd, ocean_frac=0.1, scattered_nan=15)
@@ -105,7 +113,7 @@ def test_random_specs_match_oracle(torch_cuda, seed):
     elif pair_seed or quad_seed:
         time = otime = pd.date_range("2001-11-17 00:00", periods=T, freq="12h" if pair_seed else "6h")
     else:
-        time, otime, keep = _time_axes(rng, T, spd, seed)
+        time, otime, keep = _time_axes(rng, T, spd, seed, whole_days=not gaps_seed)
         cube = np.ascontiguousarray(cube[keep])
         T = len(keep)
     lon360 = bool(seed % 3 == 0)

@@ -839,7 +839,7 @@ def test_slot_gather_spatial_stage_against_the_panel_route_and_the_oracle(torch_
 
 
 @pytest.mark.parametrize("kind", ["hourly_f64", "hourly_f32", "daily_f32", "hourly_f64_lognormal", "six_hourly_f32", "six_hourly_f64", "pairs_poly_f32",
-                                  "pairs_sine_f32", "pairs_two_f64", "dd_only_f32", "daily_multi_dd_f32", "eight_hourly_f32"])
+                                  "pairs_sine_f32", "pairs_two_f64", "dd_only_f32", "daily_multi_dd_f32", "eight_hourly_f32", "gaps_f32"])
 def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkeypatch, kind):
     """Plans with several output periods, sum-like outer reducers and no per-cell output reduce their cells by region INSIDE the
     streaming kernel at every period end (FusedArgs::rf_w: per-run weighted sums from a wave-private LDS block, k_rf_reduce adds a
@@ -890,6 +890,11 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         T = spd * 60
         cube = _cube(T, ny, nx, dtype, seed=49)
         cols = [dict(inner="mean", transform="pow", transform_arg=float(e), outer="sum") for e in (1, 2)] + [dict(inner="min", outer="mean")]
+    elif kind == "gaps_f32":
+        dtype, spd = np.float32, 4                                   # 6-hourly data with missing steps: groups of two to four rows, the `_rag` form
+        T = spd * 60 - 17
+        cube = _cube(T, ny, nx, dtype, seed=50)
+        cols = [dict(inner="mean", transform="pow", transform_arg=float(e), outer="sum") for e in (1, 2)] + [dict(inner="max", outer="mean")]
     elif kind in ("dd_only_f32", "daily_multi_dd_f32"):
         dtype = np.float32
         T, spd = 24 * 60, 24
@@ -905,6 +910,12 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
     code = hip.F64 if dtype == np.float64 else hip.F32
     d = torch_cuda.from_numpy(cube).cuda()
     ib = synth.hourly_bounds(T, spd)                                 # 60 inner groups
+    if kind == "gaps_f32":
+        lens = np.full(60, 4)
+        lens[np.random.default_rng(51).choice(60, 13, replace=False)] = 3
+        lens[[7, 31]] = 2
+        ib = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        assert ib[-1] == T
     # periods short enough to stay whole on this small grid (a period cut into several slots rules the route out): twelve or
     # six periods, the second one empty
     ob = (np.array([0, 5, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50, 55, 60], dtype=np.int64) if spd == 24
@@ -934,6 +945,8 @@ def test_region_fused_period_ends_against_the_per_cell_routes(torch_cuda, monkey
         assert "_k16_" in k13.describe() and "region-fused" not in k13.describe(), k13.describe()
     if kind == "eight_hourly_f32":
         assert "_tri" in plan.describe(), plan.describe()
+    if kind == "gaps_f32":
+        assert "_rag" in plan.describe(), plan.describe()
     if kind == "daily_multi_dd_f32":
         assert "_sl" not in plan.describe().split()[0], plan.describe()   # the two-level variant (it has a twin), not the single-level one
     fused = plan.run(d, csr)
@@ -1200,6 +1213,90 @@ def test_four_and_three_row_groups_take_the_lean_group_end(torch_cuda, dtype, sh
     quadp = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
     assert quadp.describe().split()[0].endswith(suffix)
     np.testing.assert_allclose(quadp.run_temporal(d).cpu().numpy(), ring.run_temporal(d).cpu().numpy(), rtol=4e-15, equal_nan=True)
+
+
+def _mixed_bounds(rng, G1, mix):
+    """inner bounds with group lengths drawn from `mix` ({length: share}); the first and last groups are the mix's shortest / longest"""
+    lens = rng.choice(list(mix), size=G1, p=np.array(list(mix.values()), dtype=float) / sum(mix.values()))
+    lens[0], lens[-1] = min(mix), max(mix)
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mix", [{4: 0.9, 3: 0.07, 2: 0.03}, {1: 1, 2: 1, 3: 1, 4: 1}, {2: 0.5, 4: 0.5}, {1: 0.5, 2: 0.5}], ids=["gaps", "any", "2or4", "1or2"])
+@pytest.mark.parametrize("shape", [(150, 6, 20), (151, 3, 130)])
+def test_mixed_short_groups_take_the_lean_group_end(torch_cuda, monkeypatch, dtype, mix, shape):
+    """A sub-daily series with missing steps (6-hourly data with gaps; a 12-hourly record joined to a 6-hourly one): inner groups of
+    one to four rows, mixed.  `resample_groups` (`nb_kernels.py:80-115`) hands such bounds to the same kernels as any other; here the
+    plans that qualify for the lean group end take the `_rag` form (FEAT bit 13: four row registers per group, a scalar length per
+    group from the group table).  The sum runs in time order and the mean is the correctly rounded s / n, so mean / sum / min / max
+    are bit-exact against `cport.block_stat` (`nb_kernels.py:121-155`); plans that do not qualify leave the short-group path; the
+    knob that switches the form off gives the same numbers through the general path."""
+    from aggfly_amd import hip
+    G1, ny, nx = shape
+    rng = np.random.default_rng(29 + G1)
+    ib = _mixed_bounds(rng, G1, mix)
+    T = int(ib[-1])
+    k = np.arange(T)
+    cube = (15 + 10 * np.sin(2 * np.pi * k / 365.0))[:, None, None] + rng.normal(0, 5, (T, ny, nx))
+    cube[rng.integers(0, T, 9), rng.integers(0, ny, 9), rng.integers(0, nx, 9)] = np.nan
+    cube[:, 1, 2] = np.nan
+    cube = cube.astype(dtype)
+    ob = np.array([0, 20, 21, G1], dtype=np.int64)
+    d = torch_cuda.from_numpy(cube).cuda()
+    f64 = cube.astype(np.float64)
+    code = hip.F64 if dtype == np.float64 else hip.F32
+
+    def want(col, obounds):
+        x = cport.resample(f64, ib, col["inner"], col.get("inner_args"))
+        if col.get("transform") == "pow":
+            x = cport.power(x, col["transform_arg"])
+        elif col.get("transform") == "hinge":
+            x = (x > col["transform_arg"]) * (x - col["transform_arg"])
+        return cport.resample(x, obounds, col["outer"])
+
+    poly = [dict(inner="mean", transform="pow", transform_arg=e, outer="sum") for e in (1, 2, 3, 4)]
+    mixed = [dict(inner="min", outer="sum"), dict(inner="max", transform="pow", transform_arg=2, outer="mean"),
+             dict(inner="sine_dd", inner_args=(10, 30, 0), outer="sum"), dict(inner="mean", outer="mean"), dict(inner="sum", outer="sum"),
+             dict(inner="sine_dd", inner_args=(0, 18, 1), outer="mean")]
+    two = [dict(inner="max", outer="sum"), dict(inner="min", outer="mean")]
+    generic = [dict(inner="mean", transform="hinge", transform_arg=20.0, outer="sum"), dict(inner="max", outer="max")]
+    light = [dict(inner="mean", outer="sum")]
+    # (one- and two-column mean / sum plans on float32 stream faster through the ring, as with three-row groups: the planner keeps them there)
+    for cols, rag in ((poly, True), (mixed, True), (two, True), (generic, False), (light, dtype == np.float64)):
+        plan = hip.FusedPlan(T, ny * nx, code, ib, ob, cols, exact_order=True)
+        name = plan.describe().split()[0]
+        assert name.endswith("_rag") == rag, name
+        got = plan.run_temporal(d).cpu().numpy()
+        for kk, col in enumerate(cols):
+            w = want(col, ob).reshape(len(ob) - 1, -1)
+            assert np.array_equal(np.isnan(got[kk]), np.isnan(w)), (name, col)
+            if col["inner"] == "sine_dd":
+                np.testing.assert_allclose(got[kk], w, rtol=1e-10, atol=1e-10, equal_nan=True)
+            elif col.get("transform") == "pow":
+                np.testing.assert_allclose(got[kk], w, rtol=4e-15, equal_nan=True)
+            else:
+                np.testing.assert_array_equal(got[kk], w)
+    # many periods: one time chunk per period (chunks of a few groups, shorter than a block of rows; a chunk's first row is not the cube's)
+    obm = np.unique(np.concatenate([[0], rng.integers(1, G1, 40), [G1]])).astype(np.int64)
+    pm = hip.FusedPlan(T, ny * nx, code, ib, obm, mixed, exact_order=True)
+    assert pm.describe().split()[0].endswith("_rag"), pm.describe()
+    gm = pm.run_temporal(d).cpu().numpy()
+    for kk, col in enumerate(mixed):
+        w = want(col, obm).reshape(len(obm) - 1, -1)
+        assert np.array_equal(np.isnan(gm[kk]), np.isnan(w)), col
+        np.testing.assert_allclose(gm[kk], w, rtol=1e-10 if col["inner"] == "sine_dd" else 4e-15, atol=1e-10 if col["inner"] == "sine_dd" else 0, equal_nan=True)
+    monkeypatch.setenv("AFHIP_NO_RAGGED_MODE", "1")
+    ring = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
+    monkeypatch.delenv("AFHIP_NO_RAGGED_MODE")
+    assert "_rag" not in ring.describe().split()[0] and "_pair" not in ring.describe().split()[0], ring.describe()
+    ragp = hip.FusedPlan(T, ny * nx, code, ib, ob, poly, exact_order=True)
+    np.testing.assert_allclose(ragp.run_temporal(d).cpu().numpy(), ring.run_temporal(d).cpu().numpy(), rtol=4e-15, equal_nan=True)
+    # an empty group among them, or one of five rows: not a short-group plan
+    for bad in (np.concatenate([ib[:5], ib[4:]]), np.concatenate([ib[:3], ib[3:] + 4])):
+        Tb = int(bad[-1])
+        pb = hip.FusedPlan(Tb, ny * nx, code, bad, np.array([0, len(bad) - 1], dtype=np.int64), poly)
+        assert "_rag" not in pb.describe().split()[0], pb.describe()
 
 
 @pytest.mark.parametrize("glen", [2, 3, 4])
