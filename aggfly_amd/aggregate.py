@@ -335,21 +335,40 @@ def _zero_weight_regions(wdf) -> set:
     return zr
 
 
-def _download(t):
-    """HBM tensor -> numpy.  Large results go through page-locked memory from torch's caching host allocator (pageable
+def _download(t, wait=True):
+    """HBM tensor -> numpy (``wait=False``: the copy is queued on the current stream; the caller synchronises before reading).  Large results go through page-locked memory from torch's caching host allocator (pageable
     D2H copies run at ~12 GB/s here, pinned ones at the PCIe rate: the 94 MB panel of configs[3] takes 8 ms vs 2);
     the array keeps its block alive and the allocator reuses it once the frame built on it is dropped."""
     import torch
-    if t.numel() * t.element_size() < (1 << 20):
+    if t.numel() * t.element_size() < (1 << 20) or not t.is_cuda:
         return t.cpu().numpy()
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
+    if wait:
+        torch.cuda.current_stream(t.device).synchronize()
     return host.numpy()
 
 
-def _assemble_frame(res, names, region_ids, labels, weights) -> pd.DataFrame:
+def _region_key_column(rid, n_time, weights):
+    """The region table's id column for a full region-major panel (every region `n_time` rows), or None when `_merge_regions`'
+    lookup does not apply (no table given, an index that is not unique and ascending, region ids out of order or not in it)."""
+    if weights is None:
+        return None
+    gr = weights.georegions
+    idx = gr.shp.index
+    if not (idx.is_unique and idx.is_monotonic_increasing) or (len(rid) > 1 and not bool((rid[1:] > rid[:-1]).all())):
+        return None
+    upos = idx.get_indexer(rid)
+    if (upos < 0).any():
+        return None
+    return np.repeat(gr.shp[gr.regionid].to_numpy()[upos], n_time)
+
+
+def _assemble_frame(res, names, region_ids, labels, weights, merge_with=None) -> pd.DataFrame:
     """Long frame + NaN-row policy (`spatial.py:136-154`).  res: [K, R, P], a numpy array or an HBM tensor.
+    ``merge_with``: the weights whose region table the caller would merge the frame with next (`aggregate_dataset`): a full panel
+    then carries the table's id column straight away (frame.attrs["_merged"]) instead of positions that `_merge_regions` scans
+    again — a million-row daily panel spends more time in those passes than in the kernels.
 
     The rows to keep are found on the [R, P] panel and only those are materialised — on the GPU when the
     panel is still there (mask, compaction, then one download of the kept values).  The reference builds
@@ -375,15 +394,27 @@ def _assemble_frame(res, names, region_ids, labels, weights) -> pd.DataFrame:
         ok = ~torch.isnan(res).any(dim=0) if names else torch.ones((n_regions, n_time), dtype=torch.bool, device=res.device)
         if zero_mask is not None:
             ok = ok | torch.as_tensor(zero_mask, device=res.device)[:, None]
+        n_ok = ok.sum()                                 # (queued behind the kernels; read below)
+        kept = _download(res.reshape(res.shape[0], -1), wait=False) if names else None      # ... and the panel's way home, should it be full
+        # the key and time columns of a full panel do not depend on the results: built while the kernels still run
+        key = _region_key_column(rid, n_time, merge_with)
+        if key is None:
+            cols = {"region_id": np.repeat(rid, n_time)}
+        else:                                           # aggregate_dataset: the merge with the region table is a lookup per region
+            cols = {merge_with.georegions.regionid: key}
+        cols["time"] = np.tile(_label_values(labels), n_regions)
+        if int(n_ok) == n_regions * n_time:             # (reading it waits for the stream: the panel's copy is over too)
+            # nothing dropped (the usual case): repeat / tile, like the reference
+            for k, nm in enumerate(names):
+                cols[nm] = kept[k]
+            df = pd.DataFrame(cols, copy=False)
+            if key is not None:
+                df.attrs["_merged"] = True
+            return df
         flat = ok.reshape(-1).nonzero().squeeze(1)
         kept = _download(res.reshape(res.shape[0], -1).index_select(1, flat)) if names else None
         flat = _download(flat)
         vals = [kept[k] for k in range(len(names))]
-        if len(flat) == n_regions * n_time:             # nothing dropped (the usual case): repeat / tile, like the reference
-            cols = {"region_id": np.repeat(rid, n_time), "time": np.tile(_label_values(labels), n_regions)}
-            for nm, v in zip(names, vals):
-                cols[nm] = v
-            return pd.DataFrame(cols, copy=False)
         ri, ti = np.divmod(flat, n_time)
     cols = {"region_id": rid[ri], "time": _label_values(labels)[ti]}
     for nm, v in zip(names, vals):
@@ -482,7 +513,10 @@ def aggregate_dataset(weights, dataset: Dataset = None, aggregator_dict=None, da
         aggregator_dict = kwargs
     if aggregator_dict is not None:
         res, names, region_ids, labels = panel_arrays(weights, dataset, aggregator_dict, engine)
-        df = _assemble_frame(res, names, region_ids, labels, weights)
+        merge_ok = weights.georegions.regionid not in list(names) + ["time", "region_id"]
+        df = _assemble_frame(res, names, region_ids, labels, weights, merge_with=weights if merge_ok else None)
+        if df.attrs.pop("_merged", False):
+            return df
     else:
         if dataset_dict is None:
             dataset_dict = {"variable": dataset}

@@ -28,3 +28,11 @@ for name, sp in (("daily panel (P=365, K=5)", spec),
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     out[name] = {"rows": len(df), "columns": len(df.columns), "aggregate_dataset_ms": best * 1e3, "cell_steps_per_s": T * ny * nx / best}
 print(json.dumps(out, indent=1))
+if os.environ.get("API_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        af.aggregate_dataset(dataset=ds, weights=w, **spec)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

@@ -345,6 +345,16 @@ def test_frame_assembly_and_region_merge_equal_the_reference_recipe():
             pd.testing.assert_frame_equal(got, want)
             merged = shp[["geoid"]].merge(want, left_index=True, right_on="region_id").drop(columns="region_id")
             pd.testing.assert_frame_equal(agg._merge_regions(got, w), merged)
+            # the panel as a tensor (where it is when the kernels have run), with the region table named: a FULL panel carries the
+            # table's id column straight away (attrs["_merged"]), anything else takes the two steps above — same frames either way
+            import torch
+            for panel in (res, np.where(np.isnan(res), 0.5, res)):
+                want_t = recipe(panel, names, rid, labels, w)
+                merged_t = shp[["geoid"]].merge(want_t, left_index=True, right_on="region_id").drop(columns="region_id")
+                got_t = agg._assemble_frame(torch.from_numpy(panel), names, rid, labels, w, merge_with=w)
+                direct = got_t.attrs.pop("_merged", False)
+                assert direct == (not np.isnan(panel).any() and index.is_monotonic_increasing and 9999 not in rid), (trial, direct)
+                pd.testing.assert_frame_equal(got_t if direct else agg._merge_regions(got_t, w), merged_t)
 
 
 def test_cf_time_sel_is_month_and_day_granular():
