@@ -758,18 +758,23 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     za, device, cb, idxs, cube = job.za, job.device, job.cb, job.idxs, job.cube
     bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
     nblk = max(1, -(-cb // bsz))
-    # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), so a batch takes about
-    # that long whatever its size, and the kernels of neighbouring batches were not seen to overlap: few, large batches
-    # (swept 128 / 256 / 512 MB x 2 / 4 slots on 0.9 and 3.4 GB stores: profiles/r02_gpu_decode_sweep.txt)
-    env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")     # default: a quarter of the request, 128-512 MB
-    batch_bytes = (int(env_mb) << 20) if env_mb else min(max(len(idxs) * cb // 4, 128 << 20), 512 << 20)
-    per = max(1, min(batch_bytes // cb, 65535 // nblk, 4096, len(idxs)))
-    # a quarter-size first and last batch: the upload starts after a short read, and less work is left when the host has
-    # run out of batches to overlap it with
-    cuts = list(range(0, len(idxs), per)) + [len(idxs)]
-    if len(idxs) > 2 * per and per >= 8:
-        q = per // 4
-        cuts = sorted(set([0] + list(range(q, len(idxs) - q, per)) + [len(idxs) - q, len(idxs)]))
+    # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), and a batch of ~60 chunks of this
+    # shape (9 k streams) fills the card's wave slots once: smaller batches take as long as that one, larger ones scale.  Equal
+    # batches of ~144 MB decoded (at most 16 of them; 512 MB at most each) measured best on 0.34 / 0.86 / 3.4 GB stores — 9.2 / 15.6 /
+    # 48.8 ms against 11.4 / 17.1 / 51.3 for round 2's rule (a quarter of the request per batch, 128-512 MB, with a quarter-size first
+    # and last batch): profiles/r04_ingest_batches.txt
+    env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")
+    total = len(idxs) * cb
+    n_batches = min(16, max(1, -(-total // (144 << 20))))
+    batch_bytes = (int(env_mb) << 20) if env_mb else min(-(-total // n_batches), 512 << 20)
+    per = max(1, min(-(-batch_bytes // cb), 65535 // nblk, 4096, len(idxs)))
+    n_batches = -(-len(idxs) // per)
+    cuts = sorted(set(int(round(i * len(idxs) / n_batches)) for i in range(n_batches + 1)))
+    per = max(b - a for a, b in zip(cuts, cuts[1:]))
+    env_cuts = os.environ.get("AGGFLY_HIP_GPU_DECODE_CUTS")      # experiment knob: batch ends as fractions of the request, e.g. "0.1,0.5,0.9"
+    if env_cuts:
+        cuts = sorted(set([0, len(idxs)] + [min(len(idxs), max(0, int(round(float(f) * len(idxs))))) for f in env_cuts.split(",")]))
+        per = max(b - a for a, b in zip(cuts, cuts[1:]))
     # staging slots in flight: 4 (3 measured 7 % slower), 6 when every batch is one big chunk (the converter's 265 MB chunks)
     nstage = max(1, min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "6" if per == 1 else "4")), len(cuts) - 1))
     cube_bytes = cube.view(torch.uint8).reshape(-1) if job.whole_steps else None
