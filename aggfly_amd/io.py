@@ -764,6 +764,16 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     # 48.8 ms against 11.4 / 17.1 / 51.3 for round 2's rule (a quarter of the request per batch, 128-512 MB, with a quarter-size first
     # and last batch): profiles/r04_ingest_batches.txt
     env_mb = os.environ.get("AGGFLY_HIP_GPU_DECODE_BATCH_MB")
+    # The last chunks of the request are decoded by the HOST threads — idle once the files are read, while the compressed uploads
+    # still queue — and go up decoded behind them: the decode kernels of the last compressed batch (~2.9 ms, a latency no batch size
+    # shortens) then run under that upload instead of after everything else.  As many chunks as cross PCIe decoded in that time
+    # (~128-160 MB), at most a fifth of the request.
+    # (AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB: 128 measured best — 0.34 / 0.86 / 3.4 GB stores 9.3 / 15.6 / 48.5 -> 8.3 / 14.0 / 46.7 ms;
+    # ..._MIN_MB: requests below it have no such tail — the route itself starts at 256 MB by default; tests set 0)
+    tail_mb = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", "128"))
+    tail_min = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB", "256")) << 20
+    n_tail = min(max((tail_mb << 20) // cb, 1 if tail_mb > 0 else 0), len(idxs) // 5) if len(idxs) * cb >= tail_min else 0
+    all_idxs, idxs = idxs, idxs[:len(idxs) - n_tail]
     total = len(idxs) * cb
     n_batches = min(16, max(1, -(-total // (144 << 20))))
     batch_bytes = (int(env_mb) << 20) if env_mb else min(-(-total // n_batches), 512 << 20)
@@ -783,7 +793,12 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     cap_streams = per * (nblk * tsz + cb // 65536 + 2)          # one stream per byte plane of a block; stored chunks in 64 KiB pieces
     cap_blocks = per * nblk
     rec_bytes = cap_streams * codec.LZ4_STREAM.itemsize + cap_blocks * codec.SHUFFLE_BLOCK.itemsize
-    host = _pinned_stage(per * cmax + rec_bytes, nstage, device)
+    # (the page-locked buffers are cached per size class: the tail's is one MORE of the slots' class when the two coincide)
+    cls = lambda n: 1 << max(20, (int(n) - 1).bit_length())
+    shared = n_tail > 0 and cls(n_tail * cb) == cls(per * cmax + rec_bytes)
+    host = _pinned_stage(per * cmax + rec_bytes, nstage + (1 if shared else 0), device)
+    thost = host[nstage] if shared else (_pinned_stage(n_tail * cb, 1, device)[0] if n_tail else None)
+    host = host[:nstage]
     comp_dev = [torch.empty(per * cmax + rec_bytes, dtype=torch.uint8, device=device) for _ in range(nstage)]
     tmp_dev = [torch.empty(per * (cb + 16 * nblk + 16), dtype=torch.uint8, device=device) for _ in range(nstage)]
     staged = [None] * nstage                             # decoded chunks of batches that cannot go straight into the cube
@@ -813,12 +828,25 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     try:
         _gpu_decode_batches(job, threads, cuts, per, cmax, cap_streams, cap_blocks, nstage, host, comp_dev, tmp_dev, staged, errors,
                             copy_stream, work_streams, done, uploaded, trace, cube_bytes)
+        if n_tail:
+            tail = all_idxs[len(idxs):]
+            tdev = torch.empty(n_tail * cb, dtype=torch.uint8, device=device)
+            hbuf = thost[:n_tail * cb].numpy()
+            res = codec.decode_ranges(za.native_kind, [za.chunk_locator(i) for i in tail], [hbuf[i * cb:(i + 1) * cb] for i in range(n_tail)],
+                                      threads=threads)
+            trace.lap("read")
+            with torch.cuda.stream(copy_stream):        # behind the compressed uploads; the placement runs on the copy stream too
+                tdev.copy_(thost[:n_tail * cb], non_blocking=True)
+                job.place(tail, res, tdev)
+            trace.lap("enqueue")
     except BaseException:
         drain()
         raise
     last = two[0]
     for ws in two[1:]:
         last.wait_stream(ws)
+    if n_tail:
+        last.wait_stream(copy_stream)                    # (the tail's placement ran there)
     with torch.cuda.stream(last):
         if post is not None:
             post(cube)

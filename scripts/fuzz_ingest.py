@@ -44,6 +44,8 @@ for seed in range(lo, hi):
         for mode in ("1", "0"):
             os.environ["AGGFLY_HIP_GPU_DECODE"] = mode
             os.environ["AGGFLY_HIP_GPU_DECODE_BATCH_MB"] = str(int(rng.choice([1, 2, 64])))
+            os.environ["AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB"] = str(int(rng.choice([0, 256])))      # 0: a host-decoded tail on these small requests too
+            os.environ["AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB"] = str(int(rng.choice([0, 1, 128])))
             got = af.dataset_from_path(store, "v", lon_is_360=True, device="cuda", time_sel=sel).cube().cpu().numpy()
             ok = got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
             if not ok:

@@ -24,7 +24,10 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         for sname in settings:
             os.environ.pop("AGGFLY_HIP_GPU_DECODE_CUTS", None)
             os.environ.pop("AGGFLY_HIP_GPU_DECODE_SLOTS", None)
-            if sname.startswith("slots="):                             # default cuts, another number of staging slots
+            os.environ.pop("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", None)
+            if sname.startswith("tail="):                              # default cuts, another size of the host-decoded tail (MB)
+                os.environ["AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB"] = sname[5:]
+            elif sname.startswith("slots="):                             # default cuts, another number of staging slots
                 os.environ["AGGFLY_HIP_GPU_DECODE_SLOTS"] = sname[6:]
             elif sname != "default":
                 os.environ["AGGFLY_HIP_GPU_DECODE_CUTS"] = sname
