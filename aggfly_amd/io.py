@@ -772,7 +772,8 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     # ..._MIN_MB: requests below it have no such tail — the route itself starts at 256 MB by default; tests set 0)
     tail_mb = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", "128"))
     tail_min = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB", "256")) << 20
-    n_tail = min(max((tail_mb << 20) // cb, 1 if tail_mb > 0 else 0), len(idxs) // 5) if len(idxs) * cb >= tail_min else 0
+    tail_pct = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MAX_PCT", "20"))
+    n_tail = min(max((tail_mb << 20) // cb, 1 if tail_mb > 0 else 0), len(idxs) * tail_pct // 100) if len(idxs) * cb >= tail_min else 0
     all_idxs, idxs = idxs, idxs[:len(idxs) - n_tail]
     total = len(idxs) * cb
     n_batches = min(16, max(1, -(-total // (144 << 20))))

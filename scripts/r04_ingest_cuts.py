@@ -11,12 +11,20 @@ from aggfly_amd import synth
 
 T, ny, nx = int(os.environ.get("HOURS", 8760)), 104, 236
 arr = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=1) + np.float32(273.15)
+if os.environ.get("FIELD", "noisy") != "noisy":        # smooth fields quantised like reanalysis output (scripts/r02_gpu_decode_ratio.py): Blosc ratio 2 - 6
+    k = np.arange(T)[:, None, None]; y = np.arange(ny)[None, :, None]; x = np.arange(nx)[None, None, :]
+    smooth = 285 + 12 * np.sin(2 * np.pi * k / 8760.0) + 5 * np.sin(2 * np.pi * (k % 24) / 24) + 8 * np.sin(y / 17.0) * np.cos(x / 23.0)
+    if os.environ["FIELD"] == "smooth_noise":
+        smooth = smooth + np.random.default_rng(1).normal(0, 0.3, smooth.shape)
+    arr = (np.round(smooth * 100) / 100).astype(np.float32)
 ds = af.Dataset(af.DataArray(arr, ["time", "latitude", "longitude"], {"time": pd.date_range("2001-01-01", periods=T, freq="h"),
                                                                        "latitude": np.arange(ny) * 0.25, "longitude": np.arange(nx) * 0.25}), lon_is_360=False)
 settings = os.environ["CUTS_LIST"].split(";") if os.environ.get("CUTS_LIST") else ["default", "0.25,0.5,0.75"]
 with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
     store = os.path.join(d, "s.zarr")
     af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 24, "latitude": ny, "longitude": nx}, compress="blosc")
+    size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(store) for f in fs)
+    print(f"store: {arr.nbytes / 1e6:.0f} MB decoded, {size / 1e6:.0f} MB on disk (ratio {arr.nbytes / size:.2f})", flush=True)
     fn = lambda: af.dataset_from_path(store, "t2m", lon_is_360=False, device="cuda")
     os.environ["AGGFLY_HIP_GPU_DECODE"] = "1"
     fn(); torch.cuda.synchronize()
