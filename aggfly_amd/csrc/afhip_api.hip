@@ -58,8 +58,8 @@ int fail(int code, const char* fmt, ...) {
 constexpr int MAX_DEVICES = 64;
 struct DevState {
     int cus = -1;                  // compute units (hipDeviceProp_t::multiProcessorCount)
-    double* sine_tab = nullptr;    // acos table of the sine_dd closed forms (afhip_kernels.h: sine_theta), uploaded on first use
-    double* sine_p2 = nullptr;     // P2 table of the pair-mode arc (afhip_kernels.h: sine_pair_f; afhip_sine_p2_table.h), uploaded on first use
+    double* sine_tab = nullptr;    // acos table of the sine_dd closed forms (afhip_sine.h: sine_theta), uploaded on first use
+    double* sine_p2 = nullptr;     // P2 table of the pair-mode arc (afhip_sine.h: sine_pair_g; afhip_sine_p2_table.h), uploaded on first use
 };
 DevState g_dev[MAX_DEVICES];
 std::mutex g_dev_mu;
@@ -111,7 +111,7 @@ int pointer_device(const void* p) {
     return at.device;
 }
 
-// The acos table of sine_theta (afhip_kernels.h), in the layout the kernel copies into LDS: SINE_ROWS pairs of rows
+// The acos table of sine_theta (afhip_sine.h), in the layout the kernel copies into LDS: SINE_ROWS pairs of rows
 // (C, S, TH, 0); pair k belongs to phi_k = asin(k / 256):
 //   row 2k     (a <= g: theta = pi/2 - asin(u)):  (-cos phi_k, +sin phi_k, pi/2 - phi_k)
 //   row 2k + 1 (a >  g: theta = asin(u)):         (+cos phi_k, -sin phi_k, phi_k)

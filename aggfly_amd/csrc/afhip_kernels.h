@@ -152,397 +152,13 @@ struct FusedArgs {
     int32_t rf_lds_off, rf_pad;    // byte offset, in the dynamic LDS, of the waves' parking blocks: RF_LANE_BYTES per lane (weights + lane words)
 };
 
-// ---------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double nan64() { return __longlong_as_double(0x7ff8000000000000LL); }
-__device__ __forceinline__ double inf64() { return __longlong_as_double(0x7ff0000000000000LL); }
+}  // namespace afhip
 
-// A volatile empty asm cannot be speculated, so a block that starts with it stays behind its branch.
-#define KEEP_BRANCH() asm volatile("")
+#include "afhip_numerics.h"
+#include "afhip_sine.h"
+#include "afhip_loads.h"
 
-// x**e for a small integer e, evaluated as a double-double product chain so that the
-// result is the correctly rounded power in all but ~1e-14 of cases — what libm's pow()
-// behind np.power (dataset.py:543) returns.  Plain repeated multiplication differs from
-// np.power in the last bit for 26-35 % of inputs at e = 3, 4.
-// The exponent is wave-uniform: one scalar loop drives the N independent chains of a lane.
-//
-// The pair (hi, lo) is NOT renormalised between steps: (hi + lo) x = p + (err + lo x) with p = RN(hi x), err = hi x - p exactly
-// (one fma) and the small term rounded once (a second fma) — |lo| stays within a few ulps of hi for every exponent lowered to this
-// form (|e| <= 64), so its rounding errors are of order 2^-106 and only the final hi + lo rounds at 2^-53.  Three instructions per
-// step, two for the first (lo = 0), instead of the six of a renormalising step: x^3 6 instructions, x^4 9 (were 13 and 19).
-template <int N, bool NEG = true>
-__device__ __forceinline__ void powi_dd_vec(double (&x)[N], int e) {
-    if (e == 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = 1.0;
-        return;
-    }
-    const int n = e < 0 ? -e : e;
-    if (n == 2) {                       // the chain's first step is RN(x * x) exactly: one multiply
-        KEEP_BRANCH();
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = x[i] * x[i];
-    } else if (n > 2) {
-        double hi[N], lo[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) { hi[i] = x[i] * x[i]; lo[i] = __fma_rn(x[i], x[i], -hi[i]); }
-        auto step = [&]() {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double p = hi[i] * x[i];
-                const double err = __fma_rn(hi[i], x[i], -p);
-                lo[i] = __fma_rn(lo[i], x[i], err);
-                hi[i] = p;
-            }
-        };
-        step();                         // n >= 3; the cube and the fourth power (polynomials) are straight-line code: a loop
-        if (n > 3) {                    // carries (hi, lo) through register copies
-            KEEP_BRANCH();
-            step();
-            for (int it = 4; it < n; ++it) step();
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = hi[i] + lo[i];
-    }
-    if constexpr (NEG) {                // (the lean short-group forms take non-negative exponents only: no division code in them)
-        if (e < 0) {
-            KEEP_BRANCH();
-#pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = 1.0 / x[i];
-        }
-    }
-}
-__device__ __forceinline__ double powi_dd(double x, int e) {
-    double v[1] = {x};
-    powi_dd_vec<1>(v, e);
-    return v[0];
-}
-
-// ---- f64 division / square root without the library's scaling and special-case code ----
-// 1/x for normal x: v_rcp_f64 (measured 2^-24.4 on gfx950, scripts/probe/rcp_rsq_probe.py) + one Newton step: <= 10 ulp
-// (2.2e-15).  Enough for sine_arc's quotients: their error only matters next to |x| = 1, where the closed forms are
-// ill-conditioned by themselves.
-__device__ __forceinline__ double rcp_newton1(double x) {
-    const double y = __builtin_amdgcn_rcp(x);
-    const double e = __fma_rn(-x, y, 1.0);
-    return __fma_rn(y, e, y);
-}
-// a / b given y ~ 1/b (Markstein): q0 = a*y, r = a - b*q0 exactly (fma), q = q0 + r*y.  With y the
-// CORRECTLY rounded reciprocal (the host's 1.0/n for a group length n) q is the correctly rounded
-// quotient — bit-identical to a true division (checked against exact rational arithmetic,
-// DESIGN.md §5); with a faithful y it is within 1 ulp.  v_div_fixup restores the IEEE results for
-// inf / NaN / zero operands.
-__device__ __forceinline__ double div_by_finite(double a, double b, double y) {   // finite a, normal b
-    const double q0 = a * y;
-    const double r = __fma_rn(-q0, b, a);
-    return __fma_rn(r, y, q0);
-}
-__device__ __forceinline__ double div_by(double a, double b, double y) {
-    return __builtin_amdgcn_div_fixup(div_by_finite(a, b, y), b, a);
-}
-// d = a * b + c as ONE three-address v_fma_f64 with the (wave-uniform) factor b in a scalar register pair and the addend in a
-// vector register: hipcc otherwise emits v_mov_b64 + v_fmac_f64 (the two-address form clobbers its addend).
-__device__ __forceinline__ double fma_vsv(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
-    return d;
-#else
-    return __builtin_fma(a, b, c);
-#endif
-}
-// a * b + c with the addend in scalar registers (three-address form: the compiler's v_fmac needs a v_mov of the constant first)
-__device__ __forceinline__ double fma_vvs(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
-    return d;
-#else
-    return __builtin_fma(a, b, c);
-#endif
-}
-// (k << n) + base in one instruction
-__device__ __forceinline__ uint32_t lshl_add(uint32_t base, uint32_t k, int n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t d;
-    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(k), "n"(n), "v"(base));
-    return d;
-#else
-    return (k << n) + base;
-#endif
-}
-// max(x, 0) / max(-x, 0) as one v_max_f64: the builtin first canonicalises an operand it cannot prove quiet (v_max x, x);
-// a NaN operand gives 0 either way (callers replace the value of a NaN window afterwards)
-__device__ __forceinline__ double max0(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_max_f64 %0, %1, 0" : "=v"(d) : "v"(x));
-    return d;
-#else
-    return x > 0.0 ? x : 0.0;
-#endif
-}
-// min(x, c) with the wave-uniform c in a scalar register pair, one instruction (no canonicalising v_max in front)
-__device__ __forceinline__ double min_vs(double x, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(c));
-    return d;
-#else
-    return x < c ? x : c;
-#endif
-}
-__device__ __forceinline__ double max0_neg(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_max_f64 %0, -%1, 0" : "=v"(d) : "v"(x));
-    return d;
-#else
-    return -x > 0.0 ? -x : 0.0;
-#endif
-}
-
-// ---- single-sine degree days (nb_kernels.py:202-251) ----
-// Both of the reference's closed forms are one function,
-//   arc(d, x) = d * acos(x) + alpha * sqrt(1 - x^2),            alpha = (tmax - tmin) / 2:
-//   cooling part, tmin < thr < tmax:  ((tavg - thr) * acos(z) + rng * sin(acos(z)) / 2) / pi,  z = (2 thr - tmax - tmin) / rng
-//                                     = arc(tavg - thr, z) / pi                       since sin(acos z) = sqrt(1 - z^2)
-//   heating part:  ((thr - tavg) * (atan(r / sqrt(1 - r^2)) + pi/2) + alpha * cos(atan(...))) / pi,  r = (thr - tavg) / alpha
-//                                     = arc(thr - tavg, -r) / pi                      since atan(r / sqrt(1 - r^2)) = asin(r),
-//                                       asin(r) + pi/2 = acos(-r) and cos(asin r) = sqrt(1 - r^2)
-// (|x| > 1 gives NaN in both forms, as in the reference).
-//
-// acos comes from a table instead of a polynomial (round 2 evaluated a degree-14 asin: 25 of the arc's 44 fp64 instructions;
-// C5 is bound by them).  With a = |x| and g = sqrt(1 - a^2) the smaller of the two, u = min(a, g) <= 0.7072, has
-//   asin(u) = phi_k + asin(delta),   k = round(256 u),  phi_k = asin(k / 256),  delta = sin(asin u - phi_k) = u cos(phi_k) - w sin(phi_k),
-//   w = max(a, g) = cos(asin u),  |delta| <= 0.0028   ->   asin(delta) = delta + delta^3 (1/6 + 3/40 delta^2)   (next term 5e-20)
-// and theta = acos(a) is asin(u) when g is the smaller one, pi/2 - asin(u) otherwise.  Both cases are one table row
-// (C, S, TH) per (half, k):  theta = TH + asin(u C + w S)   with
-//   a <= g:  C = -cos(phi_k), S = +sin(phi_k), TH = pi/2 - phi_k          a > g:  C = +cos(phi_k), S = -sin(phi_k), TH = phi_k
-// (host: afhip_api.hip:sine_table_host; 184 x 2 rows of 32 bytes, the two cases of a k next to each other, copied into LDS by
-// every workgroup of a sine_dd plan).
-// 11 fp64 + 3 integer instructions and two LDS reads.  Checked on the host against the reference's libm form by
-// scripts/fit/arc_table_emulation.py (1.9e-13 absolute on values of order 1-30) and on the device by scripts/sine_accuracy.py.
-constexpr int SINE_SCALE = 256;
-constexpr int SINE_ROWS = 184;                  // rows per half: k <= 181 for u <= 0.70711; the last rows are guards
-constexpr int SINE_TAB_BYTES = 2 * SINE_ROWS * 32;
-struct alignas(32) SineRow { double C, S, TH, pad; };
-typedef const __attribute__((address_space(3))) SineRow* sine_tab_t;
-
-// sqrt(q) for q in {0} U [2^-53, 1]: adding DBL_MIN leaves every q > 0 as it is, keeps q < 0 negative (rsq -> NaN: |x| > 1) and
-// makes the rsq of q = 0 finite, so that g = q * y = 0 needs no select.  v_rsq_f64 seed (2^-24.4 on gfx950,
-// scripts/probe/rcp_rsq_probe.py) + one coupled Goldschmidt step: 3e-15 relative — the arc's other terms carry more.
-__device__ __forceinline__ double sqrt_unit(double q) {
-    const double y = __builtin_amdgcn_rsq(q + 2.2250738585072014e-308);
-    const double g = q * y, h = 0.5 * y;
-    const double r = __fma_rn(-h, g, 0.5);
-    return __fma_rn(g, r, g);
-}
-// acos(a) for 0 <= a <= 1 given g = sqrt(1 - a^2).  CLAMP = false: the caller guarantees a <= 1 or NaN (pair mode: the arc is
-// only evaluated where the threshold lies strictly inside the window, so |thr - tavg| < alpha; a NaN a gives k = 0), and the row
-// index needs no bound; the generic form may be handed |r| up to 2 (the reference's heating form, NaN there) and keeps it.
-template <bool CLAMP = true>
-__device__ __forceinline__ double sine_theta(double a, double g, sine_tab_t tab) {
-    static_assert(SINE_SCALE == 256, "the index trick below adds 2^44 = 2^52 / 256");
-    const double u = __builtin_fmin(a, g), w = __builtin_fmax(a, g);
-    const double t = u + 17592186044416.0;                                      // + 2^44 (ulp 2^-8): the sum's low word is round(256 u)
-    uint32_t k = (uint32_t)__double2loint(t);
-    if (CLAMP) k = k < (uint32_t)(SINE_ROWS - 1) ? k : (uint32_t)(SINE_ROWS - 1);   // NaN / out-of-range operands stay inside the table
-    // the two cases of a k are neighbouring rows (row 2k: a <= g, row 2k + 1: a > g): row address = 64 k + base + (0 | 32)
-    const uint32_t base = (uint32_t)(uintptr_t)tab;
-    const uint32_t half = (a <= g) ? base : base + (uint32_t)sizeof(SineRow);       // (v_mov of the second base + v_cndmask)
-    sine_tab_t row = (sine_tab_t)(uintptr_t)lshl_add(half, k, 6);
-    const double C = row->C, S = row->S, TH = row->TH;
-    const double delta = __fma_rn(u, C, w * S);
-    const double t2 = delta * delta;
-    const double p = fma_vsv(t2, 0.075, 0.16666666666666666);
-    return __fma_rn(delta, __fma_rn(t2, p, 1.0), TH);            // TH + delta (1 + t2 p): four instructions from delta
-}
-__device__ __forceinline__ double sine_arc(double d, double x, double alpha, sine_tab_t tab) {
-    const double HALF_PI = 1.57079632679489661923;
-    const double a = fabs(x);
-    const double g = sqrt_unit(__fma_rn(-a, a, 1.0));          // 1 - a^2 with ONE rounding
-    const double th = sine_theta(a, g, tab);                   // acos(|x|)
-    const double ac = HALF_PI - copysign(HALF_PI - th, x);     // acos(x)
-    return __fma_rn(d, ac, alpha * g);
-}
-// (tmin, tmax) pairs: tavg is the mid-range, so z = r = (thr - tavg) / alpha =: d / alpha in both forms and, with a = |d| / alpha,
-//   cooling part = max(tavg - thr, 0) + [tmin < thr < tmax] alpha F(a),     heating part = max(thr - tavg, 0) + [..] alpha F(a),
-//   F(a) = (sqrt(1 - a^2) - a acos(a)) / pi        (F(-a) = F(a) + a folds the sign of z into the max() term;
-// the max() term alone is the reference's value on either side of the window).
-// F has ONE singularity on [0, 1], the (1 - a)^(3/2) branch point at a = 1:  F(a) = (1 - a)^(3/2) P2(a)  with P2 analytic for
-// |1 - a| < 2 — and nearly constant on [0, 1] (0.300 .. 0.318).  P2 is a table of cubics (scripts/fit/sine_p2_fit.py: mpmath,
-// Chebyshev nodes), so the arc is ONE square root and one 32-byte LDS row, where acos from sine_theta and g - a theta took 23 fp64 /
-// integer instructions (and the degree-14 asin of round 2, 44).  It is better conditioned, too: no cancellation g - a theta next
-// to a = 1.  Three layouts of the table were built in round 3: rows in a (centred cubics, 17 + rsq), rows in x = 4 (1 - a)
-// (absolute cubics, 13 + rsq) and — the one in the tree — rows in th = 2 sqrt(1 - a), 512 on [0, 2] (11 + rsq; sine_pair_g).
-constexpr int SINE_P2_N = 512;                                   // = AFHIP_SINE_P2_N of the generated table
-constexpr int SINE_P2_BYTES = (SINE_P2_N + 1) * 32 + 32;         // (+ a pad row: multiple of 64 bytes)
-struct alignas(32) SineP2Row { double c0, c1, c2, c3; };
-typedef const __attribute__((address_space(3))) SineP2Row* sine_p2_t;
-// max(x, DBL_MIN): 1 - a may come out 0 or a rounding error below it (a = |d| / alpha next to 1): t = sqrt(.) is then ~1e-154,
-// F = 0 — the limit — without a NaN from rsq; one v_max_f64 (a NaN operand would give DBL_MIN too: the cubic still carries it)
-__device__ __forceinline__ double max_tiny(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double d;
-    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(2.2250738585072014e-308));
-    return d;
-#else
-    return x > 2.2250738585072014e-308 ? x : 2.2250738585072014e-308;
-#endif
-}
-// one threshold strictly inside a (tmin, tmax) pair: alpha F(a) = u sqrt(om) P2(1 - om), u = alpha - |thr - tavg| in (0, alpha],
-// om = u / alpha = 1 - a — without the reciprocal of alpha: with rng = 2 alpha, u2 = 2 u and the seed z ~ rsq(u2 rng),
-//   th = u2 z (3 - (u2 rng) z^2) = 2 sqrt(om)   (one Newton step on the seed, in product form),   th^2 = 4 om,
-//   alpha F = (u2 th) H(th),   H(th) = P2(1 - th^2 / 4) / 4: cubic rows in th itself (scripts/fit/sine_p2_fit.py),
-// returned as the two factors w = su2 th and p = H(th).  11 VALU + rsq; `su2` is u2 carrying the sign the caller wants on the
-// product (only |su2| enters v and th); `rng` may come with either sign (the sine-only lean form hands over tmax - tmin of an UNORDERED
-// pair: only |rng| is read).
-__device__ __forceinline__ void sine_pair_g(double su2, double rng, sine_p2_t tab, double& w, double& p) {
-    static_assert(SINE_P2_N == 512, "the index trick adds 2^44 = 2^52 / 256");
-    double v;                                                    // |su2| rng + tiny: u may round to 0 (thr one ulp inside the window); rsq(0) = inf
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_fma_f64 %0, |%1|, |%2|, %3" : "=v"(v) : "v"(su2), "v"(rng), "s"(1e-300));
-#else
-    v = __builtin_fma(__builtin_fabs(su2), __builtin_fabs(rng), 1e-300);
-#endif
-    const double z = __builtin_amdgcn_rsq(v);
-    const double a = v * z;
-    const double e = __fma_rn(-a, z, 3.0);
-    const double th = (__builtin_fabs(su2) * z) * e;
-    // the table is indexed by th itself (H(th) = G(th^2), 512 cubics on [0, 2]: no x = th * th; the first table of round 3 was in x)
-    const double ti = th + 17592186044416.0;                     // + 2^44 (ulp 2^-8): the sum's low word is k = round(256 th)
-    const uint32_t k = (uint32_t)__double2loint(ti);
-    sine_p2_t row = (sine_p2_t)(uintptr_t)lshl_add((uint32_t)(uintptr_t)tab, k, 5);
-    const double c0 = row->c0, c1 = row->c1, c2 = row->c2, c3 = row->c3;
-    p = __fma_rn(__fma_rn(__fma_rn(c3, th, c2), th, c1), th, c0);
-    w = su2 * th;
-}
-// cooling part for one threshold (nb_kernels.py:224-236); alpha = rng / 2, inv_rng ~ 1 / rng (faithful; only read when `inside`)
-__device__ __forceinline__ double sine_cool(double thr, double thr2, bool inside, double tmin, double tmax, double tavg, double alpha,
-                                            double inv_rng, sine_tab_t tab) {
-    const double INV_PI = 0.31830988618379067154;
-    if (thr <= tmin) return tavg - thr;
-    if (inside) {
-        const double z = (thr2 - tmax - tmin) * inv_rng;         // thr2 = 2 thr; inf / NaN operands give NaN here too
-        return sine_arc(tavg - thr, z, alpha, tab) * INV_PI;
-    }
-    return 0.0;
-}
-// heating part (nb_kernels.py:238-249); inv_alpha ~ 2 / rng
-__device__ __forceinline__ double sine_heat(double thr, bool inside, double tmin, double tmax, double tavg, double alpha, double inv_alpha,
-                                            sine_tab_t tab) {
-    const double INV_PI = 0.31830988618379067154;
-    if (thr >= tmax) return thr - tavg;
-    if (inside) {
-        const double d = thr - tavg;
-        return sine_arc(d, -(d * inv_alpha), alpha, tab) * INV_PI;
-    }
-    return 0.0;
-}
-
-// acc += w on the lanes where t0 < v < t1 (strict; a NaN v fails both compares): the two
-// compares narrow EXEC directly (v_cmpx), the add runs under that mask and EXEC is put back —
-// 3 VALU ops, where compare + compare + a 64-bit select (2 x v_cndmask) + add takes 5.
-template <typename T>
-__device__ __forceinline__ void add_if_between(double& acc, double w, T v, T t0, T t1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long saved;
-    if constexpr (sizeof(T) == 4) {
-        asm("s_mov_b64 %[sv], exec\n\t"
-            "v_cmpx_lt_f32_e32 %[t0], %[v]\n\t"
-            "v_cmpx_gt_f32_e32 %[t1], %[v]\n\t"
-            "v_add_f64 %[acc], %[acc], %[w]\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [acc] "+v"(acc), [sv] "=&s"(saved)
-            : [w] "v"(w), [v] "v"(v), [t0] "s"(t0), [t1] "s"(t1)
-            : "vcc");
-    } else {
-        asm("s_mov_b64 %[sv], exec\n\t"
-            "v_cmpx_lt_f64_e32 %[t0], %[v]\n\t"
-            "v_cmpx_gt_f64_e32 %[t1], %[v]\n\t"
-            "v_add_f64 %[acc], %[acc], %[w]\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [acc] "+v"(acc), [sv] "=&s"(saved)
-            : [w] "v"(w), [v] "v"(v), [t0] "s"(t0), [t1] "s"(t1)
-            : "vcc");
-    }
-#else
-    acc += (v > t0 && v < t1) ? w : 0.0;
-#endif
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-// The plan tables (bounds, emit flags, chunk list) are read-only for the whole launch and
-// indexed by wave-uniform values.  Reading them through the constant address space makes
-// hipcc use scalar loads (s_load, counted on lgkmcnt), so no compiler-issued vector load —
-// and with it no compiler-inserted s_waitcnt vmcnt(0) — lands inside the streaming loop.
-template <typename T>
-__device__ __forceinline__ T ld_uniform(const T* p) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "scalar words only");
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
-#else
-    return *p;
-#endif
-}
-
-template <typename TIn, int VEC> struct RawVec;
-template <> struct alignas(8) RawVec<double, 1> { double v[1]; };
-template <> struct alignas(16) RawVec<double, 2> { double v[2]; };
-template <> struct alignas(4) RawVec<float, 1> { float v[1]; };
-template <> struct alignas(16) RawVec<float, 4> { float v[4]; };
-template <> struct alignas(8) RawVec<float, 2> { float v[2]; };
-
-// One lane's VEC cells of a row, read once: non-temporal loads keep the stream from
-// displacing the plan tables and partials in L2 / Infinity Cache.
-template <typename TIn, int VEC, int AUX>
-__device__ __forceinline__ RawVec<TIn, VEC> ld_stream(const TIn* p) {
-    RawVec<TIn, VEC> r;
-    if constexpr (AUX != 0) {
-        typedef TIn vec_t __attribute__((ext_vector_type(VEC)));
-        if constexpr (VEC == 1) {
-            r.v[0] = __builtin_nontemporal_load(p);
-        } else {
-            vec_t t = __builtin_nontemporal_load((const vec_t*)p);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) r.v[i] = t[i];
-        }
-    } else {
-        r = *(const RawVec<TIn, VEC>*)p;
-    }
-    return r;
-}
-
-// The same through a buffer descriptor on a UNIFORM row pointer + the lane's 32-bit byte offset: the address needs no vector
-// arithmetic at all (a global_load wants a 64-bit vector address: one v_lshl_add_u64 per load).
-template <typename TIn, int VEC, int AUX>
-__device__ __forceinline__ RawVec<TIn, VEC> ld_stream_row(const void* row, uint32_t voff) {
-    RawVec<TIn, VEC> r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(row), 0, -1, 0x00020000);
-    constexpr int aux = AUX != 0 ? 2 : 0;          // nt
-    constexpr int bytes = (int)sizeof(TIn) * VEC;
-    static_assert(bytes == 4 || bytes == 8 || bytes == 16, "one dword, two or four per lane");
-    if constexpr (bytes == 4) {
-        const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, aux);
-        __builtin_memcpy(&r, &t, 4);
-    } else if constexpr (bytes == 8) {
-        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, aux);
-        __builtin_memcpy(&r, &t, 8);
-    } else {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, aux);
-        __builtin_memcpy(&r, &t, 16);
-    }
-#endif
-    return r;
-}
+namespace afhip {
 
 // ---------------------------------------------------------------------------------------
 // k_fused_temporal

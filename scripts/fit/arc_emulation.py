@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host emulation (numpy float64) of the kernel's sine_arc closed form (afhip_kernels.h) against the reference's
+"""Host emulation (numpy float64) of the kernel's sine_arc closed form (afhip_sine.h) against the reference's
 acos / sin / atan / cos form (oracle.ref_temporal): checks the algebra and the error budget before a GPU run.
 The rsq seed is emulated with a relative error of 2^-23."""
 import sys, os

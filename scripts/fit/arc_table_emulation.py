@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host emulation (numpy float64) of round 3's table-driven sine arc (afhip_kernels.h: sine_theta / sine_arc) against the
+"""Host emulation (numpy float64) of round 3's table-driven sine arc (afhip_sine.h: sine_theta / sine_arc) against the
 reference's acos / sin / atan / cos closed forms (oracle.ref_temporal): checks the algebra and the error budget before a
 GPU run.  rcp / rsq seeds are emulated with a relative error of 2^-23.
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Accuracy of the gfx950 v_rcp_f64 / v_rsq_f64 seeds and of the Newton / Goldschmidt steps the kernels build on them
-(afhip_kernels.h: rcp_fast, sine_arc).  Compiles a scratch kernel with hipcc at run time; prints max relative errors."""
+(afhip_numerics.h: rcp_newton1; afhip_sine.h: sine_arc).  Compiles a scratch kernel with hipcc at run time; prints max relative errors."""
 import ctypes, os, subprocess, sys, tempfile
 import numpy as np
 import torch

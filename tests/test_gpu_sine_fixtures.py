@@ -4,7 +4,7 @@ tests/golden/make_sine_fixtures.py from the closed forms of `aggfly/aggregate/nb
 Every form the planner can pick is held to the SAME exact values, so an error is attributed to a side: the reference's
 libm arithmetic (restated in oracle/, see tests/test_oracle_golden.py::test_T4_oracle_against_the_50_digit_sine_fixtures:
 up to ~4e-9 relative next to the window's edges, 3e-14 of the window's scale) or this engine's (table acos, rsq + Newton,
-cubic arc tables — afhip_kernels.h: sine_theta / sine_pair_g / sine_column).
+cubic arc tables — afhip_sine.h: sine_theta / sine_pair_g; afhip_kernels.h: sine_column).
 
 Forms: the lean sine-only pair form (`_pair_ss`: BASELINE configs[4]'s kernel), the general pair form (`_pair`), the lean
 four-row form (`_pair_lean_quad`), and the generic group end (6-row windows; 2- and 4-row windows with the short-group
