@@ -387,3 +387,44 @@ def test_c5_sine_dd_tenth_degree_global(torch_cuda):
                                                              dict(inner="sine_dd", inner_args=(0, 18, 1), outer="sum")]).run(cube, csr)
         np.testing.assert_allclose(fast["res"].cpu().numpy(), out["res"].cpu().numpy(), rtol=1e-11, equal_nan=True)
         del csr, out
+
+
+def test_daily_panel_of_the_headline_columns_adds_up_to_the_annual_one(torch_cuda, monkeypatch):
+    """bench.py's DAILY row at its full size (hourly f32 on 215 x 1440, 3,100 regions, P = 365, K = 5; weighted sums per region formed
+    inside the streaming kernel at every period end): size-independent properties of a many-period panel —
+      * the numerators of the 365 daily periods add up to the annual plan's (the outer level is a plain sum over the days), and every
+        day's denominator is the year's (the NaN cells of this cube are the same every hour);
+      * the region-fused route and the per-cell route (AFHIP_NO_REGION_FUSED=1) agree to rounding on the whole panel;
+      * a sample of regions of the per-cell route's own output, entry by entry in table order (exact_order), like the other configs."""
+    torch = torch_cuda
+    _need(torch, 30)
+    import bench
+    cube = bench.make_cube(torch, T, NY, NX, torch.float32, 5)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    cube[:, torch.rand((NY, NX), generator=g, device="cuda") < 0.05] = float("nan")          # "ocean": NaN at every step
+    tab = synth.weights_table(NY, NX, 3100, seed=7, secondary=True, zero_frac=0.02)
+    R = int(tab["index_right"].max()) + 1
+    csr = hip.CSR(tab["index_right"].to_numpy(), tab["cell_id"].to_numpy(), tab["weight"].to_numpy(), R, C)
+    ib = synth.hourly_bounds(T)
+    G1 = len(ib) - 1
+    daily_cols = [dict(inner="dd", inner_args=(10, 30, 0))] + [dict(inner="mean", transform="pow", transform_arg=e) for e in (1, 2, 3, 4)]
+    annual_cols = [dict(c, outer="sum") for c in daily_cols]
+    daily = hip.FusedPlan(T, C, hip.F32, ib, np.arange(G1 + 1, dtype=np.int64), daily_cols)
+    out = daily.run(cube, csr)
+    assert "last-run=region-fused" in daily.describe(), daily.describe()
+    num, den, res = (out[k].cpu().numpy() for k in ("num", "den", "res"))               # [K, R, 365], [R, 365]
+    year = hip.FusedPlan(T, C, hip.F32, ib, np.array([0, G1], dtype=np.int64), annual_cols).run(cube, csr)
+    np.testing.assert_allclose(num.sum(axis=2), year["num"].cpu().numpy()[:, :, 0], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(den, np.repeat(year["den"].cpu().numpy(), G1, axis=1), rtol=1e-13)
+    monkeypatch.setenv("AFHIP_NO_REGION_FUSED", "1")
+    plain = hip.FusedPlan(T, C, hip.F32, ib, np.arange(G1 + 1, dtype=np.int64), daily_cols)
+    monkeypatch.delenv("AFHIP_NO_REGION_FUSED")
+    pc = plain.run(cube, csr)
+    assert "region-fused" not in plain.describe(), plain.describe()
+    np.testing.assert_allclose(num, pc["num"].cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(res, pc["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(den, pc["den"].cpu().numpy(), rtol=1e-13)
+    del out, pc
+    exact = hip.FusedPlan(T, C, hip.F32, ib, np.arange(G1 + 1, dtype=np.int64), daily_cols, exact_order=True).run(cube, csr, want_cells=True)
+    assert _check_sampled_regions(torch, exact, tab, R, 12, seed=8) == 12
+    np.testing.assert_allclose(res, exact["res"].cpu().numpy(), rtol=1e-12, equal_nan=True)
