@@ -280,12 +280,23 @@ static afhip_csr::RfTab* rf_table(afhip_csr* csr, int vec) {
                 }
             }
             int need = n_at > 0 ? 128 : 0;
+            // the lane a step reads (k_fused_temporal: dpp64): steps 0 - 3 the lane 1, 2, 4, 8 to the left inside its row of 16; step 4
+            // the last lane of the row before (rows 1 and 3); step 5 lane 31 (rows 2 and 3).  (AFHIP_RF_DPP=0 builds: l - 2^st.)
+            auto src_of = [](int st, int l) -> int {
+#if AFHIP_RF_DPP
+                if (st < 4) return (l & 15) >= (1 << st) ? l - (1 << st) : -1;
+                if (st == 4) return ((l >> 4) & 1) ? (l & ~15) - 1 : -1;
+                return l >= 32 ? 31 : -1;
+#else
+                return l >= (1 << st) ? l - (1 << st) : -1;
+#endif
+            };
             for (int st = 0; st < 6; ++st) {
-                const int d = 1 << st;
                 bool Fn[64];
                 for (int l = 0; l < 64; ++l) {
-                    if (l >= d && !F[l]) { bits[l] |= 1u << st; need |= 1 << st; }
-                    Fn[l] = F[l] || (l >= d && F[l - d]);
+                    const int sl = src_of(st, l);
+                    if (sl >= 0 && !F[l]) { bits[l] |= 1u << st; need |= 1 << st; }
+                    Fn[l] = F[l] || (sl >= 0 && F[sl]);
                 }
                 for (int l = 0; l < 64; ++l) F[l] = Fn[l];
             }

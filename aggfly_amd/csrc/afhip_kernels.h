@@ -187,6 +187,9 @@ namespace afhip {
 //
 // The workgroup size is a launch parameter (64 or 256 threads): waves never talk to each
 // other, so small grids are launched as single-wave workgroups for a finer tail.
+#ifndef AFHIP_RF_DPP
+#define AFHIP_RF_DPP 1             // the period end's scan moves its values by DPP (1) or by ds_bpermute (0: the Hillis-Steele steps of round 4's first forms)
+#endif
 #ifndef AFHIP_RF_WAVES
 #define AFHIP_RF_WAVES 1           // waves per SIMD the region-fused twins are compiled for (1 = no constraint)
 #endif
@@ -580,6 +583,31 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
             const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
             return __hiloint2double(hi, lo);
         };
+#if AFHIP_RF_DPP
+        // the scan's data movement as DPP moves (no LDS round trip): steps 0 - 3 shift by 1, 2, 4, 8 lanes inside each row of 16
+        // (row_shr), step 4 hands every row's last lane to the next row (row_bcast:15 -> rows 1 and 3), step 5 lane 31 to rows 2 and 3
+        // (row_bcast:31); `carried` is the whole wave shifted by one lane (wave_shr:1).  Lanes without a source keep 0 — they never add.
+        auto dpp64 = [&](double x, int st) -> double {
+            const int xl = __double2loint(x), xh = __double2hiint(x);
+            int lo, hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "=v"(lo));                             // (lanes a move does not write keep what the register held: no zeroing —
+            asm volatile("" : "=v"(hi));                             // they are the lanes that do not add at this step)
+#else
+            lo = hi = 0;
+#endif
+            switch (st) {
+                case 0: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x111, 0xf, 0xf, false); break;
+                case 1: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x112, 0xf, 0xf, false); break;
+                case 2: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x114, 0xf, 0xf, false); break;
+                case 3: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x118, 0xf, 0xf, false); break;
+                case 4: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x142, 0xa, 0xf, false); break;
+                case 5: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x143, 0xc, 0xf, false); break;
+                default: lo = __builtin_amdgcn_update_dpp(lo, xl, 0x138, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, xh, 0x138, 0xf, 0xf, false); break;
+            }
+            return __hiloint2double(hi, lo);
+        };
+#endif
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             int need = rf_need[e];
@@ -620,10 +648,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #pragma unroll
                 for (int st = 0; st < 6; ++st) {
                     if (!((need >> st) & 1)) continue;               // (uniform)
-                    const int addr = ((lane - (1 << st)) & 63) << 2;
                     double pv[CB];
+#if AFHIP_RF_DPP
+#pragma unroll
+                    for (int qq = 0; qq < CB; ++qq) pv[qq] = q0 + qq < NCOL ? dpp64(v[qq], st) : 0.0;
+#else
+                    const int addr = ((lane - (1 << st)) & 63) << 2;
 #pragma unroll
                     for (int qq = 0; qq < CB; ++qq) pv[qq] = q0 + qq < NCOL ? shfl64(v[qq], addr) : 0.0;
+#endif
                     if ((bits >> st) & 1u) {
                         KEEP_BRANCH();
 #pragma unroll
@@ -637,7 +670,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
                         const int addr = ((lane - 1) & 63) << 2;     // carried (unless the cell starts a stretch) + the cell
                         double carried[CB];
 #pragma unroll
+#if AFHIP_RF_DPP
+                        for (int qq = 0; qq < CB; ++qq) carried[qq] = q0 + qq < NCOL ? dpp64(v[qq], 6) : 0.0;
+#else
                         for (int qq = 0; qq < CB; ++qq) carried[qq] = q0 + qq < NCOL ? shfl64(v[qq], addr) : 0.0;
+#endif
                         if (end0) {
                             KEEP_BRANCH();
                             if (!fresh) {

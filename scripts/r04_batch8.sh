@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of two library builds on one box, alternating processes: the tree (period end with the column count opaque — no "column q exists" masks spilled to v_readlane — and the
-# step conditions formed once per entry) against the previous build (scripts/probe/_build/libaggfly_hip_prev.so = 3f700a0e616b)
+# A/B of two library builds on one box, alternating processes: the tree against the previous build (scripts/probe/_build/libaggfly_hip_prev.so = 3f700a0e616b);
+# first used for form 7 of the period end (fewer VALU: level), then for form 8 (the scan moves its values by DPP instead of ds_bpermute)
 mkdir -p gpurun_out/r04
 timeout -k 10 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fuzz.py -x -q -k "region_fused or rf or many_period or launch_shape" > gpurun_out/r04/batch8_tests.log 2>&1; tail -2 gpurun_out/r04/batch8_tests.log
 out=gpurun_out/r04/batch8.txt
