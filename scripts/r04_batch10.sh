@@ -5,7 +5,7 @@ timeout -k 10 400 python -m pytest tests/test_gpu_kernels.py -x -q -k "region_fu
 out=gpurun_out/r04/batch10.txt
 : > $out
 run() { echo "== [$LIBTAG] $*" >> $out; timeout -k 10 300 python scripts/r03_arms.py "$@" 2>&1 | grep -E '^\{' | cut -c1-330 >> $out; }
-for rep in 1 2 3; do
+for rep in 1 2; do
 for lib in main prev; do
   export LIBTAG=$lib
   if [ $lib = prev ]; then export AGGFLY_HIP_LIB=$PWD/scripts/probe/_build/libaggfly_hip_prev.so; else unset AGGFLY_HIP_LIB; fi
