@@ -16,6 +16,8 @@ for lib in main prev; do
   run --plan meanpoly --dtype f32 --T 1095 --ny 721 --nx 1440 --spd 3 --periods 365 --arms base
   run --plan meanpoly --dtype f64 --T 1460 --ny 721 --nx 1440 --spd 4 --periods 365 --arms base
   run --plan c2 --dtype f32 --periods 12 --arms base
+  run --plan meanpoly --dtype f32 --T 1460 --ny 721 --nx 1440 --spd 4 --periods 365 --arms base
+  run --plan meanpoly --dtype f32 --T 1460 --ny 1801 --nx 3600 --spd 4 --periods 12 --regions 40000 --arms base
 done; done
 python3 - <<'PY'
 import re
