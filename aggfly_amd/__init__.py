@@ -24,8 +24,11 @@ from .dataarray import DataArray  # noqa: F401
 from .dataset import Dataset, Grid  # noqa: F401
 from .io import dataset_from_path, dataset_to_zarr, zarr_from_path  # noqa: F401
 from .weights import (  # noqa: F401
+    CropWeights,
     GeoRegions,
     GridWeights,
+    PopWeights,
+    SecondaryWeights,
     crop_weights_from_path,
     georegions_from_gdf,
     georegions_from_path,

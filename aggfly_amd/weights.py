@@ -186,3 +186,14 @@ pop_weights_from_path = _cpu_side_only("pop_weights_from_path")
 crop_weights_from_path = _cpu_side_only("crop_weights_from_path")
 secondary_weights_from_path = _cpu_side_only("secondary_weights_from_path")
 shapefile_info = _cpu_side_only("shapefile_info")
+
+
+def _cpu_side_only_class(name):
+    init = _cpu_side_only(name)
+    return type(name, (), {"__init__": lambda self, *a, **k: init(*a, **k), "__doc__": f"`{name}` (aggfly/weights/): CPU-side, see the error it raises."})
+
+
+# ... and of its secondary-weights classes (`aggfly/__init__.py:14-17`): `from aggfly_amd import PopWeights` imports, constructing one points the same way
+SecondaryWeights = _cpu_side_only_class("SecondaryWeights")
+PopWeights = _cpu_side_only_class("PopWeights")
+CropWeights = _cpu_side_only_class("CropWeights")

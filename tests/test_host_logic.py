@@ -506,3 +506,21 @@ def test_kernel_menu_shape():
     assert info["abi"] == hip.ABI_VERSION and info["menu"] in ("full", "arms", "dev")
     if info["menu"] == "full":
         assert info["variants"] == len(full) and info["arms"] == 0 and info["region_fused_twins"] == len(twins)
+
+
+def test_every_name_the_reference_package_exports_exists_here():
+    """`aggfly/__init__.py:1-27` re-exports 27 names; a script written against it must import unchanged (`import aggfly_amd as af`).
+    The weights PRODUCERS (geopandas / rasterio work, CPU-side per the north_star) exist as names that point to the supported way in:
+    the cached table through `weights_from_objects(table=)` / `weights_from_feather`."""
+    names = ["TemporalAggregator", "SpatialAggregator", "aggregate_dataset", "aggregate_time", "aggregate_space", "distributed_client",
+             "is_distributed", "start_dask_client", "shutdown_dask_client", "Dataset", "Grid", "dataset_from_path", "dataset_to_zarr",
+             "zarr_from_path", "CropWeights", "PopWeights", "GridWeights", "SecondaryWeights", "weights_from_objects", "pop_weights_from_path",
+             "crop_weights_from_path", "secondary_weights_from_path", "GeoRegions", "georegions_from_path", "georegions_from_gdf", "shapefile_info"]
+    missing = [n for n in names if not hasattr(af, n)]
+    assert not missing, missing
+    for n in ("CropWeights", "PopWeights", "SecondaryWeights"):
+        with pytest.raises(NotImplementedError, match="weights_from_objects"):
+            getattr(af, n)("raster.tif")
+    for n in ("pop_weights_from_path", "crop_weights_from_path", "secondary_weights_from_path", "shapefile_info"):
+        with pytest.raises(NotImplementedError, match="weights_from_objects"):
+            getattr(af, n)("x")
