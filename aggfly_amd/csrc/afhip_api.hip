@@ -371,6 +371,7 @@ struct afhip_plan {
     int rf_layout = -1;                               // AFHIP_RF_LAYOUT=slot|run: layout of the run sums forced (rf_run_major)
     int rf_reduce_order = -1;                         // AFHIP_RF_REDUCE_ORDER=r|p: k_rf_reduce's (region, period) pairs region-major / period-major
     int slot_spmm_sub = 0, slot_spmm_order = -1;      // AFHIP_SLOT_SPMM_ORDER=v|p: SlotSpmmArgs::p_major forced off / on
+    int counts_spmm_sub = -1;                         // AFHIP_COUNTS_SPMM_SUB=0|4|8|16: lanes per (row, period) pair of the packed-count gather (0: one, table order)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     // per-launch profiling ring (afhip_plan_profile_*): event pairs around the temporal kernel
     std::vector<hipEvent_t> prof_ev;
@@ -1301,6 +1302,7 @@ extern "C" int afhip_plan_create(const afhip_plan_desc* desc, afhip_plan** out) 
     // experiment knobs, read once per plan (never on the run path)
     if (const char* e = getenv("AFHIP_XCD_REMAP")) pl->xcd_remap = atoi(e) ? 1 : 0;
     pl->counts_spmm = !getenv("AFHIP_NO_COUNTS_SPMM");
+    if (const char* e = getenv("AFHIP_COUNTS_SPMM_SUB")) pl->counts_spmm_sub = atoi(e);
     pl->no_slot_spmm = env_flag("AFHIP_NO_SLOT_SPMM");            // keep k_combine_slots + k_csr_spmm on every route
     pl->no_slots_divide = getenv("AFHIP_NO_SLOTS_DIVIDE") != nullptr;
     pl->no_counts_divide = getenv("AFHIP_NO_COUNTS_DIVIDE") != nullptr;
@@ -1652,10 +1654,27 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
         if (nq) {
             // rows that are never cut (exact order, or a table without long rows): the gather finishes the panel itself, no divide kernel
             divided = (exact || csr->n_split == 0) && nv == csr->R && !plan->no_counts_divide;
-            hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st,
-                               exact ? csr->indptr.p : csr->seg_ptr.p, exact ? (const int32_t*)nullptr : csr->seg_dst.p, csr->cols.p,
+            // lanes per pair: one (the table's order: `exact_order`), or a group of lanes over the row's entries with the pairs dealt period-major
+            // (one lane per pair leaves a job of few periods with few threads, each walking its row alone: annual bins on 3,100 county-sized
+            // regions 0.365 ms against 0.030 with sixteen lanes per pair; many periods turn it around — the group's lanes idle on short
+            // rows and every pair pays the group's adds: configs[3], 17 entries x 251 periods, 0.217 against 0.43.  Measured crossover:
+            // about as many periods as a row has entries; profiles/r04_counts_gather.txt)
+            const int64_t nnz_rows = csr->h_indptr.empty() ? 0 : csr->h_indptr.back();
+            const double entries = nv > 0 ? (double)nnz_rows / (double)nv : 0.0;
+            const int sub_rule = ((double)P < entries) ? (entries < 12.0 ? 8 : 16) : 0;
+            const int sub = exact ? 0 : (plan->counts_spmm_sub >= 0 ? plan->counts_spmm_sub : sub_rule);
+            const int64_t* ip = exact ? csr->indptr.p : csr->seg_ptr.p;
+            const int32_t* dr = exact ? (const int32_t*)nullptr : csr->seg_dst.p;
+            double* o_num = divided ? num_dev : (double*)nullptr; double* o_den = divided ? den_dev : (double*)nullptr; double* o_res = divided ? res_dev : (double*)nullptr;
+            if (sub == 4 || sub == 8 || sub == 16) {
+                const dim3 gr((unsigned)((nq * sub + WG - 1) / WG)), bl(WG);
+                if (sub == 4) hipLaunchKernelGGL((k_csr_spmm_counts_sub<4>), gr, bl, 0, st, ip, dr, csr->cols.p, csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk, o_num, o_den, o_res);
+                else if (sub == 8) hipLaunchKernelGGL((k_csr_spmm_counts_sub<8>), gr, bl, 0, st, ip, dr, csr->cols.p, csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk, o_num, o_den, o_res);
+                else hipLaunchKernelGGL((k_csr_spmm_counts_sub<16>), gr, bl, 0, st, ip, dr, csr->cols.p, csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk, o_num, o_den, o_res);
+            } else
+            hipLaunchKernelGGL(k_csr_spmm_counts, dim3((unsigned)((nq + WG - 1) / WG)), dim3(WG), 0, st, ip, dr, csr->cols.p,
                                csr->w.p, (const void*)partial, plan->d_slot_ptr.p, plan->sums, nv, P, (int)K, plan->desc.n_cells, plan->pk,
-                               divided ? num_dev : (double*)nullptr, divided ? den_dev : (double*)nullptr, divided ? res_dev : (double*)nullptr);
+                               o_num, o_den, o_res);
             HIP_TRY(hipGetLastError());
             if (!exact && csr->n_split) {
                 const int64_t n = csr->n_split * Q;

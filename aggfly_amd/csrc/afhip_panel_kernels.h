@@ -274,6 +274,87 @@ __global__ __launch_bounds__(WG) void k_csr_spmm_counts(const int64_t* __restric
     dst[K] = acc[MAX_COLS];
 }
 
+// k_csr_spmm_counts_sub: the same sums with SUB lanes per (row, period) pair, pairs dealt period-major.  k_csr_spmm_counts gives a
+// pair to ONE lane, whose 16-byte reads lie a slot (C records) from its neighbour lanes' — a 64-byte memory transaction per record
+// (configs[3]: 208 MB of records gathered at 0.94 TB/s, 0.22 of a 3.1 ms step).  Here the lanes of a group take the row's entries in
+// turn — neighbouring cells of one slot: neighbouring records — and the groups of a wave are neighbouring rows of one period; the
+// group's K + 1 partial sums are added by DPP (row_shr:1, 2, 4[, 8]: the group's last lane ends with the total).  The sums are a fixed
+// tree over the row's entries instead of the table's order (<= 1e-15 apart; `exact_order` plans keep k_csr_spmm_counts).
+template <int SUB>
+__global__ __launch_bounds__(WG) void k_csr_spmm_counts_sub(const int64_t* __restrict__ indptr, const int32_t* __restrict__ dst_row,
+                                                            const int32_t* __restrict__ cols,
+                                                            const double* __restrict__ w, const void* __restrict__ packed,
+                                                            const int32_t* __restrict__ slot_ptr, double* __restrict__ out,
+                                                            int64_t R, int64_t P, int K, int64_t C, const PackFmt pk,
+                                                            double* __restrict__ num, double* __restrict__ den, double* __restrict__ res) {
+    static_assert(SUB == 4 || SUB == 8 || SUB == 16, "a power-of-two share of a row of 16 lanes");
+    const int64_t n = R * P;
+    const int64_t first = ((int64_t)blockIdx.x * WG + (threadIdx.x & ~63)) / SUB;     // the wave's first pair
+    if (first >= n) return;                                            // whole waves leave together
+    const int64_t gid = ((int64_t)blockIdx.x * WG + threadIdx.x) / SUB;
+    const bool live = gid < n;                                         // (a last wave's spare groups redo the last pair, unstored)
+    const int64_t g = live ? gid : n - 1;
+    const int64_t p = g / R, r = g - p * R;                            // period-major: a wave = neighbouring rows of one period
+    const int sl = threadIdx.x & (SUB - 1);
+    const int s0 = slot_ptr[p], s1 = slot_ptr[p + 1];
+    double acc[MAX_COLS + 1];
+#pragma unroll
+    for (int k = 0; k <= MAX_COLS; ++k) acc[k] = 0.0;
+    if (s1 != s0) {                                                    // else: empty resample bin, every cell invalid
+        const int64_t j1 = indptr[r + 1];
+        for (int64_t j = indptr[r] + sl; j < j1; j += SUB) {
+            uint64_t q[4];
+            ld_record(packed, pk, s0, C, cols[j], q);
+            const double wj = w[j];
+            const bool valid = record_field(q, pk, 0) != pk.mask;
+#pragma unroll
+            for (int k = 0; k < MAX_COLS; ++k) {
+                if (k < K) {
+                    const double x = valid ? (double)record_field(q, pk, k) : 0.0;
+                    acc[k] = __dadd_rn(acc[k], __dmul_rn(wj, x));
+                }
+            }
+            acc[MAX_COLS] = __dadd_rn(acc[MAX_COLS], __dmul_rn(wj, valid ? 1.0 : 0.0));
+        }
+    }
+    // the group's lanes -> its last lane: acc += acc of the lane 1, 2, 4 (, 8) to the left (a group never straddles a row of 16 lanes)
+    auto shr = [&](double x, int st) -> double {
+        const int xl = __double2loint(x), xh = __double2hiint(x);
+        int lo, hi;
+        switch (st) {
+            case 0: lo = __builtin_amdgcn_update_dpp(0, xl, 0x111, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, xh, 0x111, 0xf, 0xf, true); break;
+            case 1: lo = __builtin_amdgcn_update_dpp(0, xl, 0x112, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, xh, 0x112, 0xf, 0xf, true); break;
+            case 2: lo = __builtin_amdgcn_update_dpp(0, xl, 0x114, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, xh, 0x114, 0xf, 0xf, true); break;
+            default: lo = __builtin_amdgcn_update_dpp(0, xl, 0x118, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, xh, 0x118, 0xf, 0xf, true); break;
+        }
+        return __hiloint2double(hi, lo);
+    };
+#pragma unroll
+    for (int st = 0; (1 << st) < SUB; ++st) {
+#pragma unroll
+        for (int k = 0; k <= MAX_COLS; ++k)
+            if (k < K || k == MAX_COLS) acc[k] = __dadd_rn(acc[k], shr(acc[k], st));
+    }
+    if (sl != SUB - 1 || !live) return;
+    if (res != nullptr) {
+        const int64_t RP = R * P, rp = r * P + p;
+        const double de = acc[MAX_COLS];
+        if (den) den[rp] = de;
+#pragma unroll
+        for (int k = 0; k < MAX_COLS; ++k) {
+            if (k >= K) continue;
+            if (num) num[(int64_t)k * RP + rp] = acc[k];
+            res[(int64_t)k * RP + rp] = (de != 0.0) ? acc[k] / de : nan64();
+        }
+        return;
+    }
+    double* dst = out + ((dst_row ? (int64_t)dst_row[r] : r) * P + p) * (K + 1);
+#pragma unroll
+    for (int k = 0; k < MAX_COLS; ++k)
+        if (k < K) dst[k] = acc[k];
+    dst[K] = acc[MAX_COLS];
+}
+
 // ---------------------------------------------------------------------------------------
 // k_csr_spmm: out[dst[v]][q] = sum_j w[j] * X[col[j]][q], j over row v = [indptr[v], indptr[v+1]) in table order (dst null:
 // v itself; rows may be segments of regions, see launch_spmm in afhip_api.hip).

@@ -340,7 +340,7 @@ def test_edge_shapes(torch_cuda):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dtype):
+def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, monkeypatch, dtype):
     """Contiguous equal-width bins take the per-lane LDS-histogram path.  Strict compares must
     survive it: values exactly ON an edge fall in no bin, values one ulp to either side fall in
     the neighbouring bins, NaN/inf fall nowhere — exactly as the reference's compare chain."""
@@ -414,8 +414,21 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, dty
     want4 = cport.block_bins(cube4, b4, dda).reshape(4, -1, 13)
     d_, p_ = plan4.run(d4, csr, want_cells=False), plan4.run(d4, csr, want_cells=True)
     np.testing.assert_array_equal(np.transpose(p_["cells"].cpu().numpy(), (1, 2, 0)), want4)
+    # (four periods, rows of a few dozen entries: the gather gives a (row, period) pair to a group of lanes and adds their shares in a
+    # fixed tree — k_csr_spmm_counts_sub, fewer periods than entries per row —, so it equals the table-order sums to rounding; with one
+    # lane per pair, AFHIP_COUNTS_SPMM_SUB=0, bit for bit; every group size the same numbers)
     for key in ("num", "den", "res"):
-        np.testing.assert_array_equal(d_[key].cpu().numpy(), p_[key].cpu().numpy(), err_msg=key)
+        np.testing.assert_allclose(d_[key].cpu().numpy(), p_[key].cpu().numpy(), rtol=1e-14, equal_nan=True, err_msg=key)
+    for sub in ("0", "4", "8", "16"):
+        monkeypatch.setenv("AFHIP_COUNTS_SPMM_SUB", sub)
+        ps = hip.FusedPlan(T4, ny * nx, code, b4, np.arange(5), cols)
+        monkeypatch.delenv("AFHIP_COUNTS_SPMM_SUB")
+        ds = ps.run(d4, csr, want_cells=False)
+        for key in ("num", "den", "res"):
+            if sub == "0":
+                np.testing.assert_array_equal(ds[key].cpu().numpy(), p_[key].cpu().numpy(), err_msg=key)
+            else:
+                np.testing.assert_allclose(ds[key].cpu().numpy(), p_[key].cpu().numpy(), rtol=1e-14, equal_nan=True, err_msg=key + sub)
     # shuffled slot order and a two-level use (daily mean + annual bins on raw hourly-like groups)
     perm = rng.permutation(13)
     plan2 = hip.FusedPlan(T, ny * nx, code, bounds, np.arange(4), [cols[i] for i in perm] + [dict(inner="mean")])
