@@ -636,8 +636,14 @@ extern "C" int afhip_read_probe(const void* cube_dev, int64_t T, int64_t row_byt
     if (blocks > 0x7fffffff) return fail(AFHIP_E_INVALID, "read_probe: rows too long for one launch");
     GUARD_DEVICE(pointer_device(cube_dev));
     hipStream_t st = (hipStream_t)stream;
+    // (a small grid gets time chunks, like the temporal kernel's launches: about 16 single-wave workgroups per CU in all, chunks of 64 rows and more)
+    int64_t chunks = 1;
+    { const int64_t want = (int64_t)16 * cu_count(pointer_device(cube_dev));
+      if (blocks < want) chunks = std::min<int64_t>(std::max<int64_t>(1, T / 64), std::min<int64_t>(65535, (want + blocks - 1) / blocks)); }
+    const int64_t rows_per_chunk = (T + chunks - 1) / chunks;
+    chunks = (T + rows_per_chunk - 1) / rows_per_chunk;
     uint32_t* out = nullptr;
-    HIP_TRY(hipMalloc((void**)&out, (size_t)lanes * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&out, (size_t)lanes * (size_t)chunks * sizeof(uint32_t)));
     std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
     int rc = AFHIP_OK;
     for (auto& e : ev)
@@ -645,7 +651,7 @@ extern "C" int afhip_read_probe(const void* cube_dev, int64_t T, int64_t row_byt
     if (!rc) {
         (void)hipEventRecord(ev[0], st);
         for (int i = 0; i < launches; ++i) {
-            hipLaunchKernelGGL(k_read_probe, dim3((unsigned)blocks), dim3(64), 0, st, (const uint32_t*)cube_dev, row_bytes / 4, T, out);
+            hipLaunchKernelGGL(k_read_probe, dim3((unsigned)blocks, (unsigned)chunks), dim3(64), 0, st, (const uint32_t*)cube_dev, row_bytes / 4, T, rows_per_chunk, out);
             (void)hipEventRecord(ev[(size_t)i + 1], st);
         }
         hipError_t e = hipGetLastError();

@@ -779,12 +779,16 @@ __global__ __launch_bounds__(WG) void k_place_box(const TE* __restrict__ src, TE
 // end: the fastest arm of scripts/probe/read_bw.hip's sweep over load width x depth x workgroup size x chunks x cache policy
 // (profiles/r03_read_ceiling.txt: 7.02 TB/s where 256-thread workgroups reach 6.69 and cached loads 6.23).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_read_probe(const uint32_t* __restrict__ base, int64_t row_dw, int64_t T, uint32_t* __restrict__ out) {
+// Small grids: like the temporal kernel, the launch cuts the time axis into blockIdx.y chunks of `rows_per_chunk` rows so that the card is full.
+__global__ __launch_bounds__(64) void k_read_probe(const uint32_t* __restrict__ base, int64_t row_dw, int64_t T_all, int64_t rows_per_chunk, uint32_t* __restrict__ out) {
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const int64_t lane = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t col = lane * 2;
     if (col >= row_dw) return;                                   // (whole lanes only: row_dw is even)
-    const uint32_t* p = base + col;
+    const int64_t k0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t T = (T_all - k0) < rows_per_chunk ? (T_all - k0) : rows_per_chunk;
+    const uint32_t* p = base + k0 * row_dw + col;
+    out += (int64_t)blockIdx.y * (row_dw / 2);
     uint32_t acc = 0;
     int64_t t = 0;
     for (; t + 4 <= T; t += 4) {

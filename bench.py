@@ -463,6 +463,13 @@ def run_other_configs(torch, steps=10, warmup=10):      # the first ~10 launches
                    "kernel": desc.split()[0].replace("variant=", "") + ("_rf" if "last-run=region-fused" in desc else ""), "spatial_route": route,
                    "kernel_ms_mean": k_ms, "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
                    "algorithmic_bytes_per_launch": T * C * elem, "regions": R, "nnz": int(csr.nnz)}
+            try:      # this box's bare read of the very cube the kernel just streamed (afhip_read_probe: 8 bytes per lane, single-wave workgroups, four
+                # rows in flight, no arithmetic — the arm tuned on the headline shape; a kernel whose launch suits its shape better can pass it)
+                pm = hip.read_probe(cube, 6)
+                bare = T * C * elem / (float(np.median(pm[1:])) * 1e-3) / 1e9
+                row.update({"bare_read_GBps": bare, "hbm_vs_bare_read": hbm / bare})
+            except Exception as e:      # a measuring aid must never take the row down with it
+                row["read_probe_error"] = f"{type(e).__name__}: {e}"
             try:      # PMC-measured HBM bytes per launch of this shape's kernel, where a counter pass over bench.py itself has been committed
                 te = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{c['name'].lower()}_{c['dtype']}_T{T}_C{C}")
                 if te:

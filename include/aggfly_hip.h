@@ -161,8 +161,8 @@ int afhip_transform(const void* x_dev, int x_dtype, int64_t n, int transform, do
 
 /* Measuring aid (no counterpart in the reference): the streaming-read ceiling of THIS box for a time-major cube — a kernel with the
  * temporal kernels' access pattern and no arithmetic (8 bytes per lane, single-wave workgroups, four non-temporal row loads in
- * flight) launched `launches` times back to back over cube_dev [T rows of row_bytes bytes, row_bytes % 8 == 0]; ms_out[i] = the
- * i-th launch's duration by HIP events.  Synchronises `stream`.  bench.py reports T * row_bytes / min(ms) beside the 8 TB/s spec peak. */
+ * flight; rows too short to fill the card are read in time chunks, as the temporal kernels do) launched `launches` times back to back over
+ * cube_dev [T rows of row_bytes bytes, row_bytes % 8 == 0]; ms_out[i] = the i-th launch's duration by HIP events.  Synchronises `stream`.  bench.py reports T * row_bytes / min(ms) beside the 8 TB/s spec peak. */
 int afhip_read_probe(const void* cube_dev, int64_t T, int64_t row_bytes, int launches, float* ms_out, void* stream);
 
 /* Ingestion helper (no counterpart in the reference, whose chunks are assembled by dask on the host,
