@@ -546,16 +546,17 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
 
 
 GPU_DECODE_AUTO_BYTES = 256 << 20                 # requests this large take the decode-in-HBM route ...
-GPU_DECODE_AUTO_BYTES_WHOLE_ROWS = 768 << 20      # ... or this large when every chunk holds whole time steps of the grid
+GPU_DECODE_AUTO_BYTES_WHOLE_ROWS = 256 << 20      # ... also when every chunk holds whole time steps of the grid (round 2: 768 MB; see _gpu_decodable)
 
 
 def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     """Blosc-1 chunks with LZ4 streams (lz4 / lz4hc), byte shuffle or none — what `afhip_lz4_decode_streams` takes; judged
     from the first chunk file's header.  ``AGGFLY_HIP_GPU_DECODE``: ``1`` always, ``0`` never, unset / ``auto``: for requests
     of `GPU_DECODE_AUTO_BYTES` decoded bytes or more — `GPU_DECODE_AUTO_BYTES_WHOLE_ROWS` for stores whose chunks hold whole time
-    steps of the grid: the host route is at its best on those (each chunk decodes straight into its rows of the slab; 40-53
-    GB/s), and the route's fixed ~6 ms (first read, last batch's kernels) only pay off on larger requests; on other chunk
-    grids it is ahead from 0.26 GB on (`profiles/r02_gpu_decode_small_requests.txt`).  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
+    steps of the grid.  The host route is at its best on those (each chunk decodes straight into its rows of the slab; 40-53 GB/s),
+    and round 2 kept them on it up to 768 MB; with round 4's equal batches and host-decoded tail the decode in HBM is ahead from
+    ~220 MB on (0.34 GB: 8.3 against 8.8 ms, 0.49 GB: 9.9 against 11.4, smooth fields 8.1 against 9.9 / 10.9 against 13.1;
+    `profiles/r04_ingest_batches.txt`); on other chunk grids it is ahead from 0.26 GB on (`profiles/r02_gpu_decode_small_requests.txt`).  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
     DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 48-85 GB/s this way against 32-53 GB/s with the decode on
     16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
     mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")

@@ -178,14 +178,14 @@ def test_float64_stores_decode_in_hbm(torch_cuda, tmp_path, monkeypatch):
 
 def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypatch):
     """No environment switch: a 306 MB request on a space-tiled store (>= `io.GPU_DECODE_AUTO_BYTES`) reads its chunk files as they
-    are and decodes them on the GPU — several batches in flight — and gives the source cube; the same cube in chunks of whole
-    time steps stays on the host threads up to `io.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS`; small windows do in either layout."""
+    are and decodes them on the GPU — several batches in flight — and gives the source cube; so does the same cube in chunks of whole
+    time steps (`io.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS`); small windows stay on the host threads in either layout."""
     from aggfly_amd import io as afio
     monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE", raising=False)
     monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "64")
     T, ny, nx = 24 * 130, 104, 236
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=11) + np.float32(273.15)
-    assert afio.GPU_DECODE_AUTO_BYTES <= cube.nbytes < afio.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS
+    assert afio.GPU_DECODE_AUTO_BYTES <= cube.nbytes and afio.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS <= cube.nbytes
     path = _store(tmp_path, "big.zarr", cube, {"time": 240, "latitude": 52, "longitude": 118})
     kinds = []
     real, real_packed = codec.decode_ranges, codec.read_packed
@@ -199,11 +199,17 @@ def test_large_request_decodes_in_hbm_by_default(torch_cuda, tmp_path, monkeypat
     small = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-01-09"))
     assert kinds[-1] == "blosc"                                      # a window of one row of chunks (24 MB): host threads
     np.testing.assert_array_equal(small.cube().cpu().numpy(), cube[48:216])
+    # the same cube in chunks of whole time steps: the same route from the same size on (round 2 kept such stores on the host threads up to
+    # 768 MB), with the last chunks — a fifth of the request here — decoded by the host threads while the compressed batches upload
     rows = _store(tmp_path, "rows.zarr", cube, {"time": 24, "latitude": ny, "longitude": nx})
     kinds.clear()
     got = af.dataset_from_path(rows, "t2m", lon_is_360=True, device="cuda")
-    assert set(kinds) == {"blosc"}, kinds
+    assert set(kinds[:-1]) == {"files as they are"} and kinds[-1] == "blosc", kinds
     np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)
+    kinds.clear()
+    small = af.dataset_from_path(rows, "t2m", lon_is_360=True, device="cuda", time_sel=slice("2001-01-03", "2001-02-09"))
+    assert set(kinds) == {"blosc"}, kinds                            # 90 MB: host threads
+    np.testing.assert_array_equal(small.cube().cpu().numpy(), cube[48:40 * 24])
 
 
 @pytest.mark.parametrize("shards", [None, {"time": 96, "latitude": 24, "longitude": 64}])

@@ -238,7 +238,7 @@ def test_gpu_decode_route_is_chosen_by_request_size(tmp_path, monkeypatch):
     af.dataset_to_zarr(ds, raw, var="v", compress=False)
     monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE", raising=False)
     za = afio.ZarrArray(os.path.join(lz4, "v"))                      # (the default chunks hold whole time steps of the grid)
-    assert not afio._gpu_decodable(za, 1 << 20) and not afio._gpu_decodable(za, afio.GPU_DECODE_AUTO_BYTES)
+    assert not afio._gpu_decodable(za, 1 << 20) and not afio._gpu_decodable(za, afio.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS - 1)
     assert afio._gpu_decodable(za, afio.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS)
     tiled = str(tmp_path / "t.zarr")
     af.dataset_to_zarr(ds, tiled, var="v", chunks={"time": 2, "latitude": 1, "longitude": 2})
