@@ -545,7 +545,7 @@ def array_to_device(za, device="cuda", threads: int = 16, slab_bytes: int = 128 
             pool.shutdown()
 
 
-GPU_DECODE_AUTO_BYTES = 256 << 20                 # requests this large take the decode-in-HBM route ...
+GPU_DECODE_AUTO_BYTES = 96 << 20                  # requests this large take the decode-in-HBM route (round 2: 256 MB) ...
 GPU_DECODE_AUTO_BYTES_WHOLE_ROWS = 256 << 20      # ... also when every chunk holds whole time steps of the grid (round 2: 768 MB; see _gpu_decodable)
 
 
@@ -556,7 +556,8 @@ def _gpu_decodable(za, request_bytes: int = 0) -> bool:
     steps of the grid.  The host route is at its best on those (each chunk decodes straight into its rows of the slab; 40-53 GB/s),
     and round 2 kept them on it up to 768 MB; with round 4's equal batches and host-decoded tail the decode in HBM is ahead from
     ~220 MB on (0.34 GB: 8.3 against 8.8 ms, 0.49 GB: 9.9 against 11.4, smooth fields 8.1 against 9.9 / 10.9 against 13.1;
-    `profiles/r04_ingest_batches.txt`); on other chunk grids it is ahead from 0.26 GB on (`profiles/r02_gpu_decode_small_requests.txt`).  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
+    `profiles/r04_ingest_batches.txt`); on other chunk grids (space-tiled 12 MB chunks) it is level at 50 MB and ahead from there
+    on (74 MB: 4.2 against 5.2 ms, 99 MB: 5.5 against 7.6; round 2 measured 0.26 GB on its pipeline).  Measured on MI355X (`profiles/r02_gpu_decode_by_ratio*.json`,
     DESIGN.md §8) the chunks of a 0.9-3.4 GB store reach HBM at 48-85 GB/s this way against 32-53 GB/s with the decode on
     16 host threads; a small request is over before the decode kernel's ~2 ms (one wave walks one stream) are."""
     mode = os.environ.get("AGGFLY_HIP_GPU_DECODE", "auto")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the decode-in-HBM route passes the host-thread route on stores whose chunks hold whole time steps (io.GPU_DECODE_AUTO_BYTES_WHOLE_ROWS): store -> HBM, best / median
-of 7 reads, both routes forced, request sizes from 0.1 to 1.2 GB (104 x 236 f32, 24-step chunks, Blosc-LZ4 + shuffle; FIELD=noisy|smooth|smooth_noise)."""
+of 7 reads, both routes forced, request sizes from 0.1 to 1.2 GB (104 x 236 f32, 24-step chunks — LAYOUT=tiled: 504 x 52 x 118 —, Blosc-LZ4 + shuffle; FIELD=noisy|smooth|smooth_noise)."""
 import os, sys, tempfile, time
 import numpy as np, pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ import aggfly_amd as af
 from aggfly_amd import synth
 
 ny, nx = 104, 236
-for hours in (1008, 1512, 2016, 2520, 3504, 5016, 8760, 12000):
+for hours in [int(h) for h in os.environ.get("HOURS_LIST", "1008,1512,2016,2520,3504,5016,8760,12000").split(",")]:
     T = hours
     arr = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=1) + np.float32(273.15)
     if os.environ.get("FIELD", "noisy") != "noisy":
@@ -22,7 +22,8 @@ for hours in (1008, 1512, 2016, 2520, 3504, 5016, 8760, 12000):
                                                                            "latitude": np.arange(ny) * 0.25, "longitude": np.arange(nx) * 0.25}), lon_is_360=False)
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
         store = os.path.join(d, "s.zarr")
-        af.dataset_to_zarr(ds, store, var="t2m", chunks={"time": 24, "latitude": ny, "longitude": nx}, compress="blosc")
+        chunks = {"time": 24, "latitude": ny, "longitude": nx} if os.environ.get("LAYOUT", "rows") == "rows" else {"time": 504, "latitude": 52, "longitude": 118}
+        af.dataset_to_zarr(ds, store, var="t2m", chunks=chunks, compress="blosc")
         fn = lambda: af.dataset_from_path(store, "t2m", lon_is_360=False, device="cuda")
         row = []
         for mode in ("1", "0"):

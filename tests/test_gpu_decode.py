@@ -128,7 +128,7 @@ def _store(tmp_path, name, cube, chunks, time=None):
 @pytest.mark.parametrize("layout", ["time_contiguous", "space_tiled", "whole_series_tiles"])
 def test_store_to_hbm_gpu_decode_equals_host_decode(torch_cuda, tmp_path, monkeypatch, layout):
     """`dataset_from_path(device="cuda")` on Blosc-LZ4 stores: with the chunks decoded in HBM (AGGFLY_HIP_GPU_DECODE=1; the
-    default for requests of 256 MB or more) or on the host threads (=0) the cube is the same, bit for bit — whole store,
+    default for requests of 96 MB or more — 256 MB where the chunks hold whole time steps) or on the host threads (=0) the cube is the same, bit for bit — whole store,
     time windows that start and end inside chunks; the GPU route never calls the host Blosc decoder."""
     T, ny, nx = 24 * 30, 40, 64
     cube = synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=3, ocean_frac=0.1, scattered_nan=40) + np.float32(273.15)

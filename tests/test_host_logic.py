@@ -228,7 +228,7 @@ def test_lat_and_time_windows_on_the_host_route(tmp_path):
 
 
 def test_gpu_decode_route_is_chosen_by_request_size(tmp_path, monkeypatch):
-    """`io._gpu_decodable`: Blosc-LZ4 stores take the decode-in-HBM route for requests of 256 MB or more, always with
+    """`io._gpu_decodable`: Blosc-LZ4 stores take the decode-in-HBM route for requests of 96 MB or more (256 MB where the chunks hold whole time steps), always with
     AGGFLY_HIP_GPU_DECODE=1, never with =0; other codecs never do."""
     from aggfly_amd import io as afio
     arr, time, lat, lon = gi.dataset_360_inputs()
