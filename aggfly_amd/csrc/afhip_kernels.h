@@ -400,7 +400,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #ifndef AFHIP_RF_CB
 #define AFHIP_RF_CB 2
 #endif
-    constexpr int RF_CB = AFHIP_RF_CB;                 // columns per block of the period end's scan (registers against overlap)
+    // columns per block of the period end's scan (registers against overlap).  The general two-cell forms of six columns take ONE (AFHIP_RF_SLIM):
+    // they are held by their bytes in flight, and with the weights re-read per block and the store addresses formed at the stores the twin fits six waves per SIMD
+#ifndef AFHIP_RF_SLIM
+#define AFHIP_RF_SLIM 1
+#endif
+    constexpr bool RF_SLIM = AFHIP_RF_SLIM && VEC == 2 && KMAX == 6 && !(FEAT & 128) && sizeof(TIn) == 4;
+    constexpr int RF_CB = RF_SLIM ? 1 : AFHIP_RF_CB;
     // The lane's weights and words are PARKED in LDS (a wave-private block behind the variant's other LDS: RF_LANE_BYTES per lane) and
     // read back at every period end: held in registers they cost the twins ten VGPRs for the whole kernel — 103 against the plain
     // variant's 74 on the float32 configs[1] plan, four waves per SIMD instead of six, for a kernel that is bound by bytes in flight.
@@ -616,17 +622,27 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
 #endif
             if (!(need & 128)) continue;                             // (uniform) no cell of this tile has an entry e
             const uint32_t bits = rb >> (16 * e), rid = rr >> (16 * e);
-            double rfw[VEC];                                         // the cells' weights for this entry, from the lane's parking block
+            double rfw0[VEC];                                        // the cells' weights for this entry, from the lane's parking block
+            if constexpr (!RF_SLIM) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) rfw[i] = *(const __attribute__((address_space(3))) double*)(rf_park + i * 16 + e * 8);
+                for (int i = 0; i < VEC; ++i) rfw0[i] = *(const __attribute__((address_space(3))) double*)(rf_park + i * 16 + e * 8);
+            }
             double* out0 = a.rf_out + (int64_t)at_slot * a.rf_slot_stride + (int64_t)rf_first[e] * a.rf_run_stride;
-            double* dst0 = out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride;           // where this lane's cells store, if they end a run
-            double* dst1 = out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride;
+            double* dst0_ = nullptr; double* dst1_ = nullptr;
+            if constexpr (!RF_SLIM) {
+                dst0_ = out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride;              // where this lane's cells store, if they end a run
+                dst1_ = out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride;
+            }
+#define dst0 (RF_SLIM ? out0 + (int64_t)(rid & 0xffu) * a.rf_run_stride : dst0_)
+#define dst1 (RF_SLIM ? out0 + (int64_t)((rid >> 8) & 0xffu) * a.rf_run_stride : dst1_)
             const bool joins = !((bits >> 7) & 1u), fresh = ((bits >> 6) & 1u) != 0u, end0 = ((bits >> 8) & 1u) != 0u, end1 = ((bits >> 9) & 1u) != 0u;
 #pragma unroll
             for (int q0 = 0; q0 < NCOL; q0 += CB) {                  // q: position in the column list (0 = the weight, q >= 1: val[q - 1])
                 if (q0 > K) continue;                                // (uniform: the block's first value column is val[q0 - 1])
                 double v[CB], p0[CB];
+                double rfw[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rfw[i] = RF_SLIM ? *(const __attribute__((address_space(3))) double*)(rf_park + i * 16 + e * 8) : rfw0[i];
 #pragma unroll
                 for (int qq = 0; qq < CB; ++qq) {
                     const int q = q0 + qq;
@@ -713,6 +729,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((FEAT & 2048
                 }
             }
         }
+#undef dst0
+#undef dst1
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("; rf_emit: end");
 #endif
