@@ -748,18 +748,10 @@ def _scatter_host_decode(job: _ScatterJob, threads: int, slab_bytes: int, post):
     return job.cube
 
 
-def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
-    """Blosc-LZ4 chunks cross PCIe compressed (DESIGN.md §8): per batch the host reads the chunk files as they are into a
-    page-locked slot and parses the containers into the record lists (`codec.blosc_lz4_plan`); one upload carries the
-    compressed bytes and the records; `hip.lz4_decode_streams` + `hip.unshuffle_blocks` decode on the slot's stream —
-    straight into the cube when every chunk of the batch holds whole time steps of the window, else into a staging
-    buffer that `job.place` empties.  The page-locked slot is free again when its upload is over; the device-side one
-    is handed from the kernels to the slot's next upload by an event."""
-    import torch
-    from . import codec, hip
-    za, device, cb, idxs, cube = job.za, job.device, job.cb, job.idxs, job.cube
-    bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
-    nblk = max(1, -(-cb // bsz))
+def _decode_batches(n_chunks: int, cb: int, nblk: int, whole_steps: bool):
+    """How `_scatter_gpu_decode` cuts a request of ``n_chunks`` chunks (``cb`` decoded bytes, ``nblk`` Blosc blocks each):
+    -> (cuts: batch boundaries over the chunks that cross PCIe compressed, per: chunks of the largest batch, n_tail: chunks at the
+    request's end that the host threads decode)."""
     # One stream of a chunk is decoded by one wave, start to end (~2 ms for a 64 KiB byte plane), and a batch of ~60 chunks of this
     # shape (9 k streams) fills the card's wave slots once: smaller batches take as long as that one, larger ones scale.  Equal
     # batches of ~144 MB decoded (at most 16 of them; 512 MB at most each) measured best on 0.34 / 0.86 / 3.4 GB stores — 9.2 / 15.6 /
@@ -775,23 +767,40 @@ def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
     tail_mb = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", "128"))
     tail_min = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB", "256")) << 20
     tail_pct = int(os.environ.get("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MAX_PCT", "20"))
-    n_tail = min(max((tail_mb << 20) // cb, 1 if tail_mb > 0 else 0), len(idxs) * tail_pct // 100) if len(idxs) * cb >= tail_min else 0
+    n_tail = min(max((tail_mb << 20) // cb, 1 if tail_mb > 0 else 0), n_chunks * tail_pct // 100) if n_chunks * cb >= tail_min else 0
     # (chunks of whole time steps only — measured +10 % there; space-tiled chunks and the converter's whole-series tiles go through the placement kernel either
     # way and measured 3 % behind with a host-decoded tail: 51.1 against 53.0, 43.2 against 44.6 GB/s; ..._MIN_MB=0, the tests' setting, lifts this too)
-    if not job.whole_steps and tail_min > 0:
+    if not whole_steps and tail_min > 0:
         n_tail = 0
-    all_idxs, idxs = idxs, idxs[:len(idxs) - n_tail]
-    total = len(idxs) * cb
+    n = n_chunks - n_tail                                 # chunks that cross PCIe compressed
+    total = n * cb
     n_batches = min(16, max(1, -(-total // (144 << 20))))
     batch_bytes = (int(env_mb) << 20) if env_mb else min(-(-total // n_batches), 512 << 20)
-    per = max(1, min(-(-batch_bytes // cb), 65535 // nblk, 4096, len(idxs)))
-    n_batches = -(-len(idxs) // per)
-    cuts = sorted(set(int(round(i * len(idxs) / n_batches)) for i in range(n_batches + 1)))
-    per = max(b - a for a, b in zip(cuts, cuts[1:]))
+    per = max(1, min(-(-batch_bytes // cb), 65535 // nblk, 4096, max(n, 1)))
+    n_batches = max(1, -(-n // per))
+    cuts = sorted(set(int(round(i * n / n_batches)) for i in range(n_batches + 1)))
+    per = max([b - a for a, b in zip(cuts, cuts[1:])] or [1])
     env_cuts = os.environ.get("AGGFLY_HIP_GPU_DECODE_CUTS")      # experiment knob: batch ends as fractions of the request, e.g. "0.1,0.5,0.9"
     if env_cuts:
-        cuts = sorted(set([0, len(idxs)] + [min(len(idxs), max(0, int(round(float(f) * len(idxs))))) for f in env_cuts.split(",")]))
+        cuts = sorted(set([0, n] + [min(n, max(0, int(round(float(f) * n)))) for f in env_cuts.split(",")]))
         per = max(b - a for a, b in zip(cuts, cuts[1:]))
+    return cuts, per, n_tail
+
+
+def _scatter_gpu_decode(job: _ScatterJob, threads: int, post):
+    """Blosc-LZ4 chunks cross PCIe compressed (DESIGN.md §8): per batch the host reads the chunk files as they are into a
+    page-locked slot and parses the containers into the record lists (`codec.blosc_lz4_plan`); one upload carries the
+    compressed bytes and the records; `hip.lz4_decode_streams` + `hip.unshuffle_blocks` decode on the slot's stream —
+    straight into the cube when every chunk of the batch holds whole time steps of the window, else into a staging
+    buffer that `job.place` empties.  The page-locked slot is free again when its upload is over; the device-side one
+    is handed from the kernels to the slot's next upload by an event."""
+    import torch
+    from . import codec, hip
+    za, device, cb, idxs, cube = job.za, job.device, job.cb, job.idxs, job.cube
+    bsz, tsz = getattr(za, "_blosc_geometry", (65536, 1))
+    nblk = max(1, -(-cb // bsz))
+    cuts, per, n_tail = _decode_batches(len(idxs), cb, nblk, job.whole_steps)
+    all_idxs, idxs = idxs, idxs[:len(idxs) - n_tail]
     # staging slots in flight: 4 (3 measured 7 % slower), 6 when every batch is one big chunk (the converter's 265 MB chunks)
     nstage = max(1, min(int(os.environ.get("AGGFLY_HIP_GPU_DECODE_SLOTS", "6" if per == 1 else "4")), len(cuts) - 1))
     cube_bytes = cube.view(torch.uint8).reshape(-1) if job.whole_steps else None

@@ -524,3 +524,37 @@ def test_every_name_the_reference_package_exports_exists_here():
     for n in ("pop_weights_from_path", "crop_weights_from_path", "secondary_weights_from_path", "shapefile_info"):
         with pytest.raises(NotImplementedError, match="weights_from_objects"):
             getattr(af, n)("x")
+
+
+def test_gpu_decode_batch_plan(monkeypatch):
+    """`io._decode_batches`: how a decode-in-HBM request is cut (profiles/r04_ingest_batches.txt): equal batches of ~144 MB decoded, at most 16
+    of them and 512 MB each, every chunk in exactly one batch or in the host-decoded tail; the tail (<= 128 MB, <= a fifth of the request) only
+    for requests of 256 MB and more on chunks of whole time steps; the knobs override."""
+    from aggfly_amd import io as afio
+    for k in ("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "AGGFLY_HIP_GPU_DECODE_CUTS", "AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", "AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB",
+              "AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MAX_PCT"):
+        monkeypatch.delenv(k, raising=False)
+    cb, nblk = 24 * 104 * 236 * 4, 37                                  # the BASELINE configs[0] store's chunks: 2.36 MB, 37 Blosc blocks
+    for n in (1, 3, 6, 100, 146, 365, 1460, 5000):
+        for whole in (True, False):
+            cuts, per, n_tail = afio._decode_batches(n, cb, nblk, whole)
+            assert cuts[0] == 0 and cuts[-1] == n - n_tail and cuts == sorted(set(cuts)), (n, cuts)
+            sizes = np.diff(cuts)
+            assert per == sizes.max() and sizes.max() - sizes.min() <= 1, (n, sizes)             # equal batches
+            assert len(sizes) <= 16 or per * cb >= 0.95 * (512 << 20), (n, len(sizes))           # at most 16, unless the 512 MB cap binds
+            assert per * cb <= (512 << 20) + cb
+            assert n_tail == (0 if (not whole or n * cb < (256 << 20)) else min((128 << 20) // cb, n // 5)), (n, whole, n_tail)
+    assert len(afio._decode_batches(365, cb, nblk, True)[0]) - 1 == 5 and afio._decode_batches(365, cb, nblk, True)[2] == 56    # 0.86 GB: 5 x 62 chunks + 56
+    assert len(afio._decode_batches(365, cb, nblk, False)[0]) - 1 == 6                                                          # space-tiled: 6 batches, no tail
+    big = 265 << 20                                                    # the converter's whole-series tiles: one chunk per batch, no tail
+    assert afio._decode_batches(6, big, 4200, False) == ([0, 1, 2, 3, 4, 5, 6], 1, 0)
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB", "0")   # (tests / the ingest fuzzer: a tail on small requests and tiled chunks too)
+    assert afio._decode_batches(10, cb, nblk, False)[2] == 2 and afio._decode_batches(10, cb, nblk, True)[2] == 2
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MB", "0")
+    assert afio._decode_batches(365, cb, nblk, True)[2] == 0
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_CUTS", "0.25,0.5")
+    assert afio._decode_batches(100, cb, nblk, True) == ([0, 25, 50, 100], 50, 0)
+    monkeypatch.delenv("AGGFLY_HIP_GPU_DECODE_CUTS")
+    monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_BATCH_MB", "1")
+    cuts, per, _ = afio._decode_batches(10, cb, nblk, True)
+    assert per == 1 and cuts == list(range(11))
