@@ -344,6 +344,7 @@ struct afhip_plan {
     const Variant* variant_rf = nullptr;   // its twin with the region-fused period ends compiled in (null: none in the menu)
     bool rf_plan_ok = false;               // the plan's columns and slots allow the route (the table decides the rest at run time)
     int last_route = 0;                    // 1: the last afhip_plan_run took the region-fused route (afhip_plan_describe tells)
+    int last_counts_lanes = -1;            // lanes per (row, period) pair of the last run's packed-count gather (1, 4, 8, 16; -1: it did not run)
     int64_t tiles = 0;
     int wg = WG;                          // threads per workgroup (64 for small grids, else 256)
     int hb_n = 0; double hb_c1 = 0, hb_c0 = 0;                          // LDS-histogram bins
@@ -1392,17 +1393,18 @@ extern "C" int afhip_plan_describe(const afhip_plan* plan, char* buf, int buf_le
     if (!plan) return 0;
     int64_t min_len = INT64_MAX, max_len = 0;
     for (auto& c : plan->chunks) { min_len = std::min(min_len, c.k_hi - c.k_lo); max_len = std::max(max_len, c.k_hi - c.k_lo); }
-    char tmp[1024];
+    char tmp[1024], cg[48] = "";
+    if (plan->last_counts_lanes > 0) snprintf(cg, sizeof cg, " last-run=count-gather/%d-lane", plan->last_counts_lanes);
     int n = snprintf(tmp, sizeof tmp,
                      "variant=%s pipe=%d vec=%d stat=%d slots=%d kmax=%d depth=%d | T=%lld cells=%lld K=%d G1=%lld P=%lld | "
-                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld%s | workspace=%.1f MiB%s",
+                     "wg=%d tiles=%lld chunks=%zu (steps %lld..%lld) out_slots=%lld%s%s | workspace=%.1f MiB%s",
                      plan->variant->name, plan->variant->pipe, plan->variant->vec, plan->variant->stat, plan->variant->nthr,
                      plan->variant->kmax, plan->variant->depth, (long long)plan->desc.T, (long long)plan->desc.n_cells,
                      plan->K, (long long)plan->desc.G1, (long long)plan->desc.P, plan->wg, (long long)plan->tiles, plan->chunks.size(),
                      (long long)(plan->chunks.empty() ? 0 : min_len), (long long)max_len, (long long)plan->n_slots,
                      plan->packed ? (plan->pk.nw == 2 ? " packed-counts16" : " packed-counts32")
                                   : (plan->last_route == 1 ? " last-run=region-fused" : (plan->rf_plan_ok ? " region-fused-capable" : "")),
-                     (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0),
+                     cg, (double)(plan->ws_partial + plan->ws_panel) / (1024.0 * 1024.0),
                      plan->last_ws == 1 ? " (caller-owned)" : (plan->last_ws == 2 ? " (plan-owned hipMalloc)" : ""));
     if (buf && buf_len > 0) snprintf(buf, buf_len, "%s", tmp);
     return n + 1;
@@ -1639,6 +1641,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
     if (prof) { HIP_TRY(hipEventRecord(plan->prof_ev[(size_t)(2 * plan->prof_count + 1)], st)); ++plan->prof_count; }
     if (kernel_ms) HIP_TRY(hipEventRecord(plan->ev[1], st));
     plan->last_route = rf ? 1 : 0;
+    plan->last_counts_lanes = -1;
     bool divided = false;           // the count gather wrote num / den / res itself
     if (rf) {
         // a region's runs added in run order -> sums[r][p][K + 1] (no pieces: rows [0, R) only)
@@ -1669,6 +1672,7 @@ extern "C" int afhip_plan_run(afhip_plan* plan, const void* cube_dev, const afhi
             const double entries = nv > 0 ? (double)nnz_rows / (double)nv : 0.0;
             const int sub_rule = ((double)P < entries) ? (entries < 12.0 ? 8 : 16) : 0;
             const int sub = exact ? 0 : (plan->counts_spmm_sub >= 0 ? plan->counts_spmm_sub : sub_rule);
+            plan->last_counts_lanes = (sub == 4 || sub == 8 || sub == 16) ? sub : 1;
             const int64_t* ip = exact ? csr->indptr.p : csr->seg_ptr.p;
             const int32_t* dr = exact ? (const int32_t*)nullptr : csr->seg_dst.p;
             double* o_num = divided ? num_dev : (double*)nullptr; double* o_den = divided ? den_dev : (double*)nullptr; double* o_res = divided ? res_dev : (double*)nullptr;

@@ -412,13 +412,24 @@ def test_bins_partition_uses_lds_histogram_and_is_exact_on_edges(torch_cuda, mon
     plan4 = hip.FusedPlan(T4, ny * nx, code, b4, np.arange(5), cols)
     assert "packed-counts32" in plan4.describe(), plan4.describe()
     want4 = cport.block_bins(cube4, b4, dda).reshape(4, -1, 13)
-    d_, p_ = plan4.run(d4, csr, want_cells=False), plan4.run(d4, csr, want_cells=True)
+    d_ = plan4.run(d4, csr, want_cells=False)
+    assert "last-run=count-gather/16-lane" in plan4.describe(), plan4.describe()          # four periods, rows of ~21 entries
+    p_ = plan4.run(d4, csr, want_cells=True)
     np.testing.assert_array_equal(np.transpose(p_["cells"].cpu().numpy(), (1, 2, 0)), want4)
     # (four periods, rows of a few dozen entries: the gather gives a (row, period) pair to a group of lanes and adds their shares in a
     # fixed tree — k_csr_spmm_counts_sub, fewer periods than entries per row —, so it equals the table-order sums to rounding; with one
     # lane per pair, AFHIP_COUNTS_SPMM_SUB=0, bit for bit; every group size the same numbers)
     for key in ("num", "den", "res"):
         np.testing.assert_allclose(d_[key].cpu().numpy(), p_[key].cpu().numpy(), rtol=1e-14, equal_nan=True, err_msg=key)
+    # ... and with more periods than a row has entries the gather keeps one lane per pair, the table's order (configs[3]: 17 entries, 251 periods)
+    b48 = np.arange(0, T4 + 1, 100, dtype=np.int64)
+    plan48 = hip.FusedPlan(T4, ny * nx, code, b48, np.arange(49), cols)
+    d48, p48 = plan48.run(d4, csr, want_cells=False), None
+    assert "last-run=count-gather/1-lane" in plan48.describe(), plan48.describe()
+    p48 = plan48.run(d4, csr, want_cells=True)
+    assert "count-gather" not in plan48.describe(), plan48.describe()
+    for key in ("num", "den", "res"):
+        np.testing.assert_array_equal(d48[key].cpu().numpy(), p48[key].cpu().numpy(), err_msg=key)
     for sub in ("0", "4", "8", "16"):
         monkeypatch.setenv("AFHIP_COUNTS_SPMM_SUB", sub)
         ps = hip.FusedPlan(T4, ny * nx, code, b4, np.arange(5), cols)
