@@ -350,7 +350,7 @@ def _torch_dtype(np_dtype):
     return table[name]
 
 
-_PINNED_STAGE = {}      # (nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
+_PINNED_STAGE = {}      # (thread, nbytes rounded up) -> [pinned uint8 tensors]: page-locking is slow, so it is done once per process
 _STAGED_DEVICES = set() # indices of the devices this process uploaded to through the staging buffers (`_pinned_stage`)
 
 
@@ -386,7 +386,9 @@ def _pinned_stage(nbytes: int, count: int, device=None):
         idx = None if device is None else torch.device(device).index
         _STAGED_DEVICES.add(int(torch.cuda.current_device() if idx is None else idx))
     size = 1 << max(20, (int(nbytes) - 1).bit_length())
-    bufs = _PINNED_STAGE.setdefault(size, [])
+    # (per calling thread: two threads that read stores at the same time — a worker per GPU in one process — must not stage through the same buffers)
+    import threading
+    bufs = _PINNED_STAGE.setdefault((threading.get_ident(), size), [])
     while len(bufs) < count:
         bufs.append(torch.empty(size, dtype=torch.uint8, pin_memory=True))
     return bufs[:count]

@@ -255,3 +255,33 @@ def test_chunk_of_another_geometry_sends_the_request_to_the_host_route(torch_cud
     got = af.dataset_from_path(path, "t2m", lon_is_360=True, device="cuda")
     assert "files as they are" in kinds and "blosc" in kinds, kinds   # started on the GPU route, finished on the host route
     np.testing.assert_array_equal(got.cube().cpu().numpy(), cube)
+
+
+def test_two_threads_read_stores_at_the_same_time(torch_cuda, tmp_path, monkeypatch):
+    """A process with a worker thread per job (or per GPU) reads stores concurrently: the page-locked staging buffers are cached per
+    thread (`io._pinned_stage`), so neither route's uploads of one read can carry the other's bytes."""
+    import threading
+    from aggfly_amd import io as afio
+    T, ny, nx = 24 * 20, 40, 64
+    cubes = [synth.temperature_cube(T, ny, nx, dtype=np.float32, seed=s, scattered_nan=10) + np.float32(273.15) for s in (21, 22)]
+    paths = [_store(tmp_path, f"s{i}.zarr", c, {"time": 24, "latitude": ny, "longitude": nx}) for i, c in enumerate(cubes)]
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE", mode)
+        monkeypatch.setenv("AGGFLY_HIP_GPU_DECODE_HOST_TAIL_MIN_MB", "0")
+        bad, stages = [], {}
+
+        def work(i):
+            try:
+                for _ in range(6):
+                    got = af.dataset_from_path(paths[i], "t2m", lon_is_360=True, device="cuda").cube().cpu().numpy()
+                    if not np.array_equal(got, cubes[i], equal_nan=True):
+                        bad.append(i)
+                stages[i] = {id(b) for (tid, _), bufs in afio._PINNED_STAGE.items() if tid == threading.get_ident() for b in bufs}
+            except Exception as e:      # noqa: BLE001
+                bad.append(repr(e))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in (0, 1)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not bad, bad
+        assert stages[0] and stages[1] and not (stages[0] & stages[1])
